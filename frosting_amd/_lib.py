@@ -1,0 +1,103 @@
+"""ctypes binding of libfrosting_rasterizer.so (include/frosting_rasterizer.h).
+
+There is no fallback: if the HIP library is missing or cannot be loaded the
+import-time / first-use error is fatal by design (a silent CPU or eager path
+would void every parity and performance claim).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libfrosting_rasterizer.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles on CPU-only hosts)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=out)
+    return LIB_PATH
+
+
+class RasterizerLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RasterizerLibraryError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C {CSRC}).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.frg_version.restype = i
+    L.frg_last_error.restype = C.c_char_p
+    L.frg_set_option.argtypes = [C.c_char_p, i]
+    L.frg_get_option.argtypes = [C.c_char_p]
+    L.frg_geometry_bytes.restype = sz
+    L.frg_geometry_bytes.argtypes = [i]
+    L.frg_image_bytes.restype = sz
+    L.frg_image_bytes.argtypes = [i, i]
+    L.frg_binning_bytes.restype = sz
+    L.frg_binning_bytes.argtypes = [i, i]
+    L.frg_backward_workspace_bytes.restype = sz
+    L.frg_backward_workspace_bytes.argtypes = [i, i]
+    L.frg_geometry_layout.argtypes = [i, vp]
+    L.frg_image_layout.argtypes = [i, i, vp]
+    L.frg_binning_layout.argtypes = [i, i, vp]
+    L.frg_mark_visible.restype = i
+    L.frg_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
+    L.frg_forward.restype = i
+    L.frg_forward.argtypes = [ALLOC_FN, ALLOC_FN, ALLOC_FN, vp,
+                              i, i, i, vp, i, i,
+                              vp, vp, vp, vp,
+                              vp, f, vp, vp,
+                              vp, vp, vp,
+                              f, f, i,
+                              vp, vp, i, vp]
+    L.frg_backward.restype = i
+    L.frg_backward.argtypes = [i, i, i, i, vp, i, i,
+                               vp, vp, vp,
+                               vp, f, vp, vp,
+                               vp, vp, vp,
+                               f, f, vp,
+                               vp, vp, vp, vp,
+                               vp, vp, vp, vp,
+                               vp, vp, vp, vp, vp,
+                               vp, sz, i, vp]
+    L.frg_mesh_raster_workspace_bytes.restype = sz
+    L.frg_mesh_raster_workspace_bytes.argtypes = [i, i]
+    L.frg_mesh_rasterize.restype = i
+    L.frg_mesh_rasterize.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().frg_last_error().decode("utf-8", "replace")
+
+
+def set_option(name: str, value: int) -> int:
+    return lib().frg_set_option(name.encode(), int(value))
+
+
+def get_option(name: str) -> int:
+    return lib().frg_get_option(name.encode())
+
+
+EXPORTED_SYMBOLS = [
+    "frg_version", "frg_last_error", "frg_mark_visible", "frg_forward", "frg_backward_workspace_bytes",
+    "frg_backward", "frg_set_option", "frg_get_option", "frg_geometry_bytes", "frg_image_bytes",
+    "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
+    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize",
+]

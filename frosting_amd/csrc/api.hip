@@ -1,0 +1,253 @@
+// C ABI of libfrosting_rasterizer.so (include/frosting_rasterizer.h): host-side
+// orchestration of the forward / backward kernel sequence on the caller's HIP
+// stream.  Mirrors the reference's Rasterizer::forward / backward control flow
+// (rasterizer_impl.cu:198-336, :340-434) -- one blocking 16-byte read-back for
+// num_rendered, everything else asynchronous.
+#include "../../include/frosting_rasterizer.h"
+#include "kernels.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+std::atomic<int> g_exact_blend{-1};
+
+int exact_blend()
+{
+    int v = g_exact_blend.load();
+    if (v < 0) {
+        const char* e = getenv("FROSTING_EXACT_BLEND");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_exact_blend.store(v);
+    }
+    return v;
+}
+
+// One pinned 16-byte landing pad per host thread for the counters read-back.
+frg::Counters* pinned_counters()
+{
+    thread_local frg::Counters* p = nullptr;
+    if (!p) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(frg::Counters), hipHostMallocDefault) != hipSuccess) p = nullptr;
+    }
+    return p;
+}
+
+#define FRG_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(FRG_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// debug mode: synchronise after every stage so a faulting kernel is attributed
+// (the reference's CHECK_CUDA, auxiliary.h:166-173)
+#define FRG_STAGE(call, name)                                                                               \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(stream);                                   \
+        if (e_ != hipSuccess) return fail(FRG_EHIP, "stage '%s' failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_fovx, float tan_fovy, float scale_modifier)
+{
+    (void)P;
+    frg::ViewParams vp;
+    vp.tan_fovx = tan_fovx; vp.tan_fovy = tan_fovy;
+    vp.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:222-223
+    vp.focal_x = width / (2.0f * tan_fovx);
+    vp.scale_modifier = scale_modifier;
+    vp.W = width; vp.H = height;
+    vp.gx = (width + FRG_TILE - 1) / FRG_TILE; vp.gy = (height + FRG_TILE - 1) / FRG_TILE;
+    vp.D = D; vp.M = M;
+    return vp;
+}
+
+}  // namespace
+
+extern "C" {
+
+int frg_version(void) { return 1; }
+const char* frg_last_error(void) { return g_err; }
+
+int frg_set_option(const char* name, int value)
+{
+    if (name && strcmp(name, "exact_blend") == 0) {
+        int old = exact_blend();
+        g_exact_blend.store(value ? 1 : 0);
+        return old;
+    }
+    return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
+}
+
+int frg_get_option(const char* name)
+{
+    if (name && strcmp(name, "exact_blend") == 0) return exact_blend();
+    return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
+}
+
+size_t frg_geometry_bytes(int P) { return frg::GeomState::carve(nullptr, P).bytes; }
+size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nullptr, width, height).bytes; }
+size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count).bytes; }
+size_t frg_backward_workspace_bytes(int P, int R)
+{
+    (void)P;
+    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_FLOATS * sizeof(float), 256);
+}
+
+void frg_geometry_layout(int P, long long* out)
+{
+    frg::GeomState s = frg::GeomState::carve(nullptr, P);
+    out[0] = (long long)(size_t)s.xydr; out[1] = (long long)(size_t)s.conic_opacity; out[2] = (long long)(size_t)s.rgb_clamped;
+    out[3] = (long long)(size_t)s.tiles_touched; out[4] = (long long)(size_t)s.point_offsets;
+}
+void frg_image_layout(int width, int height, long long* out)
+{
+    frg::ImageState s = frg::ImageState::carve(nullptr, width, height);
+    out[0] = (long long)(size_t)s.final_T; out[1] = (long long)(size_t)s.n_contrib; out[2] = (long long)(size_t)s.ranges;
+    out[3] = (long long)(size_t)s.tile_count;
+}
+void frg_binning_layout(int R, int max_tile_count, long long* out)
+{
+    frg::BinningState s = frg::BinningState::carve(nullptr, R, max_tile_count);
+    out[0] = (long long)(size_t)s.point_list; out[1] = (long long)(size_t)s.pairs;
+}
+
+int frg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* hip_stream)
+{
+    (void)projmatrix;  // the reference's frustum test only uses the view matrix (auxiliary.h:154)
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!means3D || !viewmatrix || !present) return fail(FRG_EINVAL, "null pointer");
+    FRG_HIP(frg::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
+                int P, int D, int M, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, int* radii, int debug, void* hip_stream)
+{
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (P < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
+    if (!out_color) return fail(FRG_EINVAL, "out_color is null");
+    if (P == 0) {  // rasterize_points.cu:68,81: zero image, background not applied
+        FRG_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), stream));
+        return 0;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background || !radii)
+        return fail(FRG_EINVAL, "null required pointer");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(FRG_EINVAL, "provide exactly one of shs / colors_precomp");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(FRG_EINVAL, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1)))
+        return fail(FRG_EINVAL, "SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(FRG_EINVAL, "null allocation callback");
+
+    const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+    const int T = vp.gx * vp.gy;
+
+    char* geom_chunk = geometry_alloc(user, frg_geometry_bytes(P));
+    char* img_chunk = image_alloc(user, frg_image_bytes(width, height));
+    if (!geom_chunk || !img_chunk) return fail(FRG_EALLOC, "allocation callback returned null");
+    const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
+    const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height);
+
+    FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
+
+    frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
+    FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess");
+    FRG_STAGE(frg::launch_scan(P, vp, g, img, stream), "scan");
+
+    // the single host synchronisation of the op (rasterizer_impl.cu:280-281)
+    frg::Counters* host = pinned_counters();
+    if (!host) return fail(FRG_EHIP, "hipHostMalloc failed");
+    FRG_HIP(hipMemcpyAsync(host, img.counters, sizeof(frg::Counters), hipMemcpyDeviceToHost, stream));
+    FRG_HIP(hipStreamSynchronize(stream));
+    const frg::Counters c = *host;
+    if (prefiltered && c.filtered)
+        return fail(FRG_EFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (c.num_rendered > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
+    const int R = (int)c.num_rendered;
+    const int max_tile = (int)c.max_tile_count;
+
+    char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, max_tile));
+    if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
+    const frg::BinningState b = frg::BinningState::carve(bin_chunk, R, max_tile);
+
+    if (R > 0) {
+        FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
+        FRG_STAGE(frg::launch_tile_sort(T, max_tile, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort");
+    } else {
+        // point_offsets must still be defined for backward
+        FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
+    }
+    if (exact_blend())
+        FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
+    else
+        FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
+    return R;
+}
+
+int frg_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 char* workspace, size_t workspace_bytes, int debug, void* hip_stream)
+{
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
+    if (P == 0) return FRG_OK;
+    if (!means3D || !radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background ||
+        !viewmatrix || !projmatrix || !campos)
+        return fail(FRG_EINVAL, "null required pointer");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return fail(FRG_EINVAL, "null gradient output");
+    if ((shs && !dL_dsh) || (scales && (!dL_dscale || !dL_drot || !rotations)))
+        return fail(FRG_EINVAL, "null gradient output for a provided input");
+    if (workspace_bytes < frg_backward_workspace_bytes(P, R) || !workspace)
+        return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_backward_workspace_bytes(P, R));
+    (void)colors_precomp;  // forward copied precomputed colours into the geometry state
+
+    const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+    const frg::GeomState g = frg::GeomState::carve(geom_buffer, P);
+    const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height);
+    const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
+    float* slots = reinterpret_cast<float*>(workspace);
+
+    if (exact_blend())
+        FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+    else
+        FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+
+    frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
+    frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
+    FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, stream), "preprocess_bwd");
+    return FRG_OK;
+}
+
+}  // extern "C"

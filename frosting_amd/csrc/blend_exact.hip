@@ -1,0 +1,27 @@
+// Blend kernels, EXACT arithmetic: reference operation order, no FMA contraction,
+// accurate expf.  Compiled with -ffp-contract=off as well.
+#pragma clang fp contract(off)
+#define FRG_EXACT true
+#include "blend_impl.h"
+#include "kernels.h"
+namespace frg {
+hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                const float* bg, float* out_color, hipStream_t s)
+{
+    const int T = vp.gx * vp.gy;
+    hipLaunchKernelGGL((blend_fwd_kernel<FRG_EXACT>), dim3(xcd_grid_blocks(T)), dim3(64), 0, s, T, vp.gx, vp.W, vp.H,
+                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,
+                       out_color);
+    return hipGetLastError();
+}
+
+hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                const float* bg, const float* dL_dpix, float* slots, hipStream_t s)
+{
+    const int T = vp.gx * vp.gy;
+    hipLaunchKernelGGL((blend_bwd_kernel<FRG_EXACT>), dim3(xcd_grid_blocks(T)), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H,
+                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,
+                       img.n_contrib, dL_dpix, slots, img.cutoff);
+    return hipGetLastError();
+}
+}  // namespace frg

@@ -1,0 +1,155 @@
+// Shared definitions for the gfx950 rasterizer kernels: scratch-state layout,
+// small device helpers, launch wrappers.  MI355X only (wave64, 256 CUs, 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define FRG_TILE 16
+#define FRG_TILE_PIX 256
+#define FRG_WAVE 64
+#define FRG_NUM_XCD 8
+#define FRG_SLOT_FLOATS 9   // per-instance backward partial: rgb(3) mean2D(2) conic(3) opacity(1)
+
+namespace frg {
+
+struct Dims {
+    int P, W, H, gx, gy, T;  // T = gx*gy tiles
+};
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- geometry chunk (per Gaussian, SoA of 16-byte records so the blend kernels
+// gather with one global_load_dwordx4 each) ---------------------------------
+struct GeomState {
+    float4* xydr;            // pixel x, pixel y, view depth, radius (as float, exact integer)
+    float4* conic_opacity;   // conic a, b, c, opacity          (forward.cu:253)
+    float4* rgb_clamped;     // r, g, b, clamp flags in the bit pattern of .w
+    uint32_t* tiles_touched;
+    uint32_t* point_offsets; // inclusive scan of tiles_touched (rasterizer_impl.cu:277)
+    uint32_t* block_sums;    // per-256-Gaussian block totals -> exclusive prefix
+    size_t bytes;
+    __host__ static GeomState carve(char* base, int P)
+    {
+        GeomState s;
+        size_t o = 0;
+        size_t Pp = (size_t)(P > 0 ? P : 1);
+        s.xydr = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
+        s.conic_opacity = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
+        s.rgb_clamped = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
+        s.tiles_touched = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
+        s.point_offsets = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
+        s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);
+        s.bytes = o;
+        return s;
+    }
+};
+
+// ---- image chunk ----------------------------------------------------------
+struct Counters {            // written by the scan kernel, 16 bytes read back by the host
+    uint32_t num_rendered;
+    uint32_t max_tile_count;
+    uint32_t filtered;       // prefiltered assertion (auxiliary.h:154-162)
+    uint32_t pad;
+};
+
+struct ImageState {
+    float* final_T;          // accum_alpha in the reference (rasterizer_impl.h:47)
+    uint32_t* n_contrib;
+    uint2* ranges;           // per tile [start,end) into point_list; (0,0) when empty
+    uint32_t* tile_count;    // zeroed every forward; counted by preprocess
+    uint32_t* tile_fill;     // zeroed every forward; scatter cursor
+    Counters* counters;      // zeroed every forward
+    uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
+    size_t zero_begin, zero_bytes;  // region [tile_count .. counters] cleared with one memset
+    size_t bytes;
+    __host__ static ImageState carve(char* base, int W, int H)
+    {
+        ImageState s;
+        size_t N = (size_t)W * H;
+        size_t T = (size_t)((W + FRG_TILE - 1) / FRG_TILE) * ((H + FRG_TILE - 1) / FRG_TILE);
+        size_t o = 0;
+        s.final_T = (float*)(base + o); o = align_up(o + N * 4, 256);
+        s.n_contrib = (uint32_t*)(base + o); o = align_up(o + N * 4, 256);
+        s.ranges = (uint2*)(base + o); o = align_up(o + T * 8, 256);
+        s.cutoff = (uint2*)(base + o); o = align_up(o + T * 8, 256);
+        s.zero_begin = o;
+        s.tile_count = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
+        s.tile_fill = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
+        s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
+        s.zero_bytes = o - s.zero_begin;
+        s.bytes = o;
+        return s;
+    }
+};
+
+// ---- binning chunk --------------------------------------------------------
+#define FRG_SORT_LDS_CAP 8192   // largest tile list sorted entirely in LDS
+struct BinningState {
+    uint32_t* point_list;    // sorted Gaussian indices, tile-major
+    uint2* pairs;            // (depth bits, index), tile-major, scatter order
+    uint2* pairs_tmp;        // ping-pong buffer, only when some tile exceeds the LDS capacity
+    size_t bytes;
+    __host__ static BinningState carve(char* base, int R, int max_tile_count)
+    {
+        BinningState s;
+        size_t Rr = (size_t)(R > 0 ? R : 1);
+        size_t o = 0;
+        s.point_list = (uint32_t*)(base + o); o = align_up(o + Rr * 4, 256);
+        s.pairs = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
+        s.pairs_tmp = nullptr;
+        if (max_tile_count > FRG_SORT_LDS_CAP) { s.pairs_tmp = (uint2*)(base + o); o = align_up(o + Rr * 8, 256); }
+        s.bytes = o;
+        return s;
+    }
+};
+
+// ---- per-view constants ------------------------------------------------------
+// Scalars travel by value; the matrices stay where the caller put them (device
+// memory, as in the reference) and are read through wave-uniform scalar loads.
+struct ViewParams {
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int W, H, gx, gy;
+    int D, M;   // active SH degree, coefficients per channel in memory
+};
+struct ViewMats {
+    float view[16];
+    float proj[16];
+    float campos[3];
+};
+__device__ __forceinline__ void load_view_mats(const float* __restrict__ view, const float* __restrict__ proj,
+                                               const float* __restrict__ campos, ViewMats& m)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) { m.view[i] = view[i]; m.proj[i] = proj[i]; }
+    m.campos[0] = campos[0]; m.campos[1] = campos[1]; m.campos[2] = campos[2];
+}
+
+// XCD-aware tile mapping: workgroup b runs on XCD b % 8 (observed dispatch
+// order); give every XCD a contiguous band of tile rows so that neighbouring
+// tiles -- which share most of their Gaussians -- hit the same 4 MiB L2.
+__device__ __forceinline__ int xcd_tile_of_block(int b, int T)
+{
+    const int per = T / FRG_NUM_XCD, rem = T % FRG_NUM_XCD;
+    const int xcd = b % FRG_NUM_XCD, k = b / FRG_NUM_XCD;
+    // XCDs [0,rem) own per+1 tiles, the rest own per tiles.
+    const int start = xcd * per + (xcd < rem ? xcd : rem);
+    const int mine = per + (xcd < rem ? 1 : 0);
+    if (k < mine) return start + k;
+    return -1;  // padding block of the rounded-up grid
+}
+__host__ inline int xcd_grid_blocks(int T) { return ((T + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD; }
+
+// float -> int exactly like the reference's C cast on the GPU (v_cvt_i32_f32).
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int max_radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1)
+{
+    // auxiliary.h:46-56 getRect, same float expressions and truncating casts
+    x0 = min(gx, max(0, f2i((px - max_radius) / FRG_TILE)));
+    y0 = min(gy, max(0, f2i((py - max_radius) / FRG_TILE)));
+    x1 = min(gx, max(0, f2i((px + max_radius + FRG_TILE - 1) / FRG_TILE)));
+    y1 = min(gy, max(0, f2i((py + max_radius + FRG_TILE - 1) / FRG_TILE)));
+}
+
+}  // namespace frg

@@ -1,0 +1,38 @@
+// Host-callable launchers, one per kernel translation unit (each TU is compiled
+// with the floating-point contraction mode its arithmetic contract needs).
+#pragma once
+#include "frg_common.h"
+
+namespace frg {
+
+struct FwdInputs {
+    const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *cam_pos;
+};
+
+hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
+                                 const ImageState& img, int prefiltered, hipStream_t s);
+hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, hipStream_t s);
+hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
+                          const BinningState& b, hipStream_t s);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
+
+hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
+                            uint32_t* point_list, hipStream_t stream);
+
+hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                  const float* bg, float* out_color, hipStream_t s);
+hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                 const float* bg, float* out_color, hipStream_t s);
+hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                  const float* bg, const float* dL_dpix, float* slots, hipStream_t s);
+hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                 const float* bg, const float* dL_dpix, float* slots, hipStream_t s);
+
+struct BwdOutputs {
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
+                                 const ImageState& img, const float* slots, const BwdOutputs& out, hipStream_t s);
+
+}  // namespace frg

@@ -1,0 +1,275 @@
+// Forward per-Gaussian stage, tile counting, scans and the tile-major scatter.
+//
+// Replaces (behaviour, not structure) the reference's K1-K3/K5:
+//   FORWARD::preprocess      forward.cu:155-256   -> preprocess_fwd_kernel
+//   cub InclusiveSum         rasterizer_impl.cu:277 -> block sums here + scan_kernel + scatter_kernel
+//   duplicateWithKeys        rasterizer_impl.cu:70-111  -> scatter_kernel (tile-major, no 64-bit keys)
+//   identifyTileRanges       rasterizer_impl.cu:116-138 -> scan_kernel (ranges from per-tile counts)
+// Instead of emitting (tile|depth) 64-bit keys Gaussian-major and radix-sorting
+// R of them globally, instances are counted per tile, scattered straight into
+// their tile's segment and each segment is depth-sorted in LDS (sort.hip).
+#include "gauss_math.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace frg {
+
+// wave64 inclusive scan with DPP-free shuffles (6 steps); fine for O(P) kernels.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < FRG_WAVE; d <<= 1) {
+        uint32_t n = __shfl_up(v, d, FRG_WAVE);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// One thread per Gaussian (forward.cu:155-256).  Memory-bound: 12+12+16+4 B in,
+// 192 B of SH for the visible ones, 48 B + 8 B out.
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
+                      const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
+                      const float* __restrict__ means3D, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const float* __restrict__ opacities,
+                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ colors_precomp,
+                      int* __restrict__ radii, float4* __restrict__ xydr, float4* __restrict__ conic_opacity,
+                      float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched,
+                      uint32_t* __restrict__ tile_count, uint32_t* __restrict__ block_sums,
+                      Counters* __restrict__ counters, int prefiltered)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    ViewMats vmx;
+    load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
+    uint32_t touched = 0;
+    int radius_i = 0;
+    if (idx < P) {
+        const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        const float4 p_hom = xform44(p, vmx.proj);
+        const float3 p_view = xform43(p, vmx.view);
+        const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+        const float p_projx = p_hom.x * p_w, p_projy = p_hom.y * p_w;
+        if (!(p_view.z <= 0.2f)) {  // near cull only (auxiliary.h:154)
+            float cov[6];
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov[i] = cov3D_precomp[6 * idx + i];
+            } else {
+                const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+                const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+                cov3d_from_scale_rot(s, vp.scale_modifier, q, cov);
+            }
+            const Ewa e = ewa_setup(p, vp.focal_x, vp.focal_y, vp.tan_fovx, vp.tan_fovy, vmx.view);
+            float ca, cb, cc;
+            ewa_cov2d(e, cov, ca, cb, cc);
+            ca += 0.3f; cc += 0.3f;
+            const float det = ca * cc - cb * cb;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float mid = 0.5f * (ca + cc);
+                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                const float px = ndc_to_pix(p_projx, vp.W), py = ndc_to_pix(p_projy, vp.H);
+                int x0, y0, x1, y1;
+                tile_rect(px, py, f2i(my_radius), vp.gx, vp.gy, x0, y0, x1, y1);
+                touched = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+                if (touched != 0) {
+                    radius_i = f2i(my_radius);
+                    float r = 0, g = 0, b = 0;
+                    uint32_t clamp_bits = 0;
+                    if (colors_precomp) {
+                        r = colors_precomp[3 * idx]; g = colors_precomp[3 * idx + 1]; b = colors_precomp[3 * idx + 2];
+                    } else {
+                        // forward.cu:20-71
+                        float dx = p.x - vmx.campos[0], dy = p.y - vmx.campos[1], dz = p.z - vmx.campos[2];
+                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                        dx = dx / len; dy = dy / len; dz = dz / len;
+                        float w[16];
+                        const int n = sh_weights(vp.D, dx, dy, dz, w);
+                        const float* sh = shs + (size_t)idx * vp.M * 3;
+                        float acc[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) acc[ch] = w[0] * sh[ch];
+                        if (n > 1) {
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                                acc[ch] = acc[ch] - w[1] * sh[3 + ch] + w[2] * sh[6 + ch] - w[3] * sh[9 + ch];
+                            if (n > 4) {
+#pragma unroll
+                                for (int i = 4; i < 9; i++)
+#pragma unroll
+                                    for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
+                                if (n > 9) {
+#pragma unroll
+                                    for (int i = 9; i < 16; i++)
+#pragma unroll
+                                        for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            acc[ch] += 0.5f;
+                            if (acc[ch] < 0) clamp_bits |= (1u << ch);
+                            acc[ch] = fmaxf(acc[ch], 0.0f);
+                        }
+                        r = acc[0]; g = acc[1]; b = acc[2];
+                    }
+                    xydr[idx] = make_float4(px, py, p_view.z, my_radius);
+                    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+                    rgb_clamped[idx] = make_float4(r, g, b, __uint_as_float(clamp_bits));
+                    // per-tile instance counts (replaces the key histogram of the global sort)
+                    for (int y = y0; y < y1; y++)
+                        for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * vp.gx + x], 1u);
+                }
+            }
+        } else if (prefiltered) {
+            counters->filtered = 1;  // auxiliary.h:156-160: reported by the host instead of __trap()
+        }
+        radii[idx] = radius_i;
+        tiles_touched[idx] = touched;
+    }
+    // block total of tiles_touched -> block_sums (first level of the offsets scan)
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t s = wave_incl_scan(touched, lane);
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Single workgroup: (a) exclusive scan of the per-block sums (in place), total ->
+// counters.num_rendered; (b) per-tile counts -> ranges [start,end), empty tiles
+// (0,0) exactly as the reference's memset + identifyTileRanges leave them
+// (rasterizer_impl.cu:310-317); max count -> counters.max_tile_count.
+__global__ void __launch_bounds__(1024)
+scan_kernel(int nblocks, uint32_t* __restrict__ block_sums, int T, const uint32_t* __restrict__ tile_count,
+            uint2* __restrict__ ranges, Counters* __restrict__ counters)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    __shared__ uint32_t maxc_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry_s = 0; maxc_s = 0; }
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        const int n = pass == 0 ? nblocks : T;
+        uint32_t local_max = 0;
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + tid;
+            const uint32_t v = i < n ? (pass == 0 ? block_sums[i] : tile_count[i]) : 0u;
+            local_max = max(local_max, v);
+            uint32_t inc = wave_incl_scan(v, lane);
+            if (lane == 63) wtot[wave] = inc;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; w++) woff += wtot[w];
+            const uint32_t carry = carry_s;
+            const uint32_t excl = carry + woff + inc - v;
+            if (i < n) {
+                if (pass == 0) block_sums[i] = excl;
+                else ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
+            }
+            __syncthreads();
+            if (tid == 1023) carry_s = carry + woff + inc;
+            __syncthreads();
+        }
+        if (pass == 0) {
+            if (tid == 0) { counters->num_rendered = carry_s; carry_s = 0; }
+        } else {
+            atomicMax(&maxc_s, local_max);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) counters->max_tile_count = maxc_s;
+}
+
+// One thread per Gaussian: finish the inclusive scan (point_offsets, identical to
+// the reference's cub InclusiveSum output) and scatter (depth bits, index) into
+// the Gaussian's tiles.  The order inside a tile segment is arbitrary here; the
+// LDS sort orders by (depth, index), which equals the reference's stable sort of
+// index-ordered keys (rasterizer_impl.cu:98-108, :303-308).
+__global__ void __launch_bounds__(256)
+scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float4* __restrict__ xydr,
+               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
+               uint32_t* __restrict__ point_offsets, const uint2* __restrict__ ranges,
+               uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t touched = idx < P ? tiles_touched[idx] : 0u;
+    __shared__ uint32_t wsum[4];
+    const uint32_t inc = wave_incl_scan(touched, lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = block_prefix[blockIdx.x];
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (idx >= P) return;
+    point_offsets[idx] = off + inc;
+    if (touched == 0) return;
+    const float4 g = xydr[idx];
+    int x0, y0, x1, y1;
+    tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
+    const uint2 rec = make_uint2(__float_as_uint(g.z), (uint32_t)idx);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const int t = y * gx + x;
+            const uint32_t pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
+            pairs[pos] = rec;
+        }
+}
+
+// rasterizer_impl.cu:54-66
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ viewmatrix,
+                    unsigned char* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float vm[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) vm[i] = viewmatrix[i];
+    const float3 pv = xform43(p, vm);
+    present[idx] = (pv.z <= 0.2f) ? 0 : 1;
+}
+
+// ---- host launchers -----------------------------------------------------------
+hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
+                                 const ImageState& img, int prefiltered, hipStream_t s)
+{
+    const int nb = (P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, s, P, vp, in.viewmatrix, in.projmatrix, in.cam_pos,
+                       in.means3D, in.scales, in.rotations, in.opacities, in.shs, in.cov3D_precomp, in.colors_precomp,
+                       radii, g.xydr, g.conic_opacity, g.rgb_clamped, g.tiles_touched, img.tile_count, g.block_sums,
+                       img.counters, prefiltered);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, hipStream_t s)
+{
+    const int nb = (P + 255) / 256;
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nb, g.block_sums, vp.gx * vp.gy, img.tile_count, img.ranges,
+                       img.counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
+                          const BinningState& b, hipStream_t s)
+{
+    const int nb = (P + 255) / 256;
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, P, vp.gx, vp.gy, radii, g.xydr, g.tiles_touched,
+                       g.block_sums, g.point_offsets, img.ranges, img.tile_fill, b.pairs);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+    return hipGetLastError();
+}
+
+}  // namespace frg

@@ -1,0 +1,264 @@
+// Per-Gaussian backward: deterministic reduction of the blend partials, then the
+// reference's K8 + K9 fused into one streaming kernel:
+//   computeCov2DCUDA   backward.cu:144-274   (conic -> cov2D -> cov3D and mean)
+//   preprocessCUDA bwd backward.cu:346-396   (projection path)
+//   computeColorFromSH backward.cu:20-139    (SH and view-direction path)
+//   computeCov3D bwd   backward.cu:278-341   (scale / quaternion)
+// Every gradient row is written exactly once (zeros for culled Gaussians), so the
+// caller does not pre-zero ~300 B/Gaussian as the reference must
+// (rasterize_points.cu:151-159).
+#include "gauss_math.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace frg {
+
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
+                      const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
+                      const float* __restrict__ means3D, const int* __restrict__ radii,
+                      const float* __restrict__ shs, const float* __restrict__ scales,
+                      const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                      const float4* __restrict__ xydr, const float4* __restrict__ rgb_clamped,
+                      const uint32_t* __restrict__ point_offsets, const uint2* __restrict__ cutoff,
+                      const float* __restrict__ slots,
+                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                      float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+                      float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    ViewMats vmx;
+    load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
+    const int radius = radii[idx];
+    float part[FRG_SLOT_FLOATS];
+#pragma unroll
+    for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool visible = radius > 0;
+    float3 mean = make_float3(0.f, 0.f, 0.f);
+    uint32_t clamp_bits = 0;
+    if (visible) {
+        mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        // ---- 1. sum this Gaussian's (tile) partials in emission order (y-major, x) ----
+        const float4 g = xydr[idx];
+        clamp_bits = __float_as_uint(rgb_clamped[idx].w);
+        int x0, y0, x1, y1;
+        tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
+        const uint32_t base = idx == 0 ? 0u : point_offsets[idx - 1];
+        const uint32_t dbits = __float_as_uint(g.z);
+        uint32_t s = base;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++, s++) {
+                // processed by the blend backward iff (depth, index) <= the tile's cutoff key
+                const uint2 cut = cutoff[y * vp.gx + x];
+                const bool in_prefix = dbits < cut.x || (dbits == cut.x && (uint32_t)idx <= cut.y);
+                if (!in_prefix) continue;
+                const float* sp = slots + (size_t)s * FRG_SLOT_FLOATS;
+#pragma unroll
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] += sp[c];
+            }
+        // ---- 2. computeCov2DCUDA (backward.cu:144-274) ----
+        float cov[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+            cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov);  // recomputed, bit-identical to forward
+        }
+        const float dLc0 = part[5], dLc1 = part[6], dLc3 = part[7];
+        const Ewa e = ewa_setup(mean, vp.focal_x, vp.focal_y, vp.tan_fovx, vp.tan_fovy, vmx.view);
+        float a, b, c;
+        ewa_cov2d(e, cov, a, b, c);
+        a += 0.3f; c += 0.3f;
+        const float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define T_(cc, rr) e.T[cc][rr]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dLc0 + 2 * b * c * dLc1 + (denom - a * c) * dLc3);
+            dL_dc = denom2inv * (-a * a * dLc3 + 2 * a * b * dLc1 + (denom - a * c) * dLc0);
+            dL_db = denom2inv * 2 * (b * c * dLc0 - (denom + 2 * b * b) * dLc1 + a * b * dLc3);
+            dcov[0] = (T_(0, 0) * T_(0, 0) * dL_da + T_(0, 0) * T_(1, 0) * dL_db + T_(1, 0) * T_(1, 0) * dL_dc);
+            dcov[3] = (T_(0, 1) * T_(0, 1) * dL_da + T_(0, 1) * T_(1, 1) * dL_db + T_(1, 1) * T_(1, 1) * dL_dc);
+            dcov[5] = (T_(0, 2) * T_(0, 2) * dL_da + T_(0, 2) * T_(1, 2) * dL_db + T_(1, 2) * T_(1, 2) * dL_dc);
+            dcov[1] = 2 * T_(0, 0) * T_(0, 1) * dL_da + (T_(0, 0) * T_(1, 1) + T_(0, 1) * T_(1, 0)) * dL_db + 2 * T_(1, 0) * T_(1, 1) * dL_dc;
+            dcov[2] = 2 * T_(0, 0) * T_(0, 2) * dL_da + (T_(0, 0) * T_(1, 2) + T_(0, 2) * T_(1, 0)) * dL_db + 2 * T_(1, 0) * T_(1, 2) * dL_dc;
+            dcov[4] = 2 * T_(0, 2) * T_(0, 1) * dL_da + (T_(0, 1) * T_(1, 2) + T_(0, 2) * T_(1, 1)) * dL_db + 2 * T_(1, 1) * T_(1, 2) * dL_dc;
+        }
+        const float V[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+#define TV_(rw, k) (T_(rw, 0) * V[k][0] + T_(rw, 1) * V[k][1] + T_(rw, 2) * V[k][2])
+        const float dL_dT00 = 2 * TV_(0, 0) * dL_da + TV_(1, 0) * dL_db;
+        const float dL_dT01 = 2 * TV_(0, 1) * dL_da + TV_(1, 1) * dL_db;
+        const float dL_dT02 = 2 * TV_(0, 2) * dL_da + TV_(1, 2) * dL_db;
+        const float dL_dT10 = 2 * TV_(1, 0) * dL_dc + TV_(0, 0) * dL_db;
+        const float dL_dT11 = 2 * TV_(1, 1) * dL_dc + TV_(0, 1) * dL_db;
+        const float dL_dT12 = 2 * TV_(1, 2) * dL_dc + TV_(0, 2) * dL_db;
+#undef TV_
+#undef T_
+#define W_(k, rr) vmx.view[4 * (rr) + (k)]
+        const float dL_dJ00 = W_(0, 0) * dL_dT00 + W_(0, 1) * dL_dT01 + W_(0, 2) * dL_dT02;
+        const float dL_dJ02 = W_(2, 0) * dL_dT00 + W_(2, 1) * dL_dT01 + W_(2, 2) * dL_dT02;
+        const float dL_dJ11 = W_(1, 0) * dL_dT10 + W_(1, 1) * dL_dT11 + W_(1, 2) * dL_dT12;
+        const float dL_dJ12 = W_(2, 0) * dL_dT10 + W_(2, 1) * dL_dT11 + W_(2, 2) * dL_dT12;
+#undef W_
+        const float h_x = vp.focal_x, h_y = vp.focal_y;
+        const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dL_dtx = e.xmul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = e.ymul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * e.t[0]) * tz3 * dL_dJ02 + (2 * h_y * e.t[1]) * tz3 * dL_dJ12;
+        const float* vm = vmx.view;
+        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+        // ---- 3. projection path (backward.cu:367-387) ----
+        const float* proj = vmx.proj;
+        const float4 m_hom = xform44(mean, proj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        const float g2x = part[3], g2y = part[4];
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    }
+    // screen-space outputs (also returned to the caller: viewspace gradients)
+    dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
+    *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
+    dL_dopacity[idx] = part[8];
+    dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2];
+
+    // ---- 4. SH path (backward.cu:20-139) ----
+    if (shs) {
+        float* out = dL_dsh + (size_t)idx * vp.M * 3;
+        if (!visible) {
+            for (int i = 0; i < vp.M * 3; i++) out[i] = 0.0f;
+        } else {
+            const float* sh = shs + (size_t)idx * vp.M * 3;
+            const float dox = mean.x - vmx.campos[0], doy = mean.y - vmx.campos[1], doz = mean.z - vmx.campos[2];
+            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+            const float x = dox / len, y = doy / len, z = doz / len;
+            float dRGB[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
+            float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
+            const int deg = vp.D;
+#define SH_(i, ch) sh[(i) * 3 + (ch)]
+#define OUT_(i, wgt) { _Pragma("unroll") for (int ch = 0; ch < 3; ch++) out[(i) * 3 + ch] = (wgt) * dRGB[ch]; }
+            OUT_(0, kSH0);
+            int written = 1;
+            if (deg > 0) {
+                const float w1 = -kSH1 * y, w2 = kSH1 * z, w3 = -kSH1 * x;
+                OUT_(1, w1); OUT_(2, w2); OUT_(3, w3);
+                written = 4;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    ddx[ch] = -kSH1 * SH_(3, ch); ddy[ch] = -kSH1 * SH_(1, ch); ddz[ch] = kSH1 * SH_(2, ch);
+                }
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    const float w4 = kSH2[0] * xy, w5 = kSH2[1] * yz, w6 = kSH2[2] * (2.f * zz - xx - yy);
+                    const float w7 = kSH2[3] * xz, w8 = kSH2[4] * (xx - yy);
+                    OUT_(4, w4); OUT_(5, w5); OUT_(6, w6); OUT_(7, w7); OUT_(8, w8);
+                    written = 9;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        ddx[ch] += kSH2[0] * y * SH_(4, ch) + kSH2[2] * 2.f * -x * SH_(6, ch) + kSH2[3] * z * SH_(7, ch) + kSH2[4] * 2.f * x * SH_(8, ch);
+                        ddy[ch] += kSH2[0] * x * SH_(4, ch) + kSH2[1] * z * SH_(5, ch) + kSH2[2] * 2.f * -y * SH_(6, ch) + kSH2[4] * 2.f * -y * SH_(8, ch);
+                        ddz[ch] += kSH2[1] * y * SH_(5, ch) + kSH2[2] * 2.f * 2.f * z * SH_(6, ch) + kSH2[3] * x * SH_(7, ch);
+                    }
+                    if (deg > 2) {
+                        const float w9 = kSH3[0] * y * (3.f * xx - yy), w10 = kSH3[1] * xy * z;
+                        const float w11 = kSH3[2] * y * (4.f * zz - xx - yy), w12 = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                        const float w13 = kSH3[4] * x * (4.f * zz - xx - yy), w14 = kSH3[5] * z * (xx - yy);
+                        const float w15 = kSH3[6] * x * (xx - 3.f * yy);
+                        OUT_(9, w9); OUT_(10, w10); OUT_(11, w11); OUT_(12, w12); OUT_(13, w13); OUT_(14, w14); OUT_(15, w15);
+                        written = 16;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            ddx[ch] += (kSH3[0] * SH_(9, ch) * 3.f * 2.f * xy + kSH3[1] * SH_(10, ch) * yz + kSH3[2] * SH_(11, ch) * -2.f * xy +
+                                        kSH3[3] * SH_(12, ch) * -3.f * 2.f * xz + kSH3[4] * SH_(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                                        kSH3[5] * SH_(14, ch) * 2.f * xz + kSH3[6] * SH_(15, ch) * 3.f * (xx - yy));
+                            ddy[ch] += (kSH3[0] * SH_(9, ch) * 3.f * (xx - yy) + kSH3[1] * SH_(10, ch) * xz +
+                                        kSH3[2] * SH_(11, ch) * (-3.f * yy + 4.f * zz - xx) + kSH3[3] * SH_(12, ch) * -3.f * 2.f * yz +
+                                        kSH3[4] * SH_(13, ch) * -2.f * xy + kSH3[5] * SH_(14, ch) * -2.f * yz +
+                                        kSH3[6] * SH_(15, ch) * -3.f * 2.f * xy);
+                            ddz[ch] += (kSH3[1] * SH_(10, ch) * xy + kSH3[2] * SH_(11, ch) * 4.f * 2.f * yz +
+                                        kSH3[3] * SH_(12, ch) * 3.f * (2.f * zz - xx - yy) + kSH3[4] * SH_(13, ch) * 4.f * 2.f * xz +
+                                        kSH3[5] * SH_(14, ch) * (xx - yy));
+                        }
+                    }
+                }
+            }
+#undef SH_
+#undef OUT_
+            for (int i = written * 3; i < vp.M * 3; i++) out[i] = 0.0f;  // coefficients above the active degree
+            const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
+            const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
+            const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+            // auxiliary.h:107-117 dnormvdv
+            const float sum2 = dox * dox + doy * doy + doz * doz;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((+sum2 - dox * dox) * dd0 - doy * dox * dd1 - doz * dox * dd2) * invsum32;
+            dmean[1] += (-dox * doy * dd0 + (sum2 - doy * doy) * dd1 - doz * doy * dd2) * invsum32;
+            dmean[2] += (-dox * doz * dd0 - doy * doz * dd1 + (sum2 - doz * doz) * dd2) * invsum32;
+        }
+    }
+    dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+
+    // ---- 5. cov3D -> scale, quaternion (backward.cu:278-341) ----
+    if (scales) {
+        float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        if (visible) {
+            const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const Rot3 R = quat_to_rot(q);
+            const float s[3] = {vp.scale_modifier * sc.x, vp.scale_modifier * sc.y, vp.scale_modifier * sc.z};
+            float Mm[3][3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) Mm[c][rr] = s[rr] * R.c[c][rr];
+            const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dMt[3][3];  // dMt[c][r] = dM[r][c], dM = (2 M) dSigma
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+                    dMt[rr][c] = (Mm[0][rr] * 2.0f) * dS[c][0] + (Mm[1][rr] * 2.0f) * dS[c][1] + (Mm[2][rr] * 2.0f) * dS[c][2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) ds[c] = R.c[0][c] * dMt[c][0] + R.c[1][c] * dMt[c][1] + R.c[2][c] * dMt[c][2];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) dMt[c][rr] *= s[c];
+            dq[0] = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+            dq[1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
+            dq[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
+            dq[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        }
+        dL_dscale[3 * idx] = ds[0]; dL_dscale[3 * idx + 1] = ds[1]; dL_dscale[3 * idx + 2] = ds[2];
+        *reinterpret_cast<float4*>(dL_drot + 4 * idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+}
+
+hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
+                                 const ImageState& img, const float* slots, const BwdOutputs& o, hipStream_t s)
+{
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, vp, in.viewmatrix, in.projmatrix,
+                       in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
+                       g.rgb_clamped, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
+                       o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
+    return hipGetLastError();
+}
+
+}  // namespace frg

@@ -1,0 +1,263 @@
+// Per-tile depth sort in LDS.
+//
+// Replaces cub::DeviceRadixSort::SortPairs over all R (tile|depth) keys
+// (rasterizer_impl.cu:303-308, ~6 global radix passes of 24 B/instance) with one
+// workgroup per tile that loads its segment (8 B/instance), sorts it with a
+// stable wave64 ballot-ranked LSD radix sort on the 32 depth bits, breaks depth
+// ties by ascending Gaussian index and writes the 4 B/instance point_list.
+// Result == the reference's stable sort of index-ordered (tile,depth) keys.
+#include "frg_common.h"
+#include "kernels.h"
+
+namespace frg {
+
+// Lanes of the wave holding the same 8-bit digit as this lane (invalid lanes excluded).
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+{
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane)
+{
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// One stable counting pass on digit `shift` from src to dst (n elements).
+// whist: [NWAVES][256] per-wave digit counters, wave-private during the sweeps.
+// Returns false (and moves nothing) when every key has the same digit.
+template <int NWAVES, bool BY_INDEX, typename PtrT>
+__device__ __forceinline__ bool radix_pass(PtrT src, PtrT dst, int n, int shift, uint32_t* whist, uint32_t* scratch)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = NWAVES * 64;
+    for (int i = tid; i < NWAVES * 256; i += NT) whist[i] = 0;
+    __syncthreads();
+    // contiguous strip per wave (keeps the pass stable), multiple of 64
+    const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
+    const int begin = wave * strip, end = min(n, begin + strip);
+    uint32_t* myhist = whist + wave * 256;
+    for (int i = begin; i < end; i += 64) {
+        const bool valid = i + lane < end;
+        const uint32_t key = valid ? (BY_INDEX ? src[i + lane].y : src[i + lane].x) : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        const uint64_t peers = match_digit(d, valid);
+        if (valid && lanes_below(peers, lane) == 0) myhist[d] += (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    // digit totals, exclusive over waves then over digits
+    if (tid < 256) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) {
+            const uint32_t c = whist[w * 256 + tid];
+            whist[w * 256 + tid] = run;
+            run += c;
+        }
+        scratch[tid] = run;  // total for digit tid
+    }
+    __syncthreads();
+    if (tid < 256 && scratch[tid] == (uint32_t)n) scratch[256] = 1;  // one digit holds everything
+    __syncthreads();
+    const bool uniform = scratch[256] != 0;
+    __syncthreads();
+    if (uniform) {
+        if (tid == 0) scratch[256] = 0;
+        __syncthreads();
+        return false;
+    }
+    if (tid < 64) {  // exclusive scan of 256 totals by one wave, 4 per lane
+        uint32_t v0 = scratch[4 * lane], v1 = scratch[4 * lane + 1], v2 = scratch[4 * lane + 2], v3 = scratch[4 * lane + 3];
+        uint32_t s = v0 + v1 + v2 + v3, inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        uint32_t ex = inc - s;
+        scratch[4 * lane] = ex; scratch[4 * lane + 1] = ex + v0;
+        scratch[4 * lane + 2] = ex + v0 + v1; scratch[4 * lane + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t base = scratch[tid];
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) whist[w * 256 + tid] += base;
+    }
+    __syncthreads();
+    for (int i = begin; i < end; i += 64) {
+        const bool valid = i + lane < end;
+        uint2 e = make_uint2(0u, 0u);
+        if (valid) e = src[i + lane];
+        const uint32_t d = ((BY_INDEX ? e.y : e.x) >> shift) & 255u;
+        const uint64_t peers = match_digit(d, valid);
+        const uint32_t rank = lanes_below(peers, lane);
+        uint32_t pos = 0;
+        if (valid) pos = myhist[d] + rank;
+        // all lanes have read myhist before any leader bumps it (same wave, LDS ops in order,
+        // but make the dependence explicit for the compiler)
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) myhist[d] += (uint32_t)__popcll(peers);
+        if (valid) dst[pos] = e;
+    }
+    __syncthreads();
+    return true;
+}
+
+// Depth ties: order equal-depth runs by ascending index (the stable-sort tie rule,
+// SURVEY Appendix A-7).  count_ties() returns the number of adjacent equal-depth
+// pairs; a handful are fixed by insertion (fix_ties), many (coplanar scenes) by
+// re-sorting on the index first and the depth again, which LSD stability turns
+// into (depth, index) order.
+template <typename PtrT>
+__device__ __forceinline__ int count_ties(PtrT a, int n, int nthreads, uint32_t* scratch)
+{
+    if (threadIdx.x == 0) scratch[257] = 0;
+    __syncthreads();
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < n - 1; i += nthreads) c += (a[i].x == a[i + 1].x) ? 1u : 0u;
+    if (c) atomicAdd(&scratch[257], c);
+    __syncthreads();
+    const int r = (int)scratch[257];
+    __syncthreads();
+    return r;
+}
+
+template <typename PtrT>
+__device__ __forceinline__ void fix_ties(PtrT a, int n, int nthreads)
+{
+    for (int i = threadIdx.x; i < n - 1; i += nthreads) {
+        const uint32_t k = a[i].x;
+        if (a[i + 1].x != k) continue;
+        if (i > 0 && a[i - 1].x == k) continue;  // not the run start
+        int j = i + 1;
+        while (j + 1 < n && a[j + 1].x == k) j++;
+        for (int p = i + 1; p <= j; p++) {  // insertion sort on .y within [i, j]
+            const uint2 v = a[p];
+            int q = p - 1;
+            while (q >= i && a[q].y > v.y) { a[q + 1] = a[q]; q--; }
+            a[q + 1] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// Full (depth, index) ordering of one segment; returns the buffer holding the result.
+template <int NWAVES, typename PtrT>
+__device__ __forceinline__ PtrT sort_segment(PtrT src, PtrT dst, int n, uint32_t* whist, uint32_t* scratch)
+{
+    constexpr int NT = NWAVES * 64;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; pass++) {
+        if (radix_pass<NWAVES, false, PtrT>(src, dst, n, 8 * pass, whist, scratch)) { PtrT t = src; src = dst; dst = t; }
+    }
+    const int ties = count_ties<PtrT>(src, n, NT, scratch);
+    if (ties == 0) return src;
+    if (ties <= 32) { fix_ties<PtrT>(src, n, NT); return src; }
+#pragma unroll 1
+    for (int pass = 0; pass < 4; pass++) {
+        if (radix_pass<NWAVES, true, PtrT>(src, dst, n, 8 * pass, whist, scratch)) { PtrT t = src; src = dst; dst = t; }
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 4; pass++) {
+        if (radix_pass<NWAVES, false, PtrT>(src, dst, n, 8 * pass, whist, scratch)) { PtrT t = src; src = dst; dst = t; }
+    }
+    return src;
+}
+
+// CAP = LDS capacity in elements; tiles with lo < n <= CAP are handled by this
+// instantiation (the host launches one instantiation per size class; blocks whose
+// tile is outside the class exit immediately).
+template <int NWAVES, int CAP>
+__global__ void __launch_bounds__(NWAVES * 64)
+sort_tiles_lds_kernel(int T, int lo, const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
+                      uint32_t* __restrict__ point_list)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2* bufA = reinterpret_cast<uint2*>(smem);
+    uint2* bufB = bufA + CAP;
+    uint32_t* whist = reinterpret_cast<uint32_t*>(bufB + CAP);
+    uint32_t* scratch = whist + NWAVES * 256;  // 260 words
+    const int tile = blockIdx.x;
+    if (tile >= T) return;
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= lo || n > CAP) return;
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += NT) bufA[i] = pairs[rg.x + i];
+    if (tid == 0) scratch[256] = 0;
+    __syncthreads();
+    uint2* src = bufA;
+    if (n > 1) src = sort_segment<NWAVES, uint2*>(bufA, bufB, n, whist, scratch);
+    for (int i = tid; i < n; i += NT) point_list[rg.x + i] = src[i].y;
+}
+
+// Fallback for tile lists longer than the LDS capacity: same passes, ping-pong
+// in global memory (pairs <-> pairs_tmp); only histograms live in LDS.
+template <int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64)
+sort_tiles_global_kernel(int T, int lo, const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_tmp,
+                         uint32_t* __restrict__ point_list)
+{
+    __shared__ uint32_t whist[NWAVES * 256];
+    __shared__ uint32_t scratch[260];
+    const int tile = blockIdx.x;
+    if (tile >= T) return;
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= lo) return;
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x;
+    if (tid == 0) scratch[256] = 0;
+    __syncthreads();
+    uint2* src = sort_segment<NWAVES, uint2*>(pairs + rg.x, pairs_tmp + rg.x, n, whist, scratch);
+    for (int i = tid; i < n; i += NT) point_list[rg.x + i] = src[i].y;
+}
+
+// Host-side launcher (called from api.hip)
+template <int NW, int CAP>
+static hipError_t launch_lds_class(int T, int lo, const uint2* ranges, const uint2* pairs, uint32_t* point_list, hipStream_t stream)
+{
+    const size_t lds = (size_t)CAP * 16 + NW * 1024 + 260 * 4;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_tiles_lds_kernel<NW, CAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sort_tiles_lds_kernel<NW, CAP>), dim3(T), dim3(NW * 64), lds, stream, T, lo, ranges, pairs, point_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
+                            uint32_t* point_list, hipStream_t stream)
+{
+    if (T <= 0 || max_tile_count <= 0) return hipSuccess;
+    // size classes: (0,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 16 waves, >8192 global ping-pong
+    hipError_t e = launch_lds_class<4, 2048>(T, 0, ranges, pairs, point_list, stream);
+    if (e != hipSuccess) return e;
+    if (max_tile_count > 2048) {
+        e = launch_lds_class<8, 4096>(T, 2048, ranges, pairs, point_list, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (max_tile_count > 4096) {
+        e = launch_lds_class<16, FRG_SORT_LDS_CAP>(T, 4096, ranges, pairs, point_list, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (max_tile_count > FRG_SORT_LDS_CAP) {
+        if (!pairs_tmp) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(T), dim3(1024), 0, stream, T, FRG_SORT_LDS_CAP, ranges, pairs, pairs_tmp, point_list);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace frg

@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's rasterizer Python API.
+
+Same public names, argument meaning and error behaviour as
+``diff_gaussian_rasterization/__init__.py`` of the reference
+(DGR/diff_gaussian_rasterization/__init__.py:44-220), so that
+``gaussian_splatting/gaussian_renderer/__init__.py:14``,
+``frosting_scene/frosting_model.py:29`` and ``frosting_scene/sugar_model.py:10``
+can import it unchanged (the top-level ``diff_gaussian_rasterization`` package
+re-exports this module).  Underneath, the three native entry points
+(``rasterize_gaussians``, ``rasterize_gaussians_backward``, ``mark_visible`` --
+DGR/ext.cpp:15-18) are served by the C ABI in include/frosting_rasterizer.h;
+torch is used only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _ptr(t):
+    """Device pointer of a tensor, or NULL for the reference's 'absent' encoding
+    (empty tensor, DGR/diff_gaussian_rasterization/__init__.py:197-207)."""
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32c(t, device):
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")  # reference: .data<float>() throws
+    if t.device != device:
+        raise RuntimeError(f"tensor on {t.device}, expected {device}")
+    return t.contiguous()
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _Buffers:
+    """The three resizable scratch tensors of the reference binding
+    (rasterize_points.cu:27-33,71-78), grown through the C-ABI callbacks."""
+
+    def __init__(self, device):
+        self.device = device
+        self.geom = torch.empty(0, dtype=torch.uint8, device=device)
+        self.binning = torch.empty(0, dtype=torch.uint8, device=device)
+        self.img = torch.empty(0, dtype=torch.uint8, device=device)
+
+        def make(name):
+            def cb(_user, nbytes):
+                t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+                setattr(self, name, t)
+                return t.data_ptr()
+            return _lib.ALLOC_FN(cb)
+
+        self.cb_geom, self.cb_binning, self.cb_img = make("geom"), make("binning"), make("img")
+
+
+class _NativeOps:
+    """Drop-in for the reference's pybind module ``_C`` (DGR/ext.cpp:15-18):
+    identical positional signatures and return tuples (DGR/rasterize_points.h:18-67)."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                            campos, prefiltered, debug):
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
+        if not means3D.is_cuda:
+            raise RuntimeError("frosting_amd rasterizer: means3D must live on a ROCm device (no CPU path)")
+        L = _lib.lib()
+        dev = means3D.device
+        P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+        with torch.cuda.device(dev):
+            out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            bufs = _Buffers(dev)
+            M = int(sh.shape[1]) if sh is not None and sh.numel() != 0 else 0
+            t = dict(bg=_f32c(background, dev), means=_f32c(means3D, dev), colors=_f32c(colors, dev),
+                     opac=_f32c(opacity, dev), scales=_f32c(scales, dev), rots=_f32c(rotations, dev),
+                     cov=_f32c(cov3D_precomp, dev), view=_f32c(viewmatrix, dev), proj=_f32c(projmatrix, dev),
+                     sh=_f32c(sh, dev), campos=_f32c(campos, dev))
+            rc = L.frg_forward(bufs.cb_geom, bufs.cb_binning, bufs.cb_img, None,
+                               P, int(degree), M, _ptr(t["bg"]), W, H,
+                               _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]), _ptr(t["opac"]),
+                               _ptr(t["scales"]), float(scale_modifier), _ptr(t["rots"]), _ptr(t["cov"]),
+                               _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
+                               float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                               _ptr(out_color), _ptr(radii) if P else None, int(bool(debug)), _stream_ptr(dev))
+        if rc < 0:
+            raise RuntimeError(f"frg_forward failed ({rc}): {_lib.last_error()}")
+        return rc, out_color, radii, bufs.geom, bufs.binning, bufs.img
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+        L = _lib.lib()
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])  # rasterize_points.cu:142-143
+        M = int(sh.shape[1]) if sh is not None and sh.numel() != 0 else 0
+        with torch.cuda.device(dev):
+            def e(*shape):
+                return torch.empty(shape, dtype=torch.float32, device=dev)
+            has_sh = sh is not None and sh.numel() != 0
+            has_sr = scales is not None and scales.numel() != 0
+            dL_dmeans3D, dL_dmeans2D, dL_dcolors = e(P, 3), e(P, 3), e(P, 3)
+            dL_dconic, dL_dopacity, dL_dcov3D = e(P, 2, 2), e(P, 1), e(P, 6)
+            # rows the kernels do not write (absent input) stay zero, as in the reference's zero-allocated outputs
+            dL_dsh = e(P, M, 3) if has_sh else torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
+            dL_dscales = e(P, 3) if has_sr else torch.zeros((P, 3), dtype=torch.float32, device=dev)
+            dL_drotations = e(P, 4) if has_sr else torch.zeros((P, 4), dtype=torch.float32, device=dev)
+            if P != 0:
+                ws_bytes = int(L.frg_backward_workspace_bytes(P, int(R)))
+                workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                t = dict(bg=_f32c(background, dev), means=_f32c(means3D, dev), colors=_f32c(colors, dev),
+                         scales=_f32c(scales, dev), rots=_f32c(rotations, dev), cov=_f32c(cov3D_precomp, dev),
+                         view=_f32c(viewmatrix, dev), proj=_f32c(projmatrix, dev), sh=_f32c(sh, dev),
+                         campos=_f32c(campos, dev), dpix=_f32c(dL_dout_color, dev), radii=radii.contiguous())
+                rc = L.frg_backward(P, int(degree), M, int(R), _ptr(t["bg"]), W, H,
+                                    _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]),
+                                    _ptr(t["scales"]), float(scale_modifier), _ptr(t["rots"]), _ptr(t["cov"]),
+                                    _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
+                                    float(tan_fovx), float(tan_fovy), _ptr(t["radii"]),
+                                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(t["dpix"]),
+                                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                                    _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh) if has_sh else None,
+                                    _ptr(dL_dscales) if has_sr else None, _ptr(dL_drotations) if has_sr else None,
+                                    _ptr(workspace), ws_bytes, int(bool(debug)), _stream_ptr(dev))
+                if rc < 0:
+                    raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
+                # keep the workspace alive until the stream has consumed it
+                workspace.record_stream(torch.cuda.current_stream(dev))
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        L = _lib.lib()
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        present = torch.zeros((P,), dtype=torch.bool, device=dev)
+        if P != 0:
+            with torch.cuda.device(dev):
+                m, v, p = _f32c(means3D, dev), _f32c(viewmatrix, dev), _f32c(projmatrix, dev)
+                rc = L.frg_mark_visible(P, _ptr(m), _ptr(v), _ptr(p), _ptr(present), _stream_ptr(dev))
+            if rc < 0:
+                raise RuntimeError(f"frg_mark_visible failed ({rc}): {_lib.last_error()}")
+        return present
+
+
+_C = _NativeOps()
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """The 12 per-view settings, same fields and order as the reference
+    (DGR/diff_gaussian_rasterization/__init__.py:157-169)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Autograd wiring (reference: __init__.py:44-155).  Gradients come back in
+    input order; the settings argument gets None."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        s = raster_settings
+        native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh,
+                       s.sh_degree, s.campos, s.prefiltered, s.debug)
+        if s.debug:
+            saved = _snapshot(native_args)
+            try:
+                out = _C.rasterize_gaussians(*native_args)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")  # same replay fixture as the reference (:83-90)
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians(*native_args)
+        num_rendered, color, radii, geom, binning, img = out
+        ctx.raster_settings = s
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        s = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, sh, s.sh_degree, s.campos,
+                       geom, ctx.num_rendered, binning, img, s.debug)
+        if s.debug:
+            saved = _snapshot(native_args)
+            try:
+                grads = _C.rasterize_gaussians_backward(*native_args)
+            except Exception:
+                torch.save(saved, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            grads = _C.rasterize_gaussians_backward(*native_args)
+        g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots = grads
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """``GaussianRasterizer(raster_settings)(means3D=..., means2D=..., opacities=..., shs=|colors_precomp=,
+    scales=+rotations=|cov3D_precomp=) -> (image [3,H,W], radii [P] int32)`` (reference :171-220)."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            s = self.raster_settings
+            return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr = scales is not None and rotations is not None
+        partial_sr = (scales is not None) or (rotations is not None)
+        if (not have_sr and cov3D_precomp is None) or (partial_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])  # the reference's encoding of an absent input
+        return rasterize_gaussians(
+            means3D, means2D,
+            empty if shs is None else shs,
+            empty if colors_precomp is None else colors_precomp,
+            opacities,
+            empty if scales is None else scales,
+            empty if rotations is None else rotations,
+            empty if cov3D_precomp is None else cov3D_precomp,
+            self.raster_settings)

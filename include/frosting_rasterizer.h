@@ -1,0 +1,134 @@
+/*
+ * frosting_rasterizer.h -- C ABI of the MI355X-native differentiable Gaussian-splat
+ * rasterizer (libfrosting_rasterizer.so, hand-written gfx950 HIP).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one member of the
+ * reference's native interface for this path
+ *
+ *   DGR = gaussian_splatting/submodules/diff-gaussian-rasterization
+ *   DGR/cuda_rasterizer/rasterizer.h:20-85   CudaRasterizer::Rasterizer::{markVisible,forward,backward}
+ *   DGR/rasterize_points.h:18-67             RasterizeGaussiansCUDA / ...BackwardCUDA / markVisible
+ *   DGR/ext.cpp:15-18                        pybind exports rasterize_gaussians[_backward], mark_visible
+ *
+ * with the same argument order and meaning; the only additions are the HIP
+ * stream (the reference launches on the legacy default stream), a user pointer
+ * for the allocation callbacks (the reference passes std::function closures,
+ * rasterize_points.cu:27-33) and an explicit workspace for backward.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 / int32 data unless noted;
+ *   - optional inputs (shs | colors_precomp, scales+rotations | cov3D_precomp) are
+ *     NULL when absent (the reference tests data_ptr()==nullptr, forward.cu:205,241);
+ *   - matrices are the reference's row-vector 4x4 (world_view_transform,
+ *     full_proj_transform), i.e. read column-major (auxiliary.h:58-77);
+ *   - functions return >= 0 on success, a negative FRG_E* code on failure;
+ *     frg_last_error() returns a thread-local message.  Without `debug` kernel
+ *     faults are asynchronous, as in the reference (auxiliary.h:166-173);
+ *   - no call allocates device memory behind the caller's back.
+ */
+#ifndef FROSTING_RASTERIZER_H_INCLUDED
+#define FROSTING_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRG_OK 0
+#define FRG_EINVAL (-1)   /* bad argument (e.g. neither shs nor colors_precomp) */
+#define FRG_EALLOC (-2)   /* an allocation callback returned NULL / too small workspace */
+#define FRG_EHIP (-3)     /* a HIP runtime call or kernel failed (see frg_last_error) */
+#define FRG_EFILTER (-4)  /* prefiltered=1 but a Gaussian was near-culled (auxiliary.h:154-162) */
+
+/* Resizable-buffer callback: must return device memory of at least `bytes`
+ * bytes, 256-byte aligned, owned by the caller and kept alive until the matching
+ * backward has run (replaces std::function<char*(size_t)>, rasterizer.h:32-34). */
+typedef char* (*frg_alloc_fn)(void* user, size_t bytes);
+
+/* API / ABI version of this header. */
+int frg_version(void);
+const char* frg_last_error(void);
+
+/* Replaces Rasterizer::markVisible (rasterizer.h:24-29, rasterizer_impl.cu:141-153):
+ * present[i] = (view-space z > 0.2).  `present` is one byte per Gaussian. */
+int frg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* hip_stream);
+
+/* Replaces Rasterizer::forward (rasterizer.h:31-56, rasterizer_impl.cu:198-336).
+ * Returns num_rendered (= sum of tiles_touched) or a negative error code.
+ * out_color is [3,H,W] planar and fully written; radii is [P] int32 and fully
+ * written.  The three chunks obtained through the callbacks are opaque state for
+ * frg_backward (layout: frg_*_layout below, for tests only).  One device->host
+ * read of 16 bytes (num_rendered) is the only host synchronisation. */
+int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
+                int P, int D, int M,
+                const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, int* radii, int debug, void* hip_stream);
+
+/* Bytes of scratch frg_backward needs for a forward that returned R instances. */
+size_t frg_backward_workspace_bytes(int P, int R);
+
+/* Replaces Rasterizer::backward (rasterizer.h:58-84, rasterizer_impl.cu:340-434).
+ * All nine gradient arrays are fully written (zero rows for culled Gaussians);
+ * they need NOT be zero-initialised (the reference requires zeros,
+ * rasterize_points.cu:151-159).  dL_dmean2D is [P,3] (z stays 0), dL_dconic
+ * [P,4] = (a, b, -, c), dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3],
+ * dL_dcov3D [P,6], dL_dsh [P,M,3] (ignored when shs==NULL), dL_dscale [P,3],
+ * dL_drot [P,4] (ignored when scales==NULL).  Summation order is fixed, so
+ * results are bit-reproducible run to run (the reference's atomics are not). */
+int frg_backward(int P, int D, int M, int R,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer,
+                 const float* dL_dpix,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 char* workspace, size_t workspace_bytes, int debug, void* hip_stream);
+
+/* Runtime options.  "exact_blend": 1 = blend kernels use the reference's IEEE
+ * operation order without FMA contraction and the accurate expf (bit-identical
+ * images to the reference built the same way); 0 (default) = FMA + native exp2.
+ * The per-Gaussian stages are always evaluated in the exact order, so radii,
+ * tile counts and sort keys never depend on this switch.  Returns the previous
+ * value or FRG_EINVAL for an unknown name. */
+int frg_set_option(const char* name, int value);
+int frg_get_option(const char* name);
+
+/* Sizes of the three state chunks (what the callbacks will be asked for). */
+size_t frg_geometry_bytes(int P);
+size_t frg_image_bytes(int width, int height);
+size_t frg_binning_bytes(int R, int max_tile_count);
+
+/* Test-only introspection: byte offsets of the named arrays inside each chunk.
+ * geometry: out[0]=xy_depth_radius (float4[P]: pixel x, pixel y, view depth, radius)
+ *           out[1]=conic_opacity (float4[P]) out[2]=rgb_clamped (float4[P]: r,g,b, clamp bits)
+ *           out[3]=tiles_touched (u32[P])    out[4]=point_offsets (u32[P], inclusive scan)
+ * image:    out[0]=final_T (f32[H*W]) out[1]=n_contrib (u32[H*W]) out[2]=ranges (uint2[tiles])
+ *           out[3]=tile_count (u32[tiles])
+ * binning:  out[0]=point_list (u32[R], sorted by (tile, depth, index))
+ *           out[1]=pairs_unsorted (uint2[R]: depth bits, index; tile-major, unsorted) */
+void frg_geometry_layout(int P, long long* out);
+void frg_image_layout(int width, int height, long long* out);
+void frg_binning_layout(int R, int max_tile_count, long long* out);
+
+/* ---- triangle occlusion raster (replaces nvdiffrast's dr.rasterize as used by
+ * frosting_utils/nvdiffrast.py:53-54 / mesh_rasterization.py:146-156) ----------
+ * pos: [V,4] clip-space vertices, tri: [F,3] int32, rast: [H,W,4] float32 =
+ * (u, v, z/w, triangle_id+1), 0 where empty.  depth_scratch: H*W uint64. */
+size_t frg_mesh_raster_workspace_bytes(int width, int height);
+int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width, int height,
+                       float* rast, char* workspace, size_t workspace_bytes, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE: ctypes/numpy front end of the C restatement (gs_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It is the checker, never the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libgs_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gs_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "_build/libgs_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.gso_preprocess.restype = C.c_int
+        _lib.gso_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f(a):
+    if a is None:
+        return None
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads() -> int:
+    return int(lib().gso_num_threads())
+
+
+def set_num_threads(n: int):
+    lib().gso_set_num_threads(int(n))
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    m, v, pm = _f(means3D), _f(viewmatrix), _f(projmatrix)
+    P = m.shape[0]
+    out = np.zeros(P, dtype=np.uint8)
+    lib().gso_mark_visible(C.c_int(P), _p(m), _p(v), _p(pm), _p(out))
+    return out.astype(bool)
+
+
+def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, width, height, tanfovx, tanfovy,
+            shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+            sh_degree=0, scale_modifier=1.0, stages=("preprocess", "sort", "render")):
+    """Run the restated forward.  Returns a dict with every artefact the
+    reference materialises (names follow rasterizer_impl.h:21-73)."""
+    L = lib()
+    m = _f(means3D)
+    P = m.shape[0]
+    H, W = int(height), int(width)
+    sh, cp, sc, rot, c3p = _f(shs), _f(colors_precomp), _f(scales), _f(rotations), _f(cov3D_precomp)
+    op, vm, pm, cam, bgc = _f(opacities), _f(viewmatrix), _f(projmatrix), _f(campos).reshape(-1), _f(bg)
+    M = 0 if sh is None else sh.shape[1]
+    st = dict(P=P, W=W, H=H, M=M, D=int(sh_degree))
+    st["radii"] = np.zeros(P, np.int32)
+    st["means2D"] = np.zeros((P, 2), np.float32)
+    st["depths"] = np.zeros(P, np.float32)
+    st["cov3D"] = np.zeros((P, 6), np.float32)
+    st["rgb"] = np.zeros((P, 3), np.float32)
+    st["conic_opacity"] = np.zeros((P, 4), np.float32)
+    st["clamped"] = np.zeros((P, 3), np.uint8)
+    st["tiles_touched"] = np.zeros(P, np.uint32)
+    st["point_offsets"] = np.zeros(P, np.uint32)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    st["grid"] = (gx, gy)
+    if P == 0:
+        st["num_rendered"] = 0
+        st["out_color"] = np.zeros((3, H, W), np.float32)
+        return st
+    R = L.gso_preprocess(C.c_int(P), C.c_int(int(sh_degree)), C.c_int(M), _p(m), _p(sc), C.c_float(scale_modifier),
+                         _p(rot), _p(op), _p(sh), _p(c3p), _p(cp), _p(vm), _p(pm), _p(cam), C.c_int(W), C.c_int(H),
+                         C.c_float(tanfovx), C.c_float(tanfovy), _p(st["radii"]), _p(st["means2D"]),
+                         _p(st["depths"]), _p(st["cov3D"]), _p(st["rgb"]), _p(st["conic_opacity"]),
+                         _p(st["clamped"]), _p(st["tiles_touched"]), _p(st["point_offsets"]))
+    st["num_rendered"] = int(R)
+    if "sort" not in stages:
+        return st
+    st["keys"] = np.zeros(max(R, 1), np.uint64)[:R]
+    st["point_list"] = np.zeros(max(R, 1), np.uint32)[:R]
+    st["ranges"] = np.zeros((gx * gy, 2), np.uint32)
+    keys = np.zeros(max(R, 1), np.uint64)
+    plist = np.zeros(max(R, 1), np.uint32)
+    L.gso_bin_sort(C.c_int(P), C.c_int(R), C.c_int(W), C.c_int(H), _p(st["radii"]), _p(st["means2D"]),
+                   _p(st["depths"]), _p(st["point_offsets"]), _p(keys), _p(plist), _p(st["ranges"]))
+    st["keys"], st["point_list"] = keys[:R], plist[:R]
+    if "render" not in stages:
+        return st
+    feat = cp if cp is not None else st["rgb"]
+    st["final_T"] = np.zeros((H, W), np.float32)
+    st["n_contrib"] = np.zeros((H, W), np.uint32)
+    st["out_color"] = np.zeros((3, H, W), np.float32)
+    L.gso_render(C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(plist), _p(st["means2D"]), _p(feat),
+                 _p(st["conic_opacity"]), _p(bgc), _p(st["final_T"]), _p(st["n_contrib"]), _p(st["out_color"]))
+    st["_inputs"] = dict(means3D=m, shs=sh, colors_precomp=cp, scales=sc, rotations=rot, cov3D_precomp=c3p,
+                         viewmatrix=vm, projmatrix=pm, campos=cam, bg=bgc, tanfovx=float(tanfovx),
+                         tanfovy=float(tanfovy), scale_modifier=float(scale_modifier))
+    return st
+
+
+def backward(st, dL_dout_color):
+    """Gradients for the forward described by `st` (as returned by forward())."""
+    L = lib()
+    i = st["_inputs"]
+    P, W, H, M, D, R = st["P"], st["W"], st["H"], st["M"], st["D"], st["num_rendered"]
+    dpix = _f(dL_dout_color)
+    g = dict(
+        dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dconic=np.zeros((P, 4), np.float32),
+        dL_dopacity=np.zeros((P, 1), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
+        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+        dL_drotations=np.zeros((P, 4), np.float32))
+    if P == 0:
+        return g
+    colors = i["colors_precomp"] if i["colors_precomp"] is not None else st["rgb"]
+    plist = np.ascontiguousarray(st["point_list"])
+    L.gso_render_backward(C.c_int(P), C.c_int(R), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(plist), _p(i["bg"]),
+                          _p(st["means2D"]), _p(st["conic_opacity"]), _p(colors), _p(st["final_T"]),
+                          _p(st["n_contrib"]), _p(dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]),
+                          _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+    cov = i["cov3D_precomp"] if i["cov3D_precomp"] is not None else st["cov3D"]
+    L.gso_preprocess_backward(C.c_int(P), C.c_int(D), C.c_int(M), _p(i["means3D"]), _p(st["radii"]), _p(i["shs"]),
+                              _p(st["clamped"]), _p(i["scales"]), _p(i["rotations"]), C.c_float(i["scale_modifier"]),
+                              _p(cov), _p(i["viewmatrix"]), _p(i["projmatrix"]), C.c_int(W), C.c_int(H),
+                              C.c_float(i["tanfovx"]), C.c_float(i["tanfovy"]), _p(i["campos"]),
+                              _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dcolors"]), _p(g["dL_dmeans3D"]),
+                              _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+    return g

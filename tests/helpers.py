@@ -1,0 +1,69 @@
+"""Shared helpers for the parity tests: run ours / the C oracle / the reference on
+the same seeded inputs."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from frosting_amd import scenes
+from frosting_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _C
+
+
+def settings_for(cam, bg, sh_degree, device, scale_modifier=1.0, debug=False):
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=bg.to(device), scale_modifier=scale_modifier, viewmatrix=cam.viewmatrix.to(device),
+        projmatrix=cam.projmatrix.to(device), sh_degree=sh_degree, campos=cam.campos.to(device),
+        prefiltered=False, debug=debug)
+
+
+def cov3d_from(scene):
+    """Python-side covariance (strip_symmetric(L L^T), L = R S) as the reference's
+    compute_cov3D_python path builds it (gaussian_splatting/utils/general_utils.py:64-110)."""
+    q = scene.rotations
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+    L = R * scene.scales[:, None, :]
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).contiguous()
+
+
+def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False):
+    """Call the native entry points directly (what _RasterizeGaussians.forward does)."""
+    sc = scene.to(device)
+    e = torch.Tensor([])
+    sh = sc.shs if mode == "sh" else e
+    colors = e if mode == "sh" else torch.sigmoid(sc.shs[:, 0, :]).contiguous()
+    scales, rots = (sc.scales, sc.rotations) if cov == "sr" else (e, e)
+    cov3 = e if cov == "sr" else cov3d_from(scene).to(device)
+    args = (bg.to(device), sc.means3D, colors, sc.opacities, scales, rots, 1.0, cov3, cam.viewmatrix.to(device),
+            cam.projmatrix.to(device), cam.tanfovx, cam.tanfovy, cam.image_height, cam.image_width, sh,
+            sc.sh_degree, cam.campos.to(device), False, debug)
+    out = _C.rasterize_gaussians(*args)
+    return out, args
+
+
+def oracle_kwargs(scene, cam, bg, mode="sh", cov="sr", as_numpy=True, device=None):
+    conv = (lambda t: t.numpy()) if as_numpy else (lambda t: t.to(device))
+    kw = dict(means3D=conv(scene.means3D), opacities=conv(scene.opacities), viewmatrix=conv(cam.viewmatrix),
+              projmatrix=conv(cam.projmatrix), campos=conv(cam.campos), bg=conv(bg), width=cam.image_width,
+              height=cam.image_height, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=scene.sh_degree)
+    if mode == "sh":
+        kw["shs"] = conv(scene.shs)
+    else:
+        kw["colors_precomp"] = conv(torch.sigmoid(scene.shs[:, 0, :]).contiguous())
+    if cov == "sr":
+        kw["scales"], kw["rotations"] = conv(scene.scales), conv(scene.rotations)
+    else:
+        kw["cov3D_precomp"] = conv(cov3d_from(scene))
+    return kw
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).flatten()
+    b = torch.as_tensor(b, dtype=torch.float64).flatten()
+    d = (a - b).norm()
+    n = b.norm()
+    return float(d / n) if n > 0 else float(d)
