@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Gaussian-splat rasterizer.
+
+Metric (BASELINE.json): train views/sec, forward + backward rasterization at
+3M Gaussians, 1600x1056, SH degree 3 (configs[2], "c3"), synthetic seeded scene
+(SURVEY.md section 8d), inputs resident in HBM before the timed region.
+
+One "step" = one pass of the hot path over one view: frg_forward + frg_backward
+through the C ABI (the loss gradient dL/dimage is a fixed tensor; the loss itself
+is outside the op and outside the byte model).  With --gpus N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank renders its own camera of
+the 8-camera ring (view-parallel, weak scaling) and the per-Gaussian parameter
+gradients are summed across ranks with one RCCL all-reduce per step -- the
+exchange step north_star names.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from frosting_amd import _lib, scenes  # noqa: E402
+from frosting_amd.parallel import ViewParallelRasterizer  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def stage_bytes(P, V, R, N, T):
+    """Algorithmic HBM bytes per stage and per view (SURVEY.md 8(d) table;
+    P Gaussians, V visible, R instances, N pixels, T tiles, 16 SH coefficients)."""
+    return {
+        "preprocess": 20 * P + 291 * V,
+        "scan": 0,
+        "scatter": 8 * P + 20 * V + 12 * R,
+        "sort": 24 * R + 8 * R + 8 * T,
+        "blend_fwd": 40 * R + 20 * N,
+        "blend_bwd": 76 * R + 20 * N,
+        "preprocess_bwd": 303 * V + 284 * P,
+    }
+
+
+def cpu_baseline(cfg_name: str, P: int):
+    """C restatement of the reference (oracle/gs_oracle.c, OpenMP) timed on the host
+    cores for ONE forward+backward of the same workload -- reported, not a target."""
+    from oracle import gs_oracle as G
+    G.build()
+    scene, cam, bg = scenes.config_scene(cfg_name, 0, P=P)
+    kw = dict(means3D=scene.means3D.numpy(), opacities=scene.opacities.numpy(), viewmatrix=cam.viewmatrix.numpy(),
+              projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(), bg=bg.numpy(), width=cam.image_width,
+              height=cam.image_height, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, shs=scene.shs.numpy(),
+              scales=scene.scales.numpy(), rotations=scene.rotations.numpy(), sh_degree=scene.sh_degree)
+    t0 = time.perf_counter()
+    st = G.forward(**kw)
+    gpix = (np.sign(st["out_color"] - 0.5) / st["out_color"].size).astype(np.float32)
+    G.backward(st, gpix)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "views/s", "cores": G.num_threads(), "kind": "port",
+            "sample": f"1 view fwd+bwd of {cfg_name} at P={P} (R={st['num_rendered']}), {dt:.2f} s wall, OpenMP C port "
+                      f"of the reference algorithm (oracle/gs_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=list(scenes.CONFIGS))
+    ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the rasterizer has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    cfg = scenes.CONFIGS[args.config]
+    P = args.points or cfg["P"]
+    scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
+    _lib.set_option("exact_blend", 1 if args.exact else 0)
+    _lib.set_option("profile", 1)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD if dist else None)
+    cam_d = cam.to(dev)
+    bg_d = bg.to(dev)
+
+    image, radii = vpr.forward(cam_d, bg_d)
+    gpix, _ = scenes.l1_target_grad(image.cpu(), 20241022 + rank)
+    gpix = gpix.to(dev)
+
+    def step():
+        vpr.forward(cam_d, bg_d)
+        vpr.backward(gpix)       # writes straight into the flat gradient buffer
+        vpr.allreduce_grads()    # no-op at world size 1
+
+    for _ in range(args.warmup):
+        step()
+    stage_acc = {}
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            # hipEvent stage timers of this step (events only; no extra kernels)
+            for k, v in _lib.stage_times().items():
+                stage_acc.setdefault(k, []).append(v)
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        views_per_s = world * args.steps / dt
+        V = int((radii > 0).sum())
+        R = int(vpr.num_rendered)
+        N = cam.image_width * cam.image_height
+        T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
+        B = stage_bytes(P, V, R, N, T)
+        total_bytes = 312 * P + 614 * V + 160 * R + 40 * N + 8 * T
+        out = {
+            "metric": "train views/sec (fwd+bwd raster)", "value": views_per_s, "unit": "views/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, "
+                                   f"forward+backward, 1 view per GPU per step", "P": P, "visible": V,
+                       "num_rendered": R, "tiles": T, "parallelism": f"view-parallel x{world}",
+                       "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"]},
+            "op_hbm": {"algorithmic_bytes_per_view": total_bytes,
+                       "achieved_GBps_per_gpu": total_bytes / (dt / args.steps) / 1e9,
+                       "frac_of_8TBps": total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+        }
+        if stage_acc:
+            avg = {k: float(np.mean(v)) for k, v in stage_acc.items() if np.mean(v) > 0}
+            dom = max(avg, key=avg.get)
+            ach = B[dom] / (avg[dom] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": B[dom], "avg_launch_ms": avg[dom]}
+            out["stage_ms"] = avg
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.config, P)
+            except Exception as ex:  # the baseline is informative; never lose the GPU number over it
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,8 @@ def lib():
                                vp, vp, vp, vp,
                                vp, vp, vp, vp, vp,
                                vp, sz, i, vp]
+    L.frg_stage_times.restype = i
+    L.frg_stage_times.argtypes = [vp, i]
     L.frg_mesh_raster_workspace_bytes.restype = sz
     L.frg_mesh_raster_workspace_bytes.argtypes = [i, i]
     L.frg_mesh_rasterize.restype = i
@@ -95,9 +97,19 @@ def get_option(name: str) -> int:
     return lib().frg_get_option(name.encode())
 
 
+STAGE_NAMES = ["preprocess", "scan", "scatter", "sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+
+
+def stage_times() -> dict:
+    """Milliseconds per stage of the last forward/backward (needs set_option('profile', 1))."""
+    buf = (C.c_float * 8)()
+    n = lib().frg_stage_times(buf, 8)
+    return {STAGE_NAMES[k]: float(buf[k]) for k in range(min(n, len(STAGE_NAMES)))}
+
+
 EXPORTED_SYMBOLS = [
     "frg_version", "frg_last_error", "frg_mark_visible", "frg_forward", "frg_backward_workspace_bytes",
-    "frg_backward", "frg_set_option", "frg_get_option", "frg_geometry_bytes", "frg_image_bytes",
+    "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize",
 ]

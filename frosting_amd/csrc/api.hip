@@ -27,6 +27,36 @@ int fail(int code, const char* fmt, ...)
 }
 
 std::atomic<int> g_exact_blend{-1};
+std::atomic<int> g_profile{0};
+
+// Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
+// recorded on the caller's stream between the kernels of one forward / backward;
+// frg_stage_times() synchronises and returns the elapsed milliseconds.
+enum { ST_PREPROCESS = 0, ST_SCAN, ST_SCATTER, ST_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+struct StageTimers {
+    hipEvent_t ev[ST_COUNT][2];
+    bool used[ST_COUNT];
+    bool init = false;
+    void ensure()
+    {
+        if (init) return;
+        for (int i = 0; i < ST_COUNT; i++) { (void)hipEventCreate(&ev[i][0]); (void)hipEventCreate(&ev[i][1]); used[i] = false; }
+        init = true;
+    }
+};
+thread_local StageTimers g_timers;
+
+struct StageScope {
+    int id; hipStream_t s; bool on;
+    StageScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile.load() != 0)
+    {
+        if (on) { g_timers.ensure(); (void)hipEventRecord(g_timers.ev[id][0], s); }
+    }
+    ~StageScope()
+    {
+        if (on) { (void)hipEventRecord(g_timers.ev[id][1], s); g_timers.used[id] = true; }
+    }
+};
 
 int exact_blend()
 {
@@ -92,12 +122,28 @@ int frg_set_option(const char* name, int value)
         g_exact_blend.store(value ? 1 : 0);
         return old;
     }
+    if (name && strcmp(name, "profile") == 0) return g_profile.exchange(value ? 1 : 0);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
+}
+
+int frg_stage_times(float* ms, int n)
+{
+    if (!ms || n < ST_COUNT) return fail(FRG_EINVAL, "need room for %d stages", (int)ST_COUNT);
+    for (int i = 0; i < n; i++) ms[i] = -1.0f;
+    if (!g_timers.init) return ST_COUNT;
+    for (int i = 0; i < ST_COUNT; i++) {
+        if (!g_timers.used[i]) continue;
+        if (hipEventSynchronize(g_timers.ev[i][1]) != hipSuccess) continue;
+        float t = -1.0f;
+        if (hipEventElapsedTime(&t, g_timers.ev[i][0], g_timers.ev[i][1]) == hipSuccess) ms[i] = t;
+    }
+    return ST_COUNT;
 }
 
 int frg_get_option(const char* name)
 {
     if (name && strcmp(name, "exact_blend") == 0) return exact_blend();
+    if (name && strcmp(name, "profile") == 0) return g_profile.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -176,8 +222,8 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
     FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
-    FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess");
-    FRG_STAGE(frg::launch_scan(P, vp, g, img, stream), "scan");
+    { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess"); }
+    { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, stream), "scan"); }
 
     // the single host synchronisation of the op (rasterizer_impl.cu:280-281)
     frg::Counters* host = pinned_counters();
@@ -196,16 +242,19 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
     const frg::BinningState b = frg::BinningState::carve(bin_chunk, R, max_tile);
 
     if (R > 0) {
-        FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
-        FRG_STAGE(frg::launch_tile_sort(T, max_tile, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort");
+        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, max_tile, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
     } else {
         // point_offsets must still be defined for backward
         FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
     }
-    if (exact_blend())
-        FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
-    else
-        FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
+    {
+        StageScope sc_(ST_BLEND_FWD, stream);
+        if (exact_blend())
+            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
+        else
+            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
+    }
     return R;
 }
 
@@ -239,14 +288,17 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
 
-    if (exact_blend())
-        FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
-    else
-        FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+    {
+        StageScope sc_(ST_BLEND_BWD, stream);
+        if (exact_blend())
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+        else
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+    }
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
-    FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, stream), "preprocess_bwd");
+    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, stream), "preprocess_bwd"); }
     return FRG_OK;
 }
 

@@ -61,10 +61,13 @@ def look_at_camera(center, width: int, height: int, fx: float, fy: float,
     w2c[:3, :3] = torch.stack([x, y, z])
     w2c[:3, 3] = -(w2c[:3, :3] @ c)
     tanfovx, tanfovy = width / (2.0 * fx), height / (2.0 * fy)
-    world_view = w2c.t().contiguous().float()  # row-vector convention
-    proj = projection_matrix(znear, zfar, tanfovx, tanfovy).t().contiguous().float()
-    full = world_view @ proj
-    campos = torch.linalg.inv(world_view)[3, :3].contiguous()
+    # float64 throughout, rounded once (host-independent bits; the reference does the same
+    # algebra in float32: full_proj = world_view @ projection, campos = inverse(world_view)[3,:3])
+    wv64 = w2c.t().contiguous()  # row-vector convention
+    proj64 = projection_matrix(znear, zfar, tanfovx, tanfovy).t().contiguous()
+    world_view = wv64.float()
+    full = (wv64 @ proj64).float()
+    campos = c.float().contiguous()
     return Camera(height, width, float(tanfovx), float(tanfovy), world_view, full.contiguous(), campos)
 
 
@@ -93,23 +96,30 @@ class Scene:
 
 def make_scene(P: int, seed: int, sh_degree: int = 3, log_scale: float = math.log(0.005),
                scale_sigma: float = 0.8) -> Scene:
+    # Everything is drawn and transformed in float64 and rounded once to float32, so the
+    # bits do not depend on the host's vector-math library (exp / sqrt / division differ
+    # by an ulp between CPU families in float32, which would leak into golden fixtures).
     g = torch.Generator().manual_seed(seed)
-    means = torch.randn(P, 3, generator=g)
+    f64 = torch.float64
+    means = torch.randn(P, 3, generator=g, dtype=f64)
     nrm = means.norm(dim=1, keepdim=True).clamp_min(1e-12)
-    means = torch.where(nrm > 3.0, means * (3.0 / nrm), means)
-    scales = torch.exp(log_scale + scale_sigma * torch.randn(P, 3, generator=g))
-    q = torch.randn(P, 4, generator=g)
-    q = q / q.norm(dim=1, keepdim=True)
-    opac = 0.05 + 0.9 * torch.rand(P, 1, generator=g)
+    means = torch.where(nrm > 3.0, means * (3.0 / nrm), means).float()
+    scales = torch.exp(log_scale + scale_sigma * torch.randn(P, 3, generator=g, dtype=f64)).float()
+    q = torch.randn(P, 4, generator=g, dtype=f64)
+    q = (q / q.norm(dim=1, keepdim=True)).float()
+    opac = (0.05 + 0.9 * torch.rand(P, 1, generator=g, dtype=f64)).float()
     K = 16
     shs = torch.empty(P, K, 3)
-    shs[:, 0, :] = 0.5 * torch.randn(P, 3, generator=g)
-    shs[:, 1:, :] = 0.05 * torch.randn(P, K - 1, 3, generator=g)
+    shs[:, 0, :] = (0.5 * torch.randn(P, 3, generator=g, dtype=f64)).float()
+    shs[:, 1:, :] = (0.05 * torch.randn(P, K - 1, 3, generator=g, dtype=f64)).float()
     return Scene(means.contiguous(), scales.contiguous(), q.contiguous(), opac.contiguous(), shs.contiguous(), sh_degree)
 
 
 # BASELINE.json configs (C2 / C3 shapes)
 CONFIGS = {
+    # small-image case for committed golden fixtures and CPU-sized tests (same FoV as c3)
+    "mini": dict(P=3000, width=160, height=112, fx=133.4, fy=133.4, seed=SEED_BASE + 9, bg=(0.1, 0.2, 0.3),
+                 log_scale=math.log(0.04)),
     "c2": dict(P=100_000, width=800, height=800, fx=1111.0, fy=1111.0, seed=SEED_BASE + 2, bg=(1.0, 1.0, 1.0)),
     "c3": dict(P=3_000_000, width=1600, height=1056, fx=1334.0, fy=1334.0, seed=SEED_BASE + 3, bg=(0.0, 0.0, 0.0)),
 }
@@ -117,7 +127,7 @@ CONFIGS = {
 
 def config_scene(name: str, view: int = 0, P: int | None = None):
     cfg = CONFIGS[name]
-    scene = make_scene(P or cfg["P"], cfg["seed"])
+    scene = make_scene(P or cfg["P"], cfg["seed"], log_scale=cfg.get("log_scale", math.log(0.005)))
     cam = ring_camera(view, cfg["width"], cfg["height"], cfg["fx"], cfg["fy"])
     bg = torch.tensor(cfg["bg"], dtype=torch.float32)
     return scene, cam, bg

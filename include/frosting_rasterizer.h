@@ -103,6 +103,13 @@ int frg_backward(int P, int D, int M, int R,
 int frg_set_option(const char* name, int value);
 int frg_get_option(const char* name);
 
+/* Per-stage GPU time of the calling thread's most recent forward/backward, valid
+ * after frg_set_option("profile", 1): ms[0..6] = preprocess, scan, scatter, sort,
+ * blend_fwd, blend_bwd, preprocess_bwd (milliseconds between hipEvents recorded on
+ * the caller's stream; -1 when a stage did not run).  Synchronises on the events.
+ * Returns the number of stages (7) or a negative error. */
+int frg_stage_times(float* ms, int n);
+
 /* Sizes of the three state chunks (what the callbacks will be asked for). */
 size_t frg_geometry_bytes(int P);
 size_t frg_image_bytes(int width, int height);

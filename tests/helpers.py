@@ -20,14 +20,19 @@ def settings_for(cam, bg, sh_degree, device, scale_modifier=1.0, debug=False):
 def cov3d_from(scene):
     """Python-side covariance (strip_symmetric(L L^T), L = R S) as the reference's
     compute_cov3D_python path builds it (gaussian_splatting/utils/general_utils.py:64-110)."""
-    q = scene.rotations
+    q = scene.rotations.double()   # float64, rounded once: independent of the host's BLAS / SIMD
     r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
     R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
                      2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
-    L = R * scene.scales[:, None, :]
-    S = L @ L.transpose(1, 2)
-    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).contiguous()
+    L = R * scene.scales.double()[:, None, :]
+    S = (L[:, :, None, :] * L[:, None, :, :]).sum(-1)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).float().contiguous()
+
+
+def precomp_colors(scene):
+    """Deterministic 'precomputed colour' input (float64 sigmoid of the DC coefficients, rounded once)."""
+    return torch.sigmoid(scene.shs[:, 0, :].double()).float().contiguous()
 
 
 def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False):
@@ -35,7 +40,8 @@ def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False):
     sc = scene.to(device)
     e = torch.Tensor([])
     sh = sc.shs if mode == "sh" else e
-    colors = e if mode == "sh" else torch.sigmoid(sc.shs[:, 0, :]).contiguous()
+    # colours are computed once on the CPU so every implementation sees the same bits
+    colors = e if mode == "sh" else precomp_colors(scene).to(device)
     scales, rots = (sc.scales, sc.rotations) if cov == "sr" else (e, e)
     cov3 = e if cov == "sr" else cov3d_from(scene).to(device)
     args = (bg.to(device), sc.means3D, colors, sc.opacities, scales, rots, 1.0, cov3, cam.viewmatrix.to(device),
@@ -53,7 +59,7 @@ def oracle_kwargs(scene, cam, bg, mode="sh", cov="sr", as_numpy=True, device=Non
     if mode == "sh":
         kw["shs"] = conv(scene.shs)
     else:
-        kw["colors_precomp"] = conv(torch.sigmoid(scene.shs[:, 0, :]).contiguous())
+        kw["colors_precomp"] = conv(precomp_colors(scene))
     if cov == "sr":
         kw["scales"], kw["rotations"] = conv(scene.scales), conv(scene.rotations)
     else:

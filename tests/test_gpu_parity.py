@@ -1,0 +1,319 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against
+  * the committed golden fixtures produced by the reference itself,
+  * the C oracle on the same seeded inputs,
+  * the reference's own rasterizer (oracle/_ref) when its .so travelled with the snapshot,
+and size-independent properties at BASELINE.json's full sizes.
+
+Bars: integer / index artefacts (radii, tile counts, sort keys, point list, ranges)
+bit-exact; images <= 1e-4 mean per-pixel L1 (north_star) -- in EXACT blend mode they
+are in fact bit-identical to the reference built with the same contraction mode;
+gradients within the reference's own atomic-order noise.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from frosting_amd import _lib, scenes
+from frosting_amd.introspect import State
+from frosting_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _C
+from oracle import gs_oracle as G
+from oracle import ref_rasterizer as REF
+
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RASTER_FIXTURES = sorted(glob.glob(os.path.join(GOLD, "g_*.npz")))
+L1_BAR = 1e-4  # north_star: per-pixel L1 vs the reference rasterizer
+
+
+def _bwd_args(args, out, gpix):
+    R, color, radii, geom, binning, img = out
+    return (args[0], args[1], radii, args[2], args[4], args[5], args[6], args[7], args[8], args[9], args[10], args[11],
+            gpix, args[14], args[15], args[16], geom, R, binning, img, False)
+
+
+GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+              "dL_drotations"]
+
+
+@pytest.fixture(autouse=True)
+def _reset_options():
+    yield
+    _lib.set_option("exact_blend", 0)
+    _lib.set_option("profile", 0)
+
+
+def test_native_library_is_loaded(gpu_device):
+    L = _lib.lib()
+    assert L.frg_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libfrosting_rasterizer.so" in f.read()
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("path", RASTER_FIXTURES, ids=[os.path.basename(p) for p in RASTER_FIXTURES])
+def test_against_reference_golden_fixture(gpu_device, path, exact):
+    fx = np.load(path)
+    scene, cam, bg = scenes.config_scene(str(fx["cfg"]), int(fx["view"]), P=int(fx["P"]))
+    _lib.set_option("exact_blend", exact)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device, str(fx["mode"]), str(fx["cov"]))
+    R, color, radii, geom, binning, img = out
+    st = State(scene.P, cam.image_width, cam.image_height, R, geom, binning, img)
+    vis = fx["radii"] > 0
+    assert R == int(fx["num_rendered"])
+    np.testing.assert_array_equal(radii.cpu().numpy(), fx["radii"])
+    np.testing.assert_array_equal(st.tiles_touched.cpu().numpy(), fx["tiles_touched"])
+    np.testing.assert_array_equal(st.ranges.cpu().numpy(), fx["ranges"])
+    np.testing.assert_array_equal(st.point_list.cpu().numpy(), fx["point_list"])
+    np.testing.assert_array_equal(st.sort_keys().cpu().numpy(), fx["keys"])
+    np.testing.assert_array_equal(st.depths.cpu().numpy()[vis], fx["depths"][vis])
+    np.testing.assert_array_equal(st.means2D.cpu().numpy()[vis], fx["means2D"][vis])
+    np.testing.assert_array_equal(st.conic_opacity.cpu().numpy()[vis], fx["conic_opacity"][vis])
+    image = color.cpu().numpy()
+    if exact:
+        np.testing.assert_array_equal(image, fx["image"])                       # bit-identical
+        np.testing.assert_array_equal(st.n_contrib.cpu().numpy(), fx["n_contrib"].astype(np.int32))
+    else:
+        assert np.abs(image - fx["image"]).mean() <= L1_BAR
+    gpix, _ = scenes.l1_target_grad(torch.from_numpy(fx["image"]), int(fx["loss_seed"]))
+    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+    for name, g in zip(GRAD_NAMES, grads):
+        ref = fx["grad_" + name]
+        if ref.size == 0 or not np.any(ref):
+            continue
+        assert Hh.rel_l2(g.cpu().numpy(), ref) < 3e-4, (name, Hh.rel_l2(g.cpu().numpy(), ref))
+
+
+@pytest.mark.parametrize("mode,cov", [("sh", "sr"), ("colors", "sr"), ("sh", "cov"), ("colors", "cov")])
+def test_against_c_oracle_all_input_modes(gpu_device, mode, cov):
+    scene, cam, bg = scenes.config_scene("mini", 6, P=2500)
+    _lib.set_option("exact_blend", 1)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device, mode, cov)
+    R, color, radii, geom, binning, img = out
+    st = State(scene.P, cam.image_width, cam.image_height, R, geom, binning, img)
+    o = G.forward(**Hh.oracle_kwargs(scene, cam, bg, mode, cov))
+    assert R == o["num_rendered"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    np.testing.assert_array_equal(st.point_list.cpu().numpy().astype(np.uint32), o["point_list"])
+    np.testing.assert_array_equal(st.sort_keys().cpu().numpy().astype(np.uint64), o["keys"])
+    np.testing.assert_array_equal(st.ranges.cpu().numpy().astype(np.uint32), o["ranges"])
+    assert np.abs(color.cpu().numpy() - o["out_color"]).mean() <= 1e-6
+    gpix, _ = scenes.l1_target_grad(color.cpu(), 3)
+    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+    og = G.backward(o, gpix.numpy())
+    for name, g in zip(GRAD_NAMES, grads):
+        if og[name].size == 0 or not np.any(og[name]):
+            assert not g.cpu().numpy().any() or og[name].size == 0
+            continue
+        assert Hh.rel_l2(g.cpu().numpy(), og[name]) < 2e-4, (name, Hh.rel_l2(g.cpu().numpy(), og[name]))
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_lower_sh_degrees(gpu_device, deg):
+    scene, cam, bg = scenes.config_scene("mini", 2, P=1200)
+    scene.sh_degree = deg
+    _lib.set_option("exact_blend", 1)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+    assert np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= 1e-6
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 4)
+    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+    og = G.backward(o, gpix.numpy())
+    dsh = grads[5].cpu().numpy()
+    assert Hh.rel_l2(dsh, og["dL_dsh"]) < 2e-4
+    assert not dsh[:, (deg + 1) ** 2:, :].any()  # coefficients above the active degree get zero gradient
+
+
+@pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("cfg,P,view", [("c2", 100_000, 0), ("c3", 400_000, 2)])
+def test_bit_exact_vs_reference_rasterizer(gpu_device, cfg, P, view):
+    """The reference's own code (hipcc, -ffp-contract=off) run beside ours on the same tensors."""
+    scene, cam, bg = scenes.config_scene(cfg, view, P=P)
+    _lib.set_option("exact_blend", 1)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    R, color, radii, geom, binning, img = out
+    st = State(P, cam.image_width, cam.image_height, R, geom, binning, img)
+    Rr, rcolor, rradii, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
+    assert R == Rr
+    assert torch.equal(radii, rradii)
+    assert torch.equal(st.tiles_touched, rst.tiles_touched)
+    assert torch.equal(st.point_offsets, rst.point_offsets)
+    assert torch.equal(st.ranges, rst.ranges)
+    assert torch.equal(st.point_list, rst.point_list)
+    assert torch.equal(st.sort_keys(), rst.point_list_keys)
+    assert torch.equal(st.n_contrib, rst.n_contrib)
+    assert torch.equal(color, rcolor)
+    _lib.set_option("exact_blend", 0)  # default product arithmetic: tolerance bar
+    out2, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    assert float((out2[1] - rcolor).abs().mean()) <= L1_BAR
+    assert torch.equal(out2[2], rradii)
+    gpix, _ = scenes.l1_target_grad(color.cpu(), 9)
+    gpix = gpix.to(gpu_device)
+    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out2, gpix))
+    rg = REF.backward(rst, gpix)
+    rg2 = REF.backward(rst, gpix)
+    for name, g in zip(GRAD_NAMES, grads):
+        noise = Hh.rel_l2(rg2[name].cpu(), rg[name].cpu())  # the reference's own run-to-run spread
+        assert Hh.rel_l2(g.cpu(), rg[name].cpu()) < max(5e-4, 20 * noise), name
+
+
+def test_backward_is_bit_reproducible(gpu_device):
+    scene, cam, bg = scenes.config_scene("c2", 1, P=50_000)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 5)
+    b = _bwd_args(args, out, gpix.to(gpu_device))
+    g1 = _C.rasterize_gaussians_backward(*b)
+    g2 = _C.rasterize_gaussians_backward(*b)
+    assert all(torch.equal(a, c) for a, c in zip(g1, g2))
+
+
+def test_ragged_image_and_edge_sizes(gpu_device):
+    scene, _, bg = scenes.config_scene("mini", 0, P=700)
+    _lib.set_option("exact_blend", 1)
+    for (w, h) in [(150, 101), (17, 33), (16, 16), (1, 1)]:
+        cam = scenes.ring_camera(3, w, h, 120.0, 120.0)
+        out, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+        assert out[0] == o["num_rendered"]
+        assert tuple(out[1].shape) == (3, h, w)
+        assert np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= 1e-6
+    # P == 0: zero image, background not applied (rasterize_points.cu:68,81)
+    empty = scenes.Scene(*(t[:0] for t in (scene.means3D, scene.scales, scene.rotations, scene.opacities, scene.shs)), 3)
+    cam = scenes.ring_camera(0, 64, 48, 60.0, 60.0)
+    out, args = Hh.run_ours_native(empty, cam, torch.ones(3), gpu_device)
+    assert out[0] == 0 and not out[1].any() and out[2].numel() == 0
+    # P == 1 and an all-culled scene
+    one = scenes.Scene(*(t[:1] for t in (scene.means3D, scene.scales, scene.rotations, scene.opacities, scene.shs)), 3)
+    out, _ = Hh.run_ours_native(one, cam, bg, gpu_device)
+    o = G.forward(**Hh.oracle_kwargs(one, cam, bg))
+    assert out[0] == o["num_rendered"] and np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= 1e-6
+    behind = scenes.Scene(scene.means3D * 0 + cam.campos - 0.0, scene.scales, scene.rotations, scene.opacities, scene.shs, 3)
+    out, args = Hh.run_ours_native(behind, cam, bg, gpu_device)
+    assert out[0] == 0 and not out[2].any()
+    np.testing.assert_allclose(out[1].cpu().numpy(), np.broadcast_to(bg.numpy()[:, None, None], (3, 48, 64)))
+    gpix = torch.ones(3, 48, 64, device=gpu_device)
+    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix))
+    assert all(not g.any() for g in grads)
+
+
+def test_depth_ties_and_oversized_tiles(gpu_device):
+    """Coplanar Gaussians (equal depth keys -> index tie-break) piled onto one tile so
+    that its list exceeds the 8192-entry LDS capacity (global ping-pong sort path)."""
+    P = 12_000
+    g = torch.Generator().manual_seed(1)
+    cam = scenes.ring_camera(0, 64, 64, 80.0, 80.0)
+    means = torch.zeros(P, 3)
+    means[:, :2] = 0.02 * torch.randn(P, 2, generator=g)
+    means[: P // 2, 2] = 0.5        # two exact depth planes => massive ties
+    means[P // 2:, 2] = 0.25
+    scene = scenes.Scene(means, torch.full((P, 3), 0.01), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                         torch.full((P, 1), 0.02), 0.1 * torch.randn(P, 16, 3, generator=g), 3)
+    bg = torch.zeros(3)
+    _lib.set_option("exact_blend", 1)
+    out, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    R, color, radii, geom, binning, img = out
+    st = State(P, 64, 64, R, geom, binning, img)
+    assert int(st.tile_count.max()) > 8192
+    o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+    assert R == o["num_rendered"]
+    np.testing.assert_array_equal(st.point_list.cpu().numpy().astype(np.uint32), o["point_list"])
+    assert np.abs(color.cpu().numpy() - o["out_color"]).mean() <= 1e-6
+
+
+def test_autograd_module_api_matches_call_sites(gpu_device):
+    """The call pattern of gaussian_renderer/__init__.py:36-93 and frosting_model.py:1452-1467,1649-1657."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as S2, GaussianRasterizer as R2
+    scene, cam, bg = scenes.config_scene("mini", 1, P=1500)
+    sc = scene.to(gpu_device)
+    means3D = sc.means3D.clone().requires_grad_(True)
+    shs = sc.shs.clone().requires_grad_(True)
+    opac = sc.opacities.clone().requires_grad_(True)
+    scales = sc.scales.clone().requires_grad_(True)
+    rots = sc.rotations.clone().requires_grad_(True)
+    screenspace_points = torch.zeros_like(means3D, requires_grad=True) + 0
+    screenspace_points.retain_grad()
+    settings = S2(image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tanfovx,
+                  tanfovy=cam.tanfovy, bg=bg.to(gpu_device), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(gpu_device),
+                  projmatrix=cam.projmatrix.to(gpu_device), sh_degree=3, campos=cam.campos.to(gpu_device),
+                  prefiltered=False, debug=False)
+    rasterizer = R2(raster_settings=settings)
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
+                                       opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
+    assert rendered_image.shape == (3, cam.image_height, cam.image_width) and radii.dtype == torch.int32
+    target = torch.rand_like(rendered_image)
+    (rendered_image - target).abs().mean().backward()
+    o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+    og = G.backward(o, (torch.sign(rendered_image.detach() - target) / target.numel()).cpu().numpy())
+    assert Hh.rel_l2(means3D.grad.cpu(), og["dL_dmeans3D"]) < 2e-4
+    assert Hh.rel_l2(shs.grad.cpu(), og["dL_dsh"]) < 2e-4
+    assert Hh.rel_l2(screenspace_points.grad.cpu(), og["dL_dmeans2D"]) < 2e-4  # densification statistic
+    assert not screenspace_points.grad[:, 2].any()
+    vis = rasterizer.markVisible(sc.means3D)
+    np.testing.assert_array_equal(vis.cpu().numpy(), G.mark_visible(scene.means3D.numpy(), cam.viewmatrix.numpy(),
+                                                                    cam.projmatrix.numpy()))
+    with torch.no_grad():  # inference call (metrics.py:332-342)
+        img2, _ = rasterizer(means3D=sc.means3D, means2D=screenspace_points, shs=sc.shs, opacities=sc.opacities,
+                             scales=sc.scales, rotations=sc.rotations)
+    assert torch.equal(img2, rendered_image.detach())
+
+
+def test_prefiltered_assertion_and_debug_mode(gpu_device):
+    scene, cam, bg = scenes.config_scene("mini", 0, P=300)
+    sc = scene.to(gpu_device)
+    kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+              bg=bg.to(gpu_device), scale_modifier=1.0, viewmatrix=cam.viewmatrix.to(gpu_device),
+              projmatrix=cam.projmatrix.to(gpu_device), sh_degree=3, campos=cam.campos.to(gpu_device))
+    means = sc.means3D.clone()
+    means[0] = cam.campos.to(gpu_device)  # behind the near plane
+    r = GaussianRasterizer(GaussianRasterizationSettings(prefiltered=True, debug=False, **kw))
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        r(means3D=means, means2D=means, shs=sc.shs, opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations)
+    r = GaussianRasterizer(GaussianRasterizationSettings(prefiltered=False, debug=True, **kw))
+    img, _ = r(means3D=means, means2D=means, shs=sc.shs, opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations)
+    assert torch.isfinite(img).all()
+
+
+def test_full_size_properties_c3(gpu_device):
+    """BASELINE configs[2] at full size (3M Gaussians, 1600x1056): properties that need no oracle."""
+    scene, cam, bg = scenes.config_scene("c3", 0)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    R, color, radii, geom, binning, img = out
+    st = State(scene.P, cam.image_width, cam.image_height, R, geom, binning, img)
+    assert R == int(st.tiles_touched.to(torch.int64).sum()) == int(st.point_offsets[-1])
+    counts = (st.ranges[:, 1] - st.ranges[:, 0]).to(torch.int64)
+    assert int(counts.sum()) == R and torch.equal(counts, st.tile_count.to(torch.int64))
+    keys = st.sort_keys()
+    assert bool((keys[1:] >= keys[:-1]).all())                       # sortedness of (tile, depth)
+    same = keys[1:] == keys[:-1]
+    pl = st.point_list.to(torch.int64)
+    assert bool((pl[1:][same] > pl[:-1][same]).all())                # ties in ascending index order
+    assert int(torch.bincount(pl, minlength=scene.P).sum()) == R
+    assert torch.equal(torch.bincount(pl, minlength=scene.P), st.tiles_touched.to(torch.int64))  # multiset of instances
+    assert torch.isfinite(color).all() and float(color.min()) >= 0.0
+    T = st.final_T
+    assert float(T.min()) >= 1e-4 * 0.99 and float(T.max()) <= 1.0
+    assert int((st.n_contrib.to(torch.int64).view(-1) > counts.max()).sum()) == 0
+    # linearity of backward in dL/dimage (fixed forward state)
+    gpix, _ = scenes.l1_target_grad(color.cpu(), 1)
+    gpix = gpix.to(gpu_device)
+    g1 = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix))
+    g2 = _C.rasterize_gaussians_backward(*_bwd_args(args, out, 2.0 * gpix))
+    for a, b in zip(g1, g2):
+        assert torch.equal(2.0 * a, b)                               # exact: scaling by 2 commutes with rounding
+    assert all(torch.isfinite(g).all() for g in g1)
+    assert not g1[3][radii == 0].any() and not g1[5][radii == 0].any()  # culled Gaussians get zero rows
+
+
+def test_full_size_c2_forward_vs_oracle(gpu_device):
+    """BASELINE configs[1] (100k Gaussians, 800x800 forward) against the C oracle."""
+    scene, cam, bg = scenes.config_scene("c2", 0)
+    _lib.set_option("exact_blend", 0)
+    out, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+    assert out[0] == o["num_rendered"]
+    np.testing.assert_array_equal(out[2].cpu().numpy(), o["radii"])
+    assert np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= L1_BAR

@@ -1,0 +1,94 @@
+"""CPU tests of the boundary: C-ABI library loads and exports every declared symbol,
+the Python host mirror keeps the reference's names / argument rules / errors."""
+import os
+import re
+
+import pytest
+import torch
+
+from frosting_amd import _lib
+from frosting_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _settings():
+    e = torch.eye(4)
+    return GaussianRasterizationSettings(64, 64, 0.5, 0.5, torch.zeros(3), 1.0, e, e, 3, torch.zeros(3), False, False)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "frosting_rasterizer.h")).read()
+    declared = set(re.findall(r"\b(frg_[a-z_0-9]+)\s*\(", hdr)) - {"frg_alloc_fn"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.frg_version() == 1
+
+
+def test_state_size_queries_and_options():
+    L = _lib.lib()
+    assert L.frg_geometry_bytes(1000) >= 1000 * 56
+    assert L.frg_geometry_bytes(2000) > L.frg_geometry_bytes(1000)
+    assert L.frg_image_bytes(1600, 1056) >= 1600 * 1056 * 8
+    assert L.frg_binning_bytes(1000, 10) >= 1000 * 12
+    assert L.frg_binning_bytes(1000, 100000) > L.frg_binning_bytes(1000, 10)  # ping-pong buffer for oversize tiles
+    assert L.frg_backward_workspace_bytes(10, 1000) >= 1000 * 36
+    old = _lib.set_option("exact_blend", 1)
+    assert _lib.get_option("exact_blend") == 1
+    _lib.set_option("exact_blend", old)
+    assert _lib.set_option("no_such_option", 1) < 0 and "unknown option" in _lib.last_error()
+
+
+def test_settings_fields_match_reference_order():
+    assert GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+
+
+def test_argument_validation_like_reference():
+    r = GaussianRasterizer(raster_settings=_settings())
+    m = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), colors_precomp=torch.zeros(4, 3),
+          scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.ones(4, 3))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4), cov3D_precomp=torch.zeros(4, 6))
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU tensor -- never route through a CPU path."""
+    r = GaussianRasterizer(raster_settings=_settings())
+    m = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        from frosting_amd.rasterizer import _C
+        _C.rasterize_gaussians(torch.zeros(3), torch.zeros(4, 2), *([torch.Tensor([])] * 4), 1.0, torch.Tensor([]),
+                               torch.eye(4), torch.eye(4), 0.5, 0.5, 8, 8, torch.Tensor([]), 0, torch.zeros(3),
+                               False, False)
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "frosting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "gs_oracle" not in src and "ref_rasterizer" not in src and "from oracle" not in src, f
+    drop_in = open(os.path.join(ROOT, "diff_gaussian_rasterization", "__init__.py")).read()
+    assert "oracle" not in drop_in
+
+
+def test_drop_in_import_name():
+    import diff_gaussian_rasterization as d
+    assert d.GaussianRasterizer is GaussianRasterizer
+    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(d._C))
