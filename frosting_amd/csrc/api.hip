@@ -28,6 +28,7 @@ int fail(int code, const char* fmt, ...)
 
 std::atomic<int> g_exact_blend{-1};
 std::atomic<int> g_profile{0};
+std::atomic<int> g_global_bins{0};  // test hook: force the large-image (global-atomic) binning path
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
 // recorded on the caller's stream between the kernels of one forward / backward;
@@ -123,6 +124,7 @@ int frg_set_option(const char* name, int value)
         return old;
     }
     if (name && strcmp(name, "profile") == 0) return g_profile.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -144,11 +146,12 @@ int frg_get_option(const char* name)
 {
     if (name && strcmp(name, "exact_blend") == 0) return exact_blend();
     if (name && strcmp(name, "profile") == 0) return g_profile.load();
+    if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
 size_t frg_geometry_bytes(int P) { return frg::GeomState::carve(nullptr, P).bytes; }
-size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nullptr, width, height).bytes; }
+size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nullptr, width, height, g_global_bins.load() != 0).bytes; }
 size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count).bytes; }
 size_t frg_backward_workspace_bytes(int P, int R)
 {
@@ -164,7 +167,7 @@ void frg_geometry_layout(int P, long long* out)
 }
 void frg_image_layout(int width, int height, long long* out)
 {
-    frg::ImageState s = frg::ImageState::carve(nullptr, width, height);
+    frg::ImageState s = frg::ImageState::carve(nullptr, width, height, g_global_bins.load() != 0);
     out[0] = (long long)(size_t)s.final_T; out[1] = (long long)(size_t)s.n_contrib; out[2] = (long long)(size_t)s.ranges;
     out[3] = (long long)(size_t)s.tile_count;
 }
@@ -217,7 +220,7 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
     char* img_chunk = image_alloc(user, frg_image_bytes(width, height));
     if (!geom_chunk || !img_chunk) return fail(FRG_EALLOC, "allocation callback returned null");
     const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
-    const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height);
+    const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height, g_global_bins.load() != 0);
 
     FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
 
@@ -284,7 +287,7 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
 
     const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
     const frg::GeomState g = frg::GeomState::carve(geom_buffer, P);
-    const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height);
+    const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, g_global_bins.load() != 0);
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
 

@@ -10,6 +10,10 @@
 #define FRG_WAVE 64
 #define FRG_NUM_XCD 8
 #define FRG_SLOT_FLOATS 9   // per-instance backward partial: rgb(3) mean2D(2) conic(3) opacity(1)
+#define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
+#define FRG_BIN_MAX_BLOCKS 512   // rows of the (workgroup x tile) count matrix
+#define FRG_BIN_SEGS 8           // row segments of the column scan
+#define FRG_BIN_MAX_LDS_TILES 36864  // T*4 bytes of LDS bins must fit beside the scan scratch (160 KiB/CU)
 
 namespace frg {
 
@@ -39,7 +43,7 @@ struct GeomState {
         s.rgb_clamped = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
         s.tiles_touched = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
         s.point_offsets = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
-        s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);
+        s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);  // per chunk
         s.bytes = o;
         return s;
     }
@@ -61,9 +65,12 @@ struct ImageState {
     uint32_t* tile_fill;     // zeroed every forward; scatter cursor
     Counters* counters;      // zeroed every forward
     uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
+    uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts -> scatter bases
+    uint32_t* seg_sums;      // [FRG_BIN_SEGS][T]
+    bool lds_bins;           // false: image too large for LDS histograms -> global-atomic binning
     size_t zero_begin, zero_bytes;  // region [tile_count .. counters] cleared with one memset
     size_t bytes;
-    __host__ static ImageState carve(char* base, int W, int H)
+    __host__ static ImageState carve(char* base, int W, int H, bool force_global_bins = false)
     {
         ImageState s;
         size_t N = (size_t)W * H;
@@ -78,6 +85,12 @@ struct ImageState {
         s.tile_fill = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
+        s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;
+        s.bin_matrix = nullptr; s.seg_sums = nullptr;
+        if (s.lds_bins) {
+            s.seg_sums = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_BIN_SEGS * T * 4, 256);
+            s.bin_matrix = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_BIN_MAX_BLOCKS * T * 4, 256);
+        }
         s.bytes = o;
         return s;
     }

@@ -26,9 +26,127 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
-// One thread per Gaussian (forward.cu:155-256).  Memory-bound: 12+12+16+4 B in,
-// 192 B of SH for the visible ones, 48 B + 8 B out.
-__global__ void __launch_bounds__(256)
+// Per-Gaussian forward math (forward.cu:155-256).  Returns tiles_touched; fills the
+// three 16-byte records and the tile rectangle when the Gaussian is kept.
+__device__ __forceinline__ uint32_t
+preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
+               const float* __restrict__ means3D, const float* __restrict__ scales,
+               const float* __restrict__ rotations, const float* __restrict__ opacities,
+               const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+               const float* __restrict__ colors_precomp,
+               float4* __restrict__ xydr, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_clamped,
+               Counters* __restrict__ counters, int prefiltered, int& radius_i, int& x0, int& y0, int& x1, int& y1)
+{
+    radius_i = 0;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float4 p_hom = xform44(p, vmx.proj);
+    const float3 p_view = xform43(p, vmx.view);
+    const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+    const float p_projx = p_hom.x * p_w, p_projy = p_hom.y * p_w;
+    if (p_view.z <= 0.2f) {  // near cull only (auxiliary.h:154)
+        if (prefiltered) counters->filtered = 1;  // auxiliary.h:156-160: reported by the host instead of __trap()
+        return 0u;
+    }
+    float cov[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov[i] = cov3D_precomp[6 * idx + i];
+    } else {
+        const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        cov3d_from_scale_rot(s, vp.scale_modifier, q, cov);
+    }
+    const Ewa e = ewa_setup(p, vp.focal_x, vp.focal_y, vp.tan_fovx, vp.tan_fovy, vmx.view);
+    float ca, cb, cc;
+    ewa_cov2d(e, cov, ca, cb, cc);
+    ca += 0.3f; cc += 0.3f;
+    const float det = ca * cc - cb * cb;
+    if (det == 0.0f) return 0u;
+    const float det_inv = 1.f / det;
+    const float mid = 0.5f * (ca + cc);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    const float px = ndc_to_pix(p_projx, vp.W), py = ndc_to_pix(p_projy, vp.H);
+    tile_rect(px, py, f2i(my_radius), vp.gx, vp.gy, x0, y0, x1, y1);
+    const uint32_t touched = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+    if (touched == 0) return 0u;
+    radius_i = f2i(my_radius);
+    float r = 0, g = 0, b = 0;
+    uint32_t clamp_bits = 0;
+    if (colors_precomp) {
+        r = colors_precomp[3 * idx]; g = colors_precomp[3 * idx + 1]; b = colors_precomp[3 * idx + 2];
+    } else {
+        // forward.cu:20-71
+        float dx = p.x - vmx.campos[0], dy = p.y - vmx.campos[1], dz = p.z - vmx.campos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        float w[16];
+        const int n = sh_weights(vp.D, dx, dy, dz, w);
+        const float* sh = shs + (size_t)idx * vp.M * 3;
+        float acc[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) acc[ch] = w[0] * sh[ch];
+        if (n > 1) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                acc[ch] = acc[ch] - w[1] * sh[3 + ch] + w[2] * sh[6 + ch] - w[3] * sh[9 + ch];
+            if (n > 4) {
+#pragma unroll
+                for (int i = 4; i < 9; i++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
+                if (n > 9) {
+#pragma unroll
+                    for (int i = 9; i < 16; i++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            acc[ch] += 0.5f;
+            if (acc[ch] < 0) clamp_bits |= (1u << ch);
+            acc[ch] = fmaxf(acc[ch], 0.0f);
+        }
+        r = acc[0]; g = acc[1]; b = acc[2];
+    }
+    xydr[idx] = make_float4(px, py, p_view.z, my_radius);
+    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+    rgb_clamped[idx] = make_float4(r, g, b, __uint_as_float(clamp_bits));
+    return touched;
+}
+
+// block-wide inclusive scan of one uint per thread (NW waves); returns the inclusive
+// value, *total receives the block sum.  wsum: NW words of LDS.
+template <int NW>
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* wsum, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t x = wsum[w];
+        if (w < wave) off += x;
+        tot += x;
+    }
+    *total = tot;
+    return off + inc;
+}
+
+// Persistent workgroups of 1024 threads walk chunks of 1024 Gaussians (chunk c is
+// always handled by workgroup c % gridDim.x -- the scatter kernel relies on the same
+// map).  Per-tile instance counts are accumulated in an LDS histogram private to the
+// workgroup and flushed ONCE, as a row of the (workgroup x tile) count matrix: no
+// global atomics (the first version issued R = 16.4 M of them at C3 and ran 8x over
+// its bandwidth bound).  LDS_BINS=false: T too large for LDS -> global atomics.
+template <bool LDS_BINS>
+__global__ void __launch_bounds__(FRG_BIN_THREADS)
 preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                       const float* __restrict__ means3D, const float* __restrict__ scales,
@@ -37,117 +155,71 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float* __restrict__ colors_precomp,
                       int* __restrict__ radii, float4* __restrict__ xydr, float4* __restrict__ conic_opacity,
                       float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched,
-                      uint32_t* __restrict__ tile_count, uint32_t* __restrict__ block_sums,
-                      Counters* __restrict__ counters, int prefiltered)
+                      uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
+                      uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
+    __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
+    const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
-    uint32_t touched = 0;
-    int radius_i = 0;
-    if (idx < P) {
-        const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-        const float4 p_hom = xform44(p, vmx.proj);
-        const float3 p_view = xform43(p, vmx.view);
-        const float p_w = 1.0f / (p_hom.w + 0.0000001f);
-        const float p_projx = p_hom.x * p_w, p_projy = p_hom.y * p_w;
-        if (!(p_view.z <= 0.2f)) {  // near cull only (auxiliary.h:154)
-            float cov[6];
-            if (cov3D_precomp) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) cov[i] = cov3D_precomp[6 * idx + i];
-            } else {
-                const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-                const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
-                cov3d_from_scale_rot(s, vp.scale_modifier, q, cov);
-            }
-            const Ewa e = ewa_setup(p, vp.focal_x, vp.focal_y, vp.tan_fovx, vp.tan_fovy, vmx.view);
-            float ca, cb, cc;
-            ewa_cov2d(e, cov, ca, cb, cc);
-            ca += 0.3f; cc += 0.3f;
-            const float det = ca * cc - cb * cb;
-            if (det != 0.0f) {
-                const float det_inv = 1.f / det;
-                const float mid = 0.5f * (ca + cc);
-                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-                const float px = ndc_to_pix(p_projx, vp.W), py = ndc_to_pix(p_projy, vp.H);
-                int x0, y0, x1, y1;
-                tile_rect(px, py, f2i(my_radius), vp.gx, vp.gy, x0, y0, x1, y1);
-                touched = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
-                if (touched != 0) {
-                    radius_i = f2i(my_radius);
-                    float r = 0, g = 0, b = 0;
-                    uint32_t clamp_bits = 0;
-                    if (colors_precomp) {
-                        r = colors_precomp[3 * idx]; g = colors_precomp[3 * idx + 1]; b = colors_precomp[3 * idx + 2];
-                    } else {
-                        // forward.cu:20-71
-                        float dx = p.x - vmx.campos[0], dy = p.y - vmx.campos[1], dz = p.z - vmx.campos[2];
-                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                        dx = dx / len; dy = dy / len; dz = dz / len;
-                        float w[16];
-                        const int n = sh_weights(vp.D, dx, dy, dz, w);
-                        const float* sh = shs + (size_t)idx * vp.M * 3;
-                        float acc[3];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) acc[ch] = w[0] * sh[ch];
-                        if (n > 1) {
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
-                                acc[ch] = acc[ch] - w[1] * sh[3 + ch] + w[2] * sh[6 + ch] - w[3] * sh[9 + ch];
-                            if (n > 4) {
-#pragma unroll
-                                for (int i = 4; i < 9; i++)
-#pragma unroll
-                                    for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
-                                if (n > 9) {
-#pragma unroll
-                                    for (int i = 9; i < 16; i++)
-#pragma unroll
-                                        for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            acc[ch] += 0.5f;
-                            if (acc[ch] < 0) clamp_bits |= (1u << ch);
-                            acc[ch] = fmaxf(acc[ch], 0.0f);
-                        }
-                        r = acc[0]; g = acc[1]; b = acc[2];
-                    }
-                    xydr[idx] = make_float4(px, py, p_view.z, my_radius);
-                    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
-                    rgb_clamped[idx] = make_float4(r, g, b, __uint_as_float(clamp_bits));
-                    // per-tile instance counts (replaces the key histogram of the global sort)
-                    for (int y = y0; y < y1; y++)
-                        for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * vp.gx + x], 1u);
-                }
-            }
-        } else if (prefiltered) {
-            counters->filtered = 1;  // auxiliary.h:156-160: reported by the host instead of __trap()
-        }
-        radii[idx] = radius_i;
-        tiles_touched[idx] = touched;
+    if (LDS_BINS) {
+        for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = 0;
+        __syncthreads();
     }
-    // block total of tiles_touched -> block_sums (first level of the offsets scan)
-    __shared__ uint32_t wsum[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t s = wave_incl_scan(touched, lane);
-    if (lane == 63) wsum[wave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int idx = c * FRG_BIN_THREADS + threadIdx.x;
+        uint32_t touched = 0;
+        if (idx < P) {
+            int radius_i, x0, y0, x1, y1;
+            touched = preprocess_one(idx, vp, vmx, means3D, scales, rotations, opacities, shs, cov3D_precomp,
+                                     colors_precomp, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
+                                     radius_i, x0, y0, x1, y1);
+            radii[idx] = radius_i;
+            tiles_touched[idx] = touched;
+            if (touched) {
+                for (int y = y0; y < y1; y++)
+                    for (int x = x0; x < x1; x++) {
+                        if (LDS_BINS) atomicAdd(&lds_bins[y * vp.gx + x], 1u);   // ds_add_u32
+                        else atomicAdd(&tile_count[y * vp.gx + x], 1u);
+                    }
+            }
+        }
+        uint32_t total;
+        block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
+        if (threadIdx.x == 0) block_sums[c] = total;
+    }
+    if (LDS_BINS) {
+        __syncthreads();
+        uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
+        for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) row[t] = lds_bins[t];
+    }
 }
 
-// Single workgroup: (a) exclusive scan of the per-block sums (in place), total ->
-// counters.num_rendered; (b) per-tile counts -> ranges [start,end), empty tiles
-// (0,0) exactly as the reference's memset + identifyTileRanges leave them
-// (rasterizer_impl.cu:310-317); max count -> counters.max_tile_count.
+// Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
+// seg_sums[s][t] = sum over the rows of segment s.  grid (ceil(T/256), FRG_BIN_SEGS).
+__global__ void __launch_bounds__(256)
+colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int per = (nrows + FRG_BIN_SEGS - 1) / FRG_BIN_SEGS;
+    const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+    uint32_t s = 0;
+#pragma unroll 8
+    for (int r = r0; r < r1; r++) s += bin_matrix[(size_t)r * T + t];
+    seg_sums[(size_t)blockIdx.y * T + t] = s;
+}
+
+// Single workgroup: (a) exclusive scan of the per-chunk sums (in place), total ->
+// counters.num_rendered; (b) per-tile totals -> ranges [start,end), empty tiles (0,0)
+// exactly as the reference's memset + identifyTileRanges leave them
+// (rasterizer_impl.cu:310-317); max -> counters.max_tile_count; with LDS_BINS the
+// per-segment sums become per-segment start offsets for colbase_kernel.
 __global__ void __launch_bounds__(1024)
-scan_kernel(int nblocks, uint32_t* __restrict__ block_sums, int T, const uint32_t* __restrict__ tile_count,
-            uint2* __restrict__ ranges, Counters* __restrict__ counters)
+scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
+            uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, Counters* __restrict__ counters)
 {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
@@ -156,11 +228,19 @@ scan_kernel(int nblocks, uint32_t* __restrict__ block_sums, int T, const uint32_
     if (tid == 0) { carry_s = 0; maxc_s = 0; }
     __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
-        const int n = pass == 0 ? nblocks : T;
+        const int n = pass == 0 ? nchunks : T;
         uint32_t local_max = 0;
         for (int base = 0; base < n; base += 1024) {
             const int i = base + tid;
-            const uint32_t v = i < n ? (pass == 0 ? block_sums[i] : tile_count[i]) : 0u;
+            uint32_t v = 0;
+            if (i < n) {
+                if (pass == 0) v = block_sums[i];
+                else if (use_segs) {
+#pragma unroll
+                    for (int s = 0; s < FRG_BIN_SEGS; s++) v += seg_sums[(size_t)s * T + i];
+                    tile_count[i] = v;
+                } else v = tile_count[i];
+            }
             local_max = max(local_max, v);
             uint32_t inc = wave_incl_scan(v, lane);
             if (lane == 63) wtot[wave] = inc;
@@ -171,7 +251,18 @@ scan_kernel(int nblocks, uint32_t* __restrict__ block_sums, int T, const uint32_
             const uint32_t excl = carry + woff + inc - v;
             if (i < n) {
                 if (pass == 0) block_sums[i] = excl;
-                else ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
+                else {
+                    ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
+                    if (use_segs) {  // segment s of tile i starts at excl + sum of earlier segments
+                        uint32_t run = excl;
+#pragma unroll
+                        for (int s = 0; s < FRG_BIN_SEGS; s++) {
+                            const uint32_t c = seg_sums[(size_t)s * T + i];
+                            seg_sums[(size_t)s * T + i] = run;
+                            run += c;
+                        }
+                    }
+                }
             }
             __syncthreads();
             if (tid == 1023) carry_s = carry + woff + inc;
@@ -187,39 +278,66 @@ scan_kernel(int nblocks, uint32_t* __restrict__ block_sums, int T, const uint32_
     if (tid == 0) counters->max_tile_count = maxc_s;
 }
 
-// One thread per Gaussian: finish the inclusive scan (point_offsets, identical to
-// the reference's cub InclusiveSum output) and scatter (depth bits, index) into
-// the Gaussian's tiles.  The order inside a tile segment is arbitrary here; the
-// LDS sort orders by (depth, index), which equals the reference's stable sort of
-// index-ordered keys (rasterizer_impl.cu:98-108, :303-308).
+// Turns the count matrix into the base matrix in place: base[b][t] = first position
+// in point_list/pairs that workgroup b will write for tile t.
 __global__ void __launch_bounds__(256)
-scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float4* __restrict__ xydr,
-               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_prefix,
-               uint32_t* __restrict__ point_offsets, const uint2* __restrict__ ranges,
-               uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs)
+colbase_kernel(int T, int nrows, uint32_t* __restrict__ bin_matrix, const uint32_t* __restrict__ seg_start)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t touched = idx < P ? tiles_touched[idx] : 0u;
-    __shared__ uint32_t wsum[4];
-    const uint32_t inc = wave_incl_scan(touched, lane);
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t off = block_prefix[blockIdx.x];
-    for (int w = 0; w < wave; w++) off += wsum[w];
-    if (idx >= P) return;
-    point_offsets[idx] = off + inc;
-    if (touched == 0) return;
-    const float4 g = xydr[idx];
-    int x0, y0, x1, y1;
-    tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
-    const uint2 rec = make_uint2(__float_as_uint(g.z), (uint32_t)idx);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const int t = y * gx + x;
-            const uint32_t pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
-            pairs[pos] = rec;
-        }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int per = (nrows + FRG_BIN_SEGS - 1) / FRG_BIN_SEGS;
+    const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+    uint32_t run = seg_start[(size_t)blockIdx.y * T + t];
+#pragma unroll 8
+    for (int r = r0; r < r1; r++) {
+        const uint32_t c = bin_matrix[(size_t)r * T + t];
+        bin_matrix[(size_t)r * T + t] = run;
+        run += c;
+    }
+}
+
+// Same chunk -> workgroup map as preprocess.  Finishes the inclusive scan
+// (point_offsets, identical to the reference's cub InclusiveSum output) and scatters
+// (depth bits, index) into the Gaussian's tiles at base[workgroup][tile] + LDS rank.
+// The order inside a tile segment is arbitrary here; the LDS sort orders by
+// (depth, index), which equals the reference's stable sort of index-ordered keys
+// (rasterizer_impl.cu:98-108, :303-308).
+template <bool LDS_BINS>
+__global__ void __launch_bounds__(FRG_BIN_THREADS)
+scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float4* __restrict__ xydr,
+               const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ chunk_prefix,
+               uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ bin_matrix,
+               const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
+    __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
+    const int T = gx * gy;
+    if (LDS_BINS) {
+        const uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
+        for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = row[t];
+        __syncthreads();
+    }
+    const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int idx = c * FRG_BIN_THREADS + threadIdx.x;
+        const uint32_t touched = idx < P ? tiles_touched[idx] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
+        if (idx < P) point_offsets[idx] = chunk_prefix[c] + inc;
+        if (touched == 0) continue;
+        const float4 g = xydr[idx];
+        int x0, y0, x1, y1;
+        tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
+        const uint2 rec = make_uint2(__float_as_uint(g.z), (uint32_t)idx);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const int t = y * gx + x;
+                uint32_t pos;
+                if (LDS_BINS) pos = atomicAdd(&lds_bins[t], 1u);             // ds_add_rtn_u32
+                else pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
+                pairs[pos] = rec;
+            }
+    }
 }
 
 // rasterizer_impl.cu:54-66
@@ -238,31 +356,70 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 }
 
 // ---- host launchers -----------------------------------------------------------
+static int bin_blocks(int P)
+{
+    const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    return nchunks < FRG_BIN_MAX_BLOCKS ? nchunks : FRG_BIN_MAX_BLOCKS;
+}
+
+template <typename K>
+static hipError_t allow_big_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
                                  const ImageState& img, int prefiltered, hipStream_t s)
 {
-    const int nb = (P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, s, P, vp, in.viewmatrix, in.projmatrix, in.cam_pos,
-                       in.means3D, in.scales, in.rotations, in.opacities, in.shs, in.cov3D_precomp, in.colors_precomp,
-                       radii, g.xydr, g.conic_opacity, g.rgb_clamped, g.tiles_touched, img.tile_count, g.block_sums,
-                       img.counters, prefiltered);
+    const int T = vp.gx * vp.gy;
+    const int nb = bin_blocks(P);
+    if (img.lds_bins) {
+        const size_t lds = (size_t)T * 4;
+        hipError_t e = allow_big_lds(preprocess_fwd_kernel<true>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
+                           in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
+                           in.cov3D_precomp, in.colors_precomp, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
+                           g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
+    } else {
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nb), dim3(FRG_BIN_THREADS), 0, s, P, vp, in.viewmatrix,
+                           in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
+                           in.cov3D_precomp, in.colors_precomp, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
+                           g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, hipStream_t s)
 {
-    const int nb = (P + 255) / 256;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nb, g.block_sums, vp.gx * vp.gy, img.tile_count, img.ranges,
-                       img.counters);
+    const int T = vp.gx * vp.gy;
+    const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    const int nb = bin_blocks(P);
+    if (img.lds_bins)
+        hipLaunchKernelGGL(colsum_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
+                       img.lds_bins ? 1 : 0, img.ranges, img.counters);
+    if (img.lds_bins)
+        hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     return hipGetLastError();
 }
 
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
                           const BinningState& b, hipStream_t s)
 {
-    const int nb = (P + 255) / 256;
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, P, vp.gx, vp.gy, radii, g.xydr, g.tiles_touched,
-                       g.block_sums, g.point_offsets, img.ranges, img.tile_fill, b.pairs);
+    const int T = vp.gx * vp.gy;
+    const int nb = bin_blocks(P);
+    if (img.lds_bins) {
+        const size_t lds = (size_t)T * 4;
+        hipError_t e = allow_big_lds(scatter_kernel<true>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(scatter_kernel<true>, dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp.gx, vp.gy, radii, g.xydr,
+                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs);
+    } else {
+        hipLaunchKernelGGL(scatter_kernel<false>, dim3(nb), dim3(FRG_BIN_THREADS), 0, s, P, vp.gx, vp.gy, radii, g.xydr,
+                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs);
+    }
     return hipGetLastError();
 }
 

@@ -317,3 +317,22 @@ def test_full_size_c2_forward_vs_oracle(gpu_device):
     assert out[0] == o["num_rendered"]
     np.testing.assert_array_equal(out[2].cpu().numpy(), o["radii"])
     assert np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= L1_BAR
+
+
+def test_large_image_binning_path(gpu_device):
+    """Images with more tiles than fit the LDS histograms use global-atomic binning;
+    force that path on a small image and require identical artefacts."""
+    scene, cam, bg = scenes.config_scene("mini", 2, P=2500)
+    _lib.set_option("exact_blend", 1)
+    out_a, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    st_a = State(scene.P, cam.image_width, cam.image_height, out_a[0], out_a[3], out_a[4], out_a[5])
+    keys_a, pl_a, img_a = st_a.sort_keys().clone(), st_a.point_list.clone(), out_a[1].clone()
+    _lib.set_option("global_bins", 1)
+    try:
+        out_b, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        st_b = State(scene.P, cam.image_width, cam.image_height, out_b[0], out_b[3], out_b[4], out_b[5])
+        assert out_a[0] == out_b[0]
+        assert torch.equal(keys_a, st_b.sort_keys()) and torch.equal(pl_a, st_b.point_list)
+        assert torch.equal(img_a, out_b[1])
+    finally:
+        _lib.set_option("global_bins", 0)
