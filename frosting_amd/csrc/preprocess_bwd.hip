@@ -7,6 +7,17 @@
 // Every gradient row is written exactly once (zeros for culled Gaussians), so the
 // caller does not pre-zero ~300 B/Gaussian as the reference must
 // (rasterize_points.cu:151-159).
+//
+// wave64 structure (each wave owns 64 consecutive Gaussians, no workgroup barrier):
+//   1. slot reduction: the wave's Gaussians own one contiguous run of Gaussian-major
+//      slots; the 64 lanes walk that run 64 slots at a time (coalesced), find each
+//      slot's owner by binary search over the lane offsets in LDS, drop slots whose
+//      tile never processed them (tile cutoff key), and sum per owner with a
+//      segmented shuffle scan -- fixed order, no atomics, no per-lane loop whose
+//      length is the largest Gaussian of the wave;
+//   2. SH coefficients (192 B/Gaussian) are read, and their gradients written, as
+//      wave-contiguous float4 streams transposed through LDS 16 Gaussians at a time
+//      instead of 48 stride-192 dword accesses per lane.
 #include "gauss_math.h"
 #include "kernels.h"
 
@@ -14,7 +25,20 @@
 
 namespace frg {
 
-__global__ void __launch_bounds__(256)
+#define BWD_THREADS 256
+#define BWD_SUB 16                       // Gaussians per SH transpose step
+#define BWD_ROW_F4 13                    // 12 float4 of SH + 1 pad (odd stride: conflict-free b128)
+#define BWD_LDS_WORDS (68 + 256 + 576 + BWD_SUB * BWD_ROW_F4 * 4)
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool SH16>
+__global__ void __launch_bounds__(BWD_THREADS)
 preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                       const float* __restrict__ means3D, const int* __restrict__ radii,
@@ -27,39 +51,98 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(BWD_THREADS / 64) * BWD_LDS_WORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* lds = lds_all + wave * BWD_LDS_WORDS;
+    uint32_t* own_start = lds;                                   // [65] slot start relative to the wave's first slot
+    int4* own_info = reinterpret_cast<int4*>(lds + 68);          // [64] x0, y0, rect width, depth bits
+    float* acc = reinterpret_cast<float*>(lds + 68 + 256);       // [64][9]
+    float4* shbuf = reinterpret_cast<float4*>(lds + 68 + 256 + 576);  // [BWD_SUB][BWD_ROW_F4]
+
+    const int idx0 = blockIdx.x * BWD_THREADS + wave * 64;       // first Gaussian of this wave
+    const int idx = idx0 + lane;
+    const bool valid = idx < P;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
-    const int radius = radii[idx];
+
+    const int radius = valid ? radii[idx] : 0;
+    const bool visible = radius > 0;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t clamp_bits = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (visible) {
+        g = xydr[idx];
+        clamp_bits = __float_as_uint(rgb_clamped[idx].w);
+        tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
+    }
+    // ---- 1. slot reduction ------------------------------------------------------
+    const uint32_t incl = valid ? point_offsets[idx] : 0u;
+    const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
+    const uint32_t wave_base = (uint32_t)__shfl((int)base, 0, 64);
+    uint32_t S = valid ? incl - wave_base : 0u;  // run length = max over valid lanes
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) S = max(S, (uint32_t)__shfl_xor((int)S, d, 64));
+    own_start[lane] = valid ? base - wave_base : S;
+    if (lane == 0) own_start[64] = S;
+    own_info[lane] = make_int4(x0, y0, x1 - x0, (int)__float_as_uint(g.z));
+#pragma unroll
+    for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
+    wave_fence();
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool in_run = s < S;
+        int owner = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int mid = owner + step;
+            if (mid < 64 && own_start[mid] <= s) owner = mid;
+        }
+        float part[FRG_SLOT_FLOATS];
+#pragma unroll
+        for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
+        if (in_run) {
+            const int4 info = own_info[owner];
+            const uint32_t k = s - own_start[owner];
+            const uint32_t w = (uint32_t)info.z;
+            const uint32_t ry = k / w, rx = k - ry * w;
+            const uint2 cut = cutoff[(info.y + (int)ry) * vp.gx + info.x + (int)rx];
+            const uint32_t dbits = (uint32_t)info.w, gid = (uint32_t)(idx0 + owner);
+            // processed by the blend backward iff (depth, index) <= the tile's cutoff key
+            if (dbits < cut.x || (dbits == cut.x && gid <= cut.y)) {
+                const float* sp = slots + (size_t)(wave_base + s) * FRG_SLOT_FLOATS;
+#pragma unroll
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
+            }
+        } else {
+            owner = 64 + lane;  // unique: never merges with a neighbour
+        }
+        // segmented inclusive scan over lanes (owners are non-decreasing with the lane)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o_up = __shfl_up(owner, d, 64);
+            const bool take = lane >= d && o_up == owner;
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) {
+                const float v_up = __shfl_up(part[c], d, 64);
+                part[c] += take ? v_up : 0.0f;
+            }
+        }
+        const int o_next = __shfl_down(owner, 1, 64);
+        if (in_run && (lane == 63 || o_next != owner)) {
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[owner * FRG_SLOT_FLOATS + c] += part[c];
+        }
+        wave_fence();
+    }
     float part[FRG_SLOT_FLOATS];
 #pragma unroll
-    for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
+    for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = acc[lane * FRG_SLOT_FLOATS + c];
+
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool visible = radius > 0;
     float3 mean = make_float3(0.f, 0.f, 0.f);
-    uint32_t clamp_bits = 0;
     if (visible) {
         mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-        // ---- 1. sum this Gaussian's (tile) partials in emission order (y-major, x) ----
-        const float4 g = xydr[idx];
-        clamp_bits = __float_as_uint(rgb_clamped[idx].w);
-        int x0, y0, x1, y1;
-        tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
-        const uint32_t base = idx == 0 ? 0u : point_offsets[idx - 1];
-        const uint32_t dbits = __float_as_uint(g.z);
-        uint32_t s = base;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++, s++) {
-                // processed by the blend backward iff (depth, index) <= the tile's cutoff key
-                const uint2 cut = cutoff[y * vp.gx + x];
-                const bool in_prefix = dbits < cut.x || (dbits == cut.x && (uint32_t)idx <= cut.y);
-                if (!in_prefix) continue;
-                const float* sp = slots + (size_t)s * FRG_SLOT_FLOATS;
-#pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] += sp[c];
-            }
         // ---- 2. computeCov2DCUDA (backward.cu:144-274) ----
         float cov[6];
         if (cov3D_precomp) {
@@ -127,34 +210,63 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
     }
     // screen-space outputs (also returned to the caller: viewspace gradients)
-    dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
-    *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
-    dL_dopacity[idx] = part[8];
-    dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2];
+    if (valid) {
+        dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
+        *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
+        dL_dopacity[idx] = part[8];
+        dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2];
+    }
 
     // ---- 4. SH path (backward.cu:20-139) ----
     if (shs) {
-        float* out = dL_dsh + (size_t)idx * vp.M * 3;
-        if (!visible) {
-            for (int i = 0; i < vp.M * 3; i++) out[i] = 0.0f;
-        } else {
-            const float* sh = shs + (size_t)idx * vp.M * 3;
+        float sh[48], wgt[16], dRGB[3] = {0.f, 0.f, 0.f};  // dL/dsh[i][ch] = wgt[i] * dRGB[ch]
+#pragma unroll
+        for (int i = 0; i < 48; i++) sh[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
+        const int M = vp.M;
+        if (SH16) {
+            // coalesced read: the wave's 64 x 48 floats are one contiguous stream of 768 float4
+            const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
+            const int nvalid = min(64, P - idx0);
+#pragma unroll 1
+            for (int h = 0; h < 64 / BWD_SUB; h++) {
+#pragma unroll
+                for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
+                    const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
+                    if (h * BWD_SUB + gl < nvalid) shbuf[gl * BWD_ROW_F4 + j] = src[(size_t)h * BWD_SUB * 12 + f];
+                }
+                wave_fence();
+                if ((lane / BWD_SUB) == h) {
+#pragma unroll
+                    for (int j = 0; j < 12; j++) {
+                        const float4 v = shbuf[(lane % BWD_SUB) * BWD_ROW_F4 + j];
+                        sh[4 * j] = v.x; sh[4 * j + 1] = v.y; sh[4 * j + 2] = v.z; sh[4 * j + 3] = v.w;
+                    }
+                }
+                wave_fence();
+            }
+        } else if (visible) {
+            const float* s = shs + (size_t)idx * M * 3;
+            const int n = min(M, 16) * 3;
+#pragma unroll
+            for (int i = 0; i < 48; i++)
+                if (i < n) sh[i] = s[i];
+        }
+        if (visible) {
             const float dox = mean.x - vmx.campos[0], doy = mean.y - vmx.campos[1], doz = mean.z - vmx.campos[2];
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
             const float x = dox / len, y = doy / len, z = doz / len;
-            float dRGB[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
             float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
             const int deg = vp.D;
 #define SH_(i, ch) sh[(i) * 3 + (ch)]
-#define OUT_(i, wgt) { _Pragma("unroll") for (int ch = 0; ch < 3; ch++) out[(i) * 3 + ch] = (wgt) * dRGB[ch]; }
+#define OUT_(i, wv) wgt[i] = (wv)
             OUT_(0, kSH0);
-            int written = 1;
             if (deg > 0) {
                 const float w1 = -kSH1 * y, w2 = kSH1 * z, w3 = -kSH1 * x;
                 OUT_(1, w1); OUT_(2, w2); OUT_(3, w3);
-                written = 4;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     ddx[ch] = -kSH1 * SH_(3, ch); ddy[ch] = -kSH1 * SH_(1, ch); ddz[ch] = kSH1 * SH_(2, ch);
@@ -164,7 +276,6 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                     const float w4 = kSH2[0] * xy, w5 = kSH2[1] * yz, w6 = kSH2[2] * (2.f * zz - xx - yy);
                     const float w7 = kSH2[3] * xz, w8 = kSH2[4] * (xx - yy);
                     OUT_(4, w4); OUT_(5, w5); OUT_(6, w6); OUT_(7, w7); OUT_(8, w8);
-                    written = 9;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
                         ddx[ch] += kSH2[0] * y * SH_(4, ch) + kSH2[2] * 2.f * -x * SH_(6, ch) + kSH2[3] * z * SH_(7, ch) + kSH2[4] * 2.f * x * SH_(8, ch);
@@ -177,7 +288,6 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                         const float w13 = kSH3[4] * x * (4.f * zz - xx - yy), w14 = kSH3[5] * z * (xx - yy);
                         const float w15 = kSH3[6] * x * (xx - 3.f * yy);
                         OUT_(9, w9); OUT_(10, w10); OUT_(11, w11); OUT_(12, w12); OUT_(13, w13); OUT_(14, w14); OUT_(15, w15);
-                        written = 16;
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
                             ddx[ch] += (kSH3[0] * SH_(9, ch) * 3.f * 2.f * xy + kSH3[1] * SH_(10, ch) * yz + kSH3[2] * SH_(11, ch) * -2.f * xy +
@@ -196,7 +306,6 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             }
 #undef SH_
 #undef OUT_
-            for (int i = written * 3; i < vp.M * 3; i++) out[i] = 0.0f;  // coefficients above the active degree
             const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
             const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
             const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
@@ -207,13 +316,44 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             dmean[1] += (-dox * doy * dd0 + (sum2 - doy * doy) * dd1 - doz * doy * dd2) * invsum32;
             dmean[2] += (-dox * doz * dd0 - doy * doz * dd1 + (sum2 - doz * doz) * dd2) * invsum32;
         }
-    }
-    dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+        // gradient rows: coefficients above the active degree and culled Gaussians are zero
+        if (SH16) {
+            float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)idx0 * 12;
+            const int nvalid = min(64, P - idx0);
+#pragma unroll 1
+            for (int h = 0; h < 64 / BWD_SUB; h++) {
+                if ((lane / BWD_SUB) == h) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+                    for (int j = 0; j < 12; j++)
+                        shbuf[(lane % BWD_SUB) * BWD_ROW_F4 + j] =
+                            make_float4(wgt[(4 * j) / 3] * dRGB[(4 * j) % 3], wgt[(4 * j + 1) / 3] * dRGB[(4 * j + 1) % 3],
+                                        wgt[(4 * j + 2) / 3] * dRGB[(4 * j + 2) % 3], wgt[(4 * j + 3) / 3] * dRGB[(4 * j + 3) % 3]);
+                }
+                wave_fence();
+#pragma unroll
+                for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
+                    const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
+                    if (h * BWD_SUB + gl < nvalid) dst[(size_t)h * BWD_SUB * 12 + f] = shbuf[gl * BWD_ROW_F4 + j];
+                }
+                wave_fence();
+            }
+        } else if (valid) {
+            float* o = dL_dsh + (size_t)idx * M * 3;
+            const int n = min(M, 16) * 3;
+#pragma unroll
+            for (int i = 0; i < 48; i++)
+                if (i < n) o[i] = wgt[i / 3] * dRGB[i % 3];
+            for (int i = 48; i < M * 3; i++) o[i] = 0.0f;
+        }
+    }
+    if (valid) {
+        dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+    }
 
     // ---- 5. cov3D -> scale, quaternion (backward.cu:278-341) ----
-    if (scales) {
+    if (scales && valid) {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         if (visible) {
             const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
@@ -254,10 +394,20 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, hipStream_t s)
 {
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, vp, in.viewmatrix, in.projmatrix,
-                       in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
-                       g.rgb_clamped, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
-                       o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
+    const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
+    // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
+    const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(o.dL_dsh) % 16 == 0);
+    if (sh16)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,
+                           in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
+                           g.rgb_clamped, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
+                           o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,
+                           in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
+                           g.rgb_clamped, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
+                           o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
     return hipGetLastError();
 }
 
