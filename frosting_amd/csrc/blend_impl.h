@@ -6,6 +6,12 @@
 //     broadcast read of a staged Gaussian is amortised over 4 pixel evaluations;
 //   * instances are staged 64 at a time through LDS from 16-byte per-Gaussian
 //     records (three global_load_dwordx4 gathers per instance);
+//   * EXACT QUADRANT CULLING: while staging, the lane that fetched a Gaussian bounds
+//     its falloff over each 8x8 quadrant (power <= -1/2 lambda_min dist^2) and drops
+//     quadrants -- and, by ballot compaction, whole instances -- where alpha is
+//     provably below the reference's 1/255 cut-off.  The reference's tile lists are
+//     3-sigma squares, so ~40 % of instances and ~70 % of quadrant evaluations go away
+//     while every pixel keeps exactly the value it would have had;
 //   * backward: the per-(tile,Gaussian) gradient is reduced across the wave with a
 //     fixed DPP tree and written ONCE, without atomics, into the instance's
 //     Gaussian-major slot; the per-Gaussian backward kernel sums the slots in a
@@ -27,9 +33,9 @@ struct BlendMath;
 
 template <>
 struct BlendMath<true> {
-    static __device__ __forceinline__ float power(float2 xy, float4 co, float px, float py, float& dx, float& dy)
+    static __device__ __forceinline__ float power(float x, float y, float4 co, float px, float py, float& dx, float& dy)
     {
-        dx = xy.x - px; dy = xy.y - py;
+        dx = x - px; dy = y - py;
         return -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
     }
     static __device__ __forceinline__ float expo(float p) { return expf(p); }
@@ -38,9 +44,9 @@ struct BlendMath<true> {
 
 template <>
 struct BlendMath<false> {
-    static __device__ __forceinline__ float power(float2 xy, float4 co, float px, float py, float& dx, float& dy)
+    static __device__ __forceinline__ float power(float x, float y, float4 co, float px, float py, float& dx, float& dy)
     {
-        dx = xy.x - px; dy = xy.y - py;
+        dx = x - px; dy = y - py;
         return -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
     }
     static __device__ __forceinline__ float expo(float p) { return __expf(p); }
@@ -53,6 +59,38 @@ __device__ __forceinline__ void lane_pixel(int lane, int q, int tx, int ty, int&
     px = tx * FRG_TILE + (q & 1) * 8 + (lane & 7);
     py = ty * FRG_TILE + (q >> 1) * 8 + (lane >> 3);
 }
+
+// Bit q set <=> some pixel of quadrant q of tile (tx,ty) may reach alpha >= 1/255.
+// alpha = min(0.99, o * exp(power)) with power = -1/2 d^T C d <= -1/2 lambda_min |d|^2,
+// so alpha < 1/255 whenever 1/2 lambda_min dist^2 > ln(255 o), dist = distance from
+// the centre to the quadrant's pixel rectangle.  Margins (0.1 % relative, 0.02
+// absolute on a threshold <= 5.6) dominate the rounding of the per-pixel evaluation
+// (|error| <= ~1e-6 * lambda_max * d^2, lambda_max <= 1/0.3 by the low-pass, d^2 <= 512),
+// so the cull never removes a pixel the reference would have blended.
+__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float4 co, int tx, int ty)
+{
+    const float o = co.w;
+    if (!(o >= 1.0f / 255.0f)) return (o != o) ? 0xFu : 0u;  // exp(power) <= 1 => alpha <= o < 1/255 everywhere
+    const float a = co.x, b = co.y, c = co.z;
+    const float mid = 0.5f * (a + c), det = a * c - b * b;
+    const float lam_max = mid + sqrtf(fmaxf(mid * mid - det, 0.0f));
+    float lam_min = (det > 0.0f && lam_max > 0.0f) ? det / lam_max : 0.0f;
+    if (!(lam_min == lam_min)) lam_min = 0.0f;
+    const float thr = __logf(255.0f * o) + 0.02f;
+    const float k = 0.5f * lam_min * 0.999f;
+    const float X0 = (float)(tx * FRG_TILE), Y0 = (float)(ty * FRG_TILE);
+    // distances to the two column bands [X0,X0+7], [X0+8,X0+15] and two row bands
+    const float dxl = fmaxf(fmaxf(X0 - x, x - (X0 + 7.0f)), 0.0f), dxr = fmaxf(fmaxf(X0 + 8.0f - x, x - (X0 + 15.0f)), 0.0f);
+    const float dyt = fmaxf(fmaxf(Y0 - y, y - (Y0 + 7.0f)), 0.0f), dyb = fmaxf(fmaxf(Y0 + 8.0f - y, y - (Y0 + 15.0f)), 0.0f);
+    uint32_t m = 0;
+    if (!(k * (dxl * dxl + dyt * dyt) > thr)) m |= 1u;
+    if (!(k * (dxr * dxr + dyt * dyt) > thr)) m |= 2u;
+    if (!(k * (dxl * dxl + dyb * dyb) > thr)) m |= 4u;
+    if (!(k * (dxr * dxr + dyb * dyb) > thr)) m |= 8u;
+    return m;
+}
+
+__device__ __forceinline__ int lanes_before(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 
 // ---------------------------------------------------------------------------
 template <bool EXACT>
@@ -71,54 +109,67 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
 
-    __shared__ float2 s_xy[64];
-    __shared__ float4 s_co[64];
+    __shared__ float4 s_a[64];    // x, y, quadrant mask bits, contributor (1-based list position)
+    __shared__ float4 s_co[64];   // conic a, b, c, opacity
     __shared__ float4 s_rgb[64];
 
     float pxf[4], pyf[4], Tr[4], C[4][3];
     uint32_t last[4];
-    bool inside[4];
+    int pix[4];
     uint32_t live = 0;  // bit q set while pixel q still blends
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int px, py;
         lane_pixel(lane, q, tx, ty, px, py);
         pxf[q] = (float)px; pyf[q] = (float)py;
-        inside[q] = px < W && py < H;
-        if (inside[q]) live |= 1u << q;
+        const bool inside = px < W && py < H;
+        pix[q] = inside ? py * W + px : -1;
+        if (inside) live |= 1u << q;
         Tr[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.0f; last[q] = 0;
     }
 
     for (int base = 0; base < n; base += 64) {
         if (__ballot(live != 0) == 0ull) break;  // whole tile saturated
         const int cnt = min(64, n - base);
-        __syncthreads();
+        uint32_t m = 0;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
         if (lane < cnt) {
             const uint32_t id = point_list[rg.x + base + lane];
-            const float4 a = xydr[id];
-            s_xy[lane] = make_float2(a.x, a.y);
-            s_co[lane] = conic_opacity[id];
-            s_rgb[lane] = rgb_clamped[id];
+            a = xydr[id];
+            co = conic_opacity[id];
+            col = rgb_clamped[id];
+            m = quadrant_mask(a.x, a.y, co, tx, ty);
+        }
+        const uint64_t keep = __ballot(m != 0);
+        const int nkeep = __popcll(keep);
+        __syncthreads();
+        if (m != 0) {
+            const int d = lanes_before(keep, lane);
+            s_a[d] = make_float4(a.x, a.y, __uint_as_float(m), __uint_as_float((uint32_t)(base + lane + 1)));
+            s_co[d] = co;
+            s_rgb[d] = col;
         }
         __syncthreads();
-        for (int j = 0; live != 0 && j < cnt; j++) {
-            const float2 xy = s_xy[j];
-            const float4 co = s_co[j];
-            const uint32_t contributor = (uint32_t)(base + j + 1);
+        for (int j = 0; live != 0 && j < nkeep; j++) {
+            const float4 ga = s_a[j];
+            const float4 gco = s_co[j];
+            const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(ga.z));
+            const uint32_t contributor = __float_as_uint(ga.w);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                if (!(qm & (1u << q))) continue;       // wave-uniform: quadrant provably untouched
                 if (!(live & (1u << q))) continue;
                 float dx, dy;
-                const float power = M::power(xy, co, pxf[q], pyf[q], dx, dy);
+                const float power = M::power(ga.x, ga.y, gco, pxf[q], pyf[q], dx, dy);
                 if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, co.w * M::expo(power));
+                const float alpha = fminf(0.99f, gco.w * M::expo(power));
                 if (alpha < 1.0f / 255.0f) continue;
                 const float test_T = Tr[q] * (1 - alpha);
                 if (test_T < 0.0001f) { live &= ~(1u << q); continue; }
-                const float4 col = s_rgb[j];
-                C[q][0] += M::mul3(col.x, alpha, Tr[q]);
-                C[q][1] += M::mul3(col.y, alpha, Tr[q]);
-                C[q][2] += M::mul3(col.z, alpha, Tr[q]);
+                const float4 gc = s_rgb[j];
+                C[q][0] += M::mul3(gc.x, alpha, Tr[q]);
+                C[q][1] += M::mul3(gc.y, alpha, Tr[q]);
+                C[q][2] += M::mul3(gc.z, alpha, Tr[q]);
                 Tr[q] = test_T;
                 last[q] = contributor;
             }
@@ -129,8 +180,8 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     const size_t plane = (size_t)H * W;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        if (!inside[q]) continue;
-        const size_t pid = (size_t)pyf[q] * W + (size_t)pxf[q];
+        if (pix[q] < 0) continue;
+        const size_t pid = (size_t)pix[q];
         final_T[pid] = Tr[q];
         n_contrib[pid] = last[q];
         out_color[pid] = C[q][0] + Tr[q] * bg0;
@@ -175,12 +226,18 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     const int lane = threadIdx.x;
     const uint2 rg = ranges[tile];
 
-    __shared__ float2 s_xy[64];
+    __shared__ float4 s_a[64];     // x, y, quadrant mask, 0-based list position
     __shared__ float4 s_co[64];
-    __shared__ float4 s_rgb[64];
+    __shared__ float4 s_rgb[64];   // r, g, b, Gaussian-major slot index
     __shared__ float s_part[64 * FRG_SLOT_FLOATS];
 
-    float pxf[4], pyf[4], Tr[4], Tfin[4], dLp[4][3], accum[4][3], lastc[4][3], lasta[4], bgdot[4];
+    // Per-pixel state of the back-to-front walk.  The reference carries the colour
+    // composited behind the current Gaussian (accum_rec, last_color, last_alpha:
+    // backward.cu:508-521); we carry the equivalent scalar
+    //     S = sum_ch dL/dC_ch * (colour already composited behind) + T_final * (bg . dL/dC)
+    // so that dL/dalpha_i = T_i * (c_i . dL/dC) - S / (1 - alpha_i), then S += alpha_i T_i (c_i . dL/dC).
+    // Same mathematics, 2 registers instead of 9 per pixel.
+    float pxf[4], pyf[4], Tr[4], S[4], dLp[4][3];
     uint32_t lastcon[4];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t plane = (size_t)H * W;
@@ -192,17 +249,12 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         pxf[q] = (float)px; pyf[q] = (float)py;
         const bool inside = px < W && py < H;
         const size_t pid = (size_t)py * W + px;
-        Tfin[q] = inside ? final_T[pid] : 0.0f;
-        Tr[q] = Tfin[q];
+        Tr[q] = inside ? final_T[pid] : 0.0f;
         lastcon[q] = inside ? n_contrib[pid] : 0u;
         maxc = max(maxc, lastcon[q]);
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            dLp[q][ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
-            accum[q][ch] = 0.0f; lastc[q][ch] = 0.0f;
-        }
-        lasta[q] = 0.0f;
-        bgdot[q] = bg0 * dLp[q][0] + bg1 * dLp[q][1] + bg2 * dLp[q][2];
+        for (int ch = 0; ch < 3; ch++) dLp[q][ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
+        S[q] = Tr[q] * (bg0 * dLp[q][0] + bg1 * dLp[q][1] + bg2 * dLp[q][2]);
     }
     // tile-wide number of list entries that can still receive gradient
 #pragma unroll
@@ -221,59 +273,70 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     // walk the processed prefix [0, maxc) back to front, 64 instances at a time
     for (int hi = (int)maxc - 1; hi >= 0; hi -= 64) {
         const int cnt = min(64, hi + 1);
-        uint32_t my_slot = 0;
-        __syncthreads();
+        uint32_t m = 0, my_slot = 0;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
         if (lane < cnt) {
             const uint32_t id = point_list[rg.x + hi - lane];
-            const float4 a = xydr[id];
-            s_xy[lane] = make_float2(a.x, a.y);
-            s_co[lane] = conic_opacity[id];
-            s_rgb[lane] = rgb_clamped[id];
+            a = xydr[id];
+            co = conic_opacity[id];
+            col = rgb_clamped[id];
+            m = quadrant_mask(a.x, a.y, co, tx, ty);
             // Gaussian-major slot of this (Gaussian, tile) instance: position in the
             // reference's duplicateWithKeys emission order (rasterizer_impl.cu:98-108)
             int x0, y0, x1, y1;
             tile_rect(a.x, a.y, (int)a.w, gx, gy, x0, y0, x1, y1);
             const uint32_t off = id == 0 ? 0u : point_offsets[id - 1];
             my_slot = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            if (m == 0) {  // provably no contribution in this tile: the slot is still owed a value
+                float* dst = slots + (size_t)my_slot * FRG_SLOT_FLOATS;
+#pragma unroll
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) dst[c] = 0.0f;
+            }
+        }
+        const uint64_t keep = __ballot(m != 0);
+        const int nkeep = __popcll(keep);
+        __syncthreads();
+        if (m != 0) {
+            const int d = lanes_before(keep, lane);
+            s_a[d] = make_float4(a.x, a.y, __uint_as_float(m), __uint_as_float((uint32_t)(hi - lane)));
+            s_co[d] = co;
+            s_rgb[d] = make_float4(col.x, col.y, col.z, __uint_as_float(my_slot));
         }
         __syncthreads();
-        for (int k = 0; k < cnt; k++) {
-            const int pos = hi - k;  // 0-based position in the tile list
-            const float2 xy = s_xy[k];
-            const float4 co = s_co[k];
-            const float4 col = s_rgb[k];
+        for (int k = 0; k < nkeep; k++) {
+            const float4 ga = s_a[k];
+            const float4 gco = s_co[k];
+            const float4 gc = s_rgb[k];
+            const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(ga.z));
+            const uint32_t pos = __float_as_uint(ga.w);  // 0-based position in the tile list
             float part[FRG_SLOT_FLOATS];
 #pragma unroll
             for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if ((uint32_t)pos >= lastcon[q]) continue;
+                if (!(qm & (1u << q))) continue;
+                if (pos >= lastcon[q]) continue;
                 float dx, dy;
-                const float power = M::power(xy, co, pxf[q], pyf[q], dx, dy);
+                const float power = M::power(ga.x, ga.y, gco, pxf[q], pyf[q], dx, dy);
                 if (power > 0.0f) continue;
                 const float G = M::expo(power);
-                const float alpha = fminf(0.99f, co.w * G);
+                const float alpha = fminf(0.99f, gco.w * G);
                 if (alpha < 1.0f / 255.0f) continue;
                 any = true;
-                Tr[q] = Tr[q] / (1.f - alpha);
-                const float dchannel_dcolor = alpha * Tr[q];
-                float dL_dalpha = 0.0f;
-                const float cc[3] = {col.x, col.y, col.z};
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    accum[q][ch] = lasta[q] * lastc[q][ch] + (1.f - lasta[q]) * accum[q][ch];
-                    lastc[q][ch] = cc[ch];
-                    dL_dalpha += (cc[ch] - accum[q][ch]) * dLp[q][ch];
-                    part[ch] += dchannel_dcolor * dLp[q][ch];
-                }
-                dL_dalpha *= Tr[q];
-                lasta[q] = alpha;
-                dL_dalpha += (-Tfin[q] / (1.f - alpha)) * bgdot[q];
-                const float dL_dG = co.w * dL_dalpha;
+                const float one_m = 1.f - alpha;
+                Tr[q] = Tr[q] / one_m;                       // transmittance in front of this Gaussian
+                const float w = alpha * Tr[q];               // dC/dcolour
+                const float cdot = gc.x * dLp[q][0] + gc.y * dLp[q][1] + gc.z * dLp[q][2];
+                part[0] += w * dLp[q][0];
+                part[1] += w * dLp[q][1];
+                part[2] += w * dLp[q][2];
+                const float dL_dalpha = Tr[q] * cdot - S[q] / one_m;
+                S[q] += w * cdot;
+                const float dL_dG = gco.w * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                const float dG_ddelx = -gdx * gco.x - gdy * gco.y;
+                const float dG_ddely = -gdy * gco.z - gdx * gco.y;
                 part[3] += dL_dG * dG_ddelx * ddelx_dx;
                 part[4] += dL_dG * dG_ddely * ddely_dy;
                 part[5] += -0.5f * gdx * dx * dL_dG;
@@ -291,8 +354,9 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             }
         }
         __syncthreads();
-        if (lane < cnt) {
-            float* dst = slots + (size_t)my_slot * FRG_SLOT_FLOATS;
+        if (lane < nkeep) {
+            const uint32_t slot = __float_as_uint(s_rgb[lane].w);
+            float* dst = slots + (size_t)slot * FRG_SLOT_FLOATS;
 #pragma unroll
             for (int c = 0; c < FRG_SLOT_FLOATS; c++) dst[c] = s_part[lane * FRG_SLOT_FLOATS + c];
         }
