@@ -150,6 +150,8 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             s_rgb[d] = col;
         }
         __syncthreads();
+        // (A branch-free evaluation of all four quadrants was measured slower here: it needs
+        // 77 VGPRs, dropping from 8 to 6 waves per SIMD, and this loop is latency-bound.)
         for (int j = 0; live != 0 && j < nkeep; j++) {
             const float4 ga = s_a[j];
             const float4 gco = s_co[j];
@@ -302,52 +304,58 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             s_co[d] = co;
             s_rgb[d] = make_float4(col.x, col.y, col.z, __uint_as_float(my_slot));
         }
+#pragma unroll
+        for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[lane * FRG_SLOT_FLOATS + c] = 0.0f;
         __syncthreads();
+        float4 ga = s_a[0], gco = s_co[0];
         for (int k = 0; k < nkeep; k++) {
-            const float4 ga = s_a[k];
-            const float4 gco = s_co[k];
+            const float4 ca = ga, cco = gco;
+            if (k + 1 < nkeep) { ga = s_a[k + 1]; gco = s_co[k + 1]; }
+            const uint32_t qm = __float_as_uint(ca.z);
+            const uint32_t pos = __float_as_uint(ca.w);  // 0-based position in the tile list
+            // phase 1: falloff of all four quadrants, branch-free (independent exp chains)
+            float G[4], alpha[4], dxs[4], dys[4];
+            uint32_t ok = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float power = M::power(ca.x, ca.y, cco, pxf[q], pyf[q], dxs[q], dys[q]);
+                G[q] = M::expo(power);
+                alpha[q] = fminf(0.99f, cco.w * G[q]);
+                if (pos < lastcon[q] && !(power > 0.0f) && !(alpha[q] < 1.0f / 255.0f)) ok |= 1u << q;
+            }
+            ok &= qm;
+            if (__ballot(ok != 0) == 0ull) continue;  // row k of s_part stays zero
+            // phase 2: gradient contributions of the pixels that blended this Gaussian
             const float4 gc = s_rgb[k];
-            const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(ga.z));
-            const uint32_t pos = __float_as_uint(ga.w);  // 0-based position in the tile list
             float part[FRG_SLOT_FLOATS];
 #pragma unroll
             for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
-            bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (!(qm & (1u << q))) continue;
-                if (pos >= lastcon[q]) continue;
-                float dx, dy;
-                const float power = M::power(ga.x, ga.y, gco, pxf[q], pyf[q], dx, dy);
-                if (power > 0.0f) continue;
-                const float G = M::expo(power);
-                const float alpha = fminf(0.99f, gco.w * G);
-                if (alpha < 1.0f / 255.0f) continue;
-                any = true;
-                const float one_m = 1.f - alpha;
+                if (__ballot((ok >> q) & 1u) == 0ull) continue;   // wave-uniform
+                if (!((ok >> q) & 1u)) continue;
+                const float one_m = 1.f - alpha[q];
                 Tr[q] = Tr[q] / one_m;                       // transmittance in front of this Gaussian
-                const float w = alpha * Tr[q];               // dC/dcolour
+                const float w = alpha[q] * Tr[q];            // dC/dcolour
                 const float cdot = gc.x * dLp[q][0] + gc.y * dLp[q][1] + gc.z * dLp[q][2];
                 part[0] += w * dLp[q][0];
                 part[1] += w * dLp[q][1];
                 part[2] += w * dLp[q][2];
                 const float dL_dalpha = Tr[q] * cdot - S[q] / one_m;
                 S[q] += w * cdot;
-                const float dL_dG = gco.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * gco.x - gdy * gco.y;
-                const float dG_ddely = -gdy * gco.z - gdx * gco.y;
+                const float dL_dG = cco.w * dL_dalpha;
+                const float gdx = G[q] * dxs[q], gdy = G[q] * dys[q];
+                const float dG_ddelx = -gdx * cco.x - gdy * cco.y;
+                const float dG_ddely = -gdy * cco.z - gdx * cco.y;
                 part[3] += dL_dG * dG_ddelx * ddelx_dx;
                 part[4] += dL_dG * dG_ddely * ddely_dy;
-                part[5] += -0.5f * gdx * dx * dL_dG;
-                part[6] += -0.5f * gdx * dy * dL_dG;
-                part[7] += -0.5f * gdy * dy * dL_dG;
-                part[8] += G * dL_dalpha;
+                part[5] += -0.5f * gdx * dxs[q] * dL_dG;
+                part[6] += -0.5f * gdx * dys[q] * dL_dG;
+                part[7] += -0.5f * gdy * dys[q] * dL_dG;
+                part[8] += G[q] * dL_dalpha;
             }
-            if (__ballot(any) != 0ull) {
 #pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = wave_sum_to_lane63(part[c]);
-            }
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = wave_sum_to_lane63(part[c]);
             if (lane == 63) {
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[k * FRG_SLOT_FLOATS + c] = part[c];
