@@ -78,7 +78,7 @@ def lib():
     L.frg_stage_times.restype = i
     L.frg_stage_times.argtypes = [vp, i]
     L.frg_mesh_raster_workspace_bytes.restype = sz
-    L.frg_mesh_raster_workspace_bytes.argtypes = [i, i]
+    L.frg_mesh_raster_workspace_bytes.argtypes = [i, i, i]
     L.frg_mesh_rasterize.restype = i
     L.frg_mesh_rasterize.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
     _lib = L

@@ -1,7 +1,206 @@
-// Triangle occlusion raster (placeholder TU until the kernel lands).
+// Triangle occlusion raster: the z-buffered "which face does each pixel see" pass that
+// Frosting runs on the shell base mesh for occlusion culling and texture baking
+// (frosting_utils/mesh_rasterization.py:109-156 -> frosting_utils/nvdiffrast.py:53,
+// third-party nvdiffrast `dr.rasterize`, not in the reference tree).  Same contract:
+//   pos  [V,4] clip-space vertices (x, y, z, w) = [v,1] @ full_proj_transform
+//   tri  [F,3] int32
+//   rast [H,W,4] float32 = (u, v, z/w, triangle_id + 1), all zero where no triangle;
+//        u, v = perspective-correct barycentrics of vertex 0 and 1; pixel (col i, row j) is
+//        sampled at NDC ((i+0.5)/W*2-1, (j+0.5)/H*2-1); fragments outside -1 <= z/w <= 1 or
+//        behind the eye are discarded; nearest z/w wins, ties go to the smaller triangle id.
+//
+// 2-D homogeneous rasterisation (edge functions from the adjugate of [x y w]), so triangles
+// that cross the w = 0 plane need no clipping.  One thread per triangle walks its pixel
+// bounding box and depth-tests with a 64-bit atomicMin on (ordered depth << 32 | id);
+// triangles covering many pixels are deferred to a workgroup-per-triangle pass.  A resolve
+// pass recomputes the attributes of each pixel's winner.
 #include "../../include/frosting_rasterizer.h"
 #include "frg_common.h"
-extern "C" {
-size_t frg_mesh_raster_workspace_bytes(int width, int height) { return frg::align_up((size_t)width * height * 8, 256); }
-int frg_mesh_rasterize(int, int, const float*, const int*, int, int, float*, char*, size_t, void*) { return FRG_EINVAL; }
+
+namespace frg {
+
+#define MESH_BIG_AREA 1024  // bounding boxes above this many pixels go to the cooperative pass
+
+struct TriSetup {
+    // edge functions e_i(X,Y) = a_i X + b_i Y + c_i (NDC), e_i / sum(e) = perspective-correct barycentric
+    float a[3], b[3], c[3];
+    float z[3], w[3];
+    int x0, y0, x1, y1;  // pixel bounding box [x0,x1) x [y0,y1)
+    bool ok;
+};
+
+__device__ __forceinline__ uint32_t ordered_depth(float z)
+{
+    const uint32_t u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
 }
+
+__device__ __forceinline__ TriSetup tri_setup(const float4 v0, const float4 v1, const float4 v2, int W, int H)
+{
+    TriSetup t;
+    t.ok = false;
+    // adjugate of M = [[x0 x1 x2],[y0 y1 y2],[w0 w1 w2]] (double: the determinant cancels badly for slivers)
+    const double x0 = v0.x, y0 = v0.y, w0 = v0.w, x1 = v1.x, y1 = v1.y, w1 = v1.w, x2 = v2.x, y2 = v2.y, w2 = v2.w;
+    const double a0 = y1 * w2 - y2 * w1, b0 = x2 * w1 - x1 * w2, c0 = x1 * y2 - x2 * y1;
+    const double a1 = y2 * w0 - y0 * w2, b1 = x0 * w2 - x2 * w0, c1 = x2 * y0 - x0 * y2;
+    const double a2 = y0 * w1 - y1 * w0, b2 = x1 * w0 - x0 * w1, c2 = x0 * y1 - x1 * y0;
+    const double det = x0 * a0 + y0 * b0 + w0 * c0;
+    if (!(det != 0.0) || det != det) return t;   // degenerate (zero area in homogeneous space)
+    const double inv = 1.0 / det;                 // dividing by det also folds the facing into the sign
+    t.a[0] = (float)(a0 * inv); t.b[0] = (float)(b0 * inv); t.c[0] = (float)(c0 * inv);
+    t.a[1] = (float)(a1 * inv); t.b[1] = (float)(b1 * inv); t.c[1] = (float)(c1 * inv);
+    t.a[2] = (float)(a2 * inv); t.b[2] = (float)(b2 * inv); t.c[2] = (float)(c2 * inv);
+    t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
+    t.w[0] = v0.w; t.w[1] = v1.w; t.w[2] = v2.w;
+    // bounding box: exact when every vertex is in front of the eye, whole screen otherwise
+    if (v0.w > 1e-6f && v1.w > 1e-6f && v2.w > 1e-6f) {
+        const float nx0 = v0.x / v0.w, nx1 = v1.x / v1.w, nx2 = v2.x / v2.w;
+        const float ny0 = v0.y / v0.w, ny1 = v1.y / v1.w, ny2 = v2.y / v2.w;
+        const float mnx = fminf(nx0, fminf(nx1, nx2)), mxx = fmaxf(nx0, fmaxf(nx1, nx2));
+        const float mny = fminf(ny0, fminf(ny1, ny2)), mxy = fmaxf(ny0, fmaxf(ny1, ny2));
+        if (mxx < -1.f || mnx > 1.f || mxy < -1.f || mny > 1.f) return t;
+        // pixel i centre at ((i + 0.5) / W) * 2 - 1  =>  i = (ndc + 1) * W / 2 - 0.5
+        t.x0 = max(0, (int)floorf((mnx + 1.f) * 0.5f * W - 0.5f));
+        t.x1 = min(W, (int)ceilf((mxx + 1.f) * 0.5f * W - 0.5f) + 1);
+        t.y0 = max(0, (int)floorf((mny + 1.f) * 0.5f * H - 0.5f));
+        t.y1 = min(H, (int)ceilf((mxy + 1.f) * 0.5f * H - 0.5f) + 1);
+    } else if (v0.w <= 1e-6f && v1.w <= 1e-6f && v2.w <= 1e-6f) {
+        return t;  // entirely behind the eye
+    } else {
+        t.x0 = 0; t.y0 = 0; t.x1 = W; t.y1 = H;
+    }
+    t.ok = t.x1 > t.x0 && t.y1 > t.y0;
+    return t;
+}
+
+// Evaluate one pixel; returns true and (u, v, z/w) when the pixel centre is covered.
+__device__ __forceinline__ bool tri_sample(const TriSetup& t, int px, int py, int W, int H, float& u, float& v, float& zw)
+{
+    const float X = ((float)px + 0.5f) / (float)W * 2.f - 1.f;
+    const float Y = ((float)py + 0.5f) / (float)H * 2.f - 1.f;
+    const float e0 = t.a[0] * X + t.b[0] * Y + t.c[0];
+    const float e1 = t.a[1] * X + t.b[1] * Y + t.c[1];
+    const float e2 = t.a[2] * X + t.b[2] * Y + t.c[2];
+    if (e0 < 0.f || e1 < 0.f || e2 < 0.f) return false;
+    const float s = e0 + e1 + e2;          // = 1 / w at the pixel
+    if (!(s > 0.f)) return false;          // behind the eye or exactly degenerate
+    const float r = 1.f / s;
+    const float b0 = e0 * r, b1 = e1 * r, b2 = e2 * r;
+    const float zc = b0 * t.z[0] + b1 * t.z[1] + b2 * t.z[2];
+    const float wc = b0 * t.w[0] + b1 * t.w[1] + b2 * t.w[2];
+    zw = zc / wc;
+    if (!(zw >= -1.f && zw <= 1.f)) return false;
+    u = b0; v = b1;
+    return true;
+}
+
+__device__ __forceinline__ TriSetup load_tri(int f, const float4* __restrict__ pos, const int* __restrict__ tri, int V, int W, int H)
+{
+    const int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
+    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) {
+        TriSetup t; t.ok = false; return t;
+    }
+    return tri_setup(pos[i0], pos[i1], pos[i2], W, H);
+}
+
+__global__ void __launch_bounds__(256)
+mesh_clear_kernel(size_t n, unsigned long long* __restrict__ depth, uint32_t* __restrict__ big_count)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) depth[i] = ~0ull;
+    if (i == 0) *big_count = 0;
+}
+
+__global__ void __launch_bounds__(256)
+mesh_raster_small_kernel(int V, int F, const float4* __restrict__ pos, const int* __restrict__ tri, int W, int H,
+                         unsigned long long* __restrict__ depth, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const TriSetup t = load_tri(f, pos, tri, V, W, H);
+    if (!t.ok) return;
+    if ((long long)(t.x1 - t.x0) * (t.y1 - t.y0) > MESH_BIG_AREA) {
+        big_list[atomicAdd(big_count, 1u)] = (uint32_t)f;
+        return;
+    }
+    for (int py = t.y0; py < t.y1; py++)
+        for (int px = t.x0; px < t.x1; px++) {
+            float u, v, zw;
+            if (tri_sample(t, px, py, W, H, u, v, zw))
+                atomicMin(&depth[(size_t)py * W + px], ((unsigned long long)ordered_depth(zw) << 32) | (uint32_t)f);
+        }
+}
+
+__global__ void __launch_bounds__(256)
+mesh_raster_big_kernel(int V, const float4* __restrict__ pos, const int* __restrict__ tri, int W, int H,
+                       unsigned long long* __restrict__ depth, const uint32_t* __restrict__ big_list,
+                       const uint32_t* __restrict__ big_count)
+{
+    const uint32_t n = *big_count;
+    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+        const int f = (int)big_list[b];
+        const TriSetup t = load_tri(f, pos, tri, V, W, H);
+        if (!t.ok) continue;
+        const int bw = t.x1 - t.x0;
+        const long long area = (long long)bw * (t.y1 - t.y0);
+        for (long long p = threadIdx.x; p < area; p += 256) {
+            const int px = t.x0 + (int)(p % bw), py = t.y0 + (int)(p / bw);
+            float u, v, zw;
+            if (tri_sample(t, px, py, W, H, u, v, zw))
+                atomicMin(&depth[(size_t)py * W + px], ((unsigned long long)ordered_depth(zw) << 32) | (uint32_t)f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mesh_resolve_kernel(int V, const float4* __restrict__ pos, const int* __restrict__ tri, int W, int H,
+                    const unsigned long long* __restrict__ depth, float4* __restrict__ rast)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)W * H) return;
+    const unsigned long long key = depth[i];
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key != ~0ull) {
+        const int f = (int)(uint32_t)key;
+        const TriSetup t = load_tri(f, pos, tri, V, W, H);
+        float u = 0.f, v = 0.f, zw = 0.f;
+        tri_sample(t, (int)(i % W), (int)(i / W), W, H, u, v, zw);
+        out = make_float4(u, v, zw, (float)(f + 1));
+    }
+    rast[i] = out;
+}
+
+}  // namespace frg
+
+extern "C" {
+
+size_t frg_mesh_raster_workspace_bytes(int F, int width, int height)
+{
+    return frg::align_up((size_t)width * height * 8, 256) + frg::align_up((size_t)(F > 0 ? F : 1) * 4, 256) + 256;
+}
+
+int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width, int height, float* rast,
+                       char* workspace, size_t workspace_bytes, void* hip_stream)
+{
+    if (V < 0 || F < 0 || width <= 0 || height <= 0 || !rast) return FRG_EINVAL;
+    if (!workspace || workspace_bytes < frg_mesh_raster_workspace_bytes(F, width, height)) return FRG_EALLOC;
+    if (F > 0 && (!pos || !tri)) return FRG_EINVAL;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t N = (size_t)width * height;
+    unsigned long long* depth = reinterpret_cast<unsigned long long*>(workspace);
+    uint32_t* big_list = reinterpret_cast<uint32_t*>(workspace + frg::align_up(N * 8, 256));
+    uint32_t* big_count = reinterpret_cast<uint32_t*>(workspace + frg::align_up(N * 8, 256) + frg::align_up((size_t)(F > 0 ? F : 1) * 4, 256));
+    const float4* p4 = reinterpret_cast<const float4*>(pos);
+    hipLaunchKernelGGL(frg::mesh_clear_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, big_count);
+    if (F > 0) {
+        hipLaunchKernelGGL(frg::mesh_raster_small_kernel, dim3((F + 255) / 256), dim3(256), 0, s, V, F, p4, tri, width, height,
+                           depth, big_list, big_count);
+        hipLaunchKernelGGL(frg::mesh_raster_big_kernel, dim3(2048), dim3(256), 0, s, V, p4, tri, width, height, depth,
+                           big_list, big_count);
+    }
+    hipLaunchKernelGGL(frg::mesh_resolve_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, V, p4, tri, width, height,
+                       depth, reinterpret_cast<float4*>(rast));
+    return hipGetLastError() == hipSuccess ? FRG_OK : FRG_EHIP;
+}
+
+}  // extern "C"

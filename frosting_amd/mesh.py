@@ -1,0 +1,97 @@
+"""Triangle occlusion raster and the occlusion-culling mask.
+
+Replaces the nvdiffrast seam of the reference: ``frosting_utils/mesh_rasterization.py:6-16``
+imports ``nvdiffrast.torch as dr`` inside try/except and ``frosting_utils/nvdiffrast.py:53``
+calls ``dr.rasterize(glctx, pos=pos, tri=faces, resolution=[H, W])``.  This module offers
+the same two names (``RasterizeGLContext``, ``rasterize``) with the same return convention
+on top of the HIP kernel behind ``frg_mesh_rasterize``; ``install_as_nvdiffrast()`` registers
+it under ``sys.modules['nvdiffrast.torch']`` so the reference picks it up unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+import types
+
+import torch
+
+from . import _lib
+
+
+class RasterizeGLContext:
+    """Stand-in for nvdiffrast's OpenGL context object: holds the reusable workspace."""
+
+    def __init__(self, output_db: bool = False, mode: str = "automatic", device=None):
+        self.device = device
+        self._work = None
+
+    def workspace(self, nbytes, device):
+        if self._work is None or self._work.numel() < nbytes or self._work.device != device:
+            self._work = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._work
+
+
+RasterizeCudaContext = RasterizeGLContext
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """pos [1,V,4] float32 clip space, tri [F,3] int32, resolution [H,W] ->
+    (rast [1,H,W,4] = (u, v, z/w, triangle_id+1), None).  Not differentiable (the
+    reference only consumes it under no_grad / for indices)."""
+    if pos.dim() != 3 or pos.shape[0] != 1 or pos.shape[2] != 4:
+        raise ValueError("pos must be [1, V, 4] (instanced / range mode is not used by the reference)")
+    if not pos.is_cuda:
+        raise RuntimeError("frosting_amd.mesh.rasterize needs a ROCm device tensor (no CPU path)")
+    H, W = int(resolution[0]), int(resolution[1])
+    dev = pos.device
+    p = pos[0].detach().to(torch.float32).contiguous()
+    t = tri.detach().to(device=dev, dtype=torch.int32).contiguous()
+    V, F = p.shape[0], t.shape[0]
+    L = _lib.lib()
+    rast = torch.empty((1, H, W, 4), dtype=torch.float32, device=dev)
+    nbytes = int(L.frg_mesh_raster_workspace_bytes(F, W, H))
+    ctx = glctx if isinstance(glctx, RasterizeGLContext) else RasterizeGLContext()
+    work = ctx.workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        rc = L.frg_mesh_rasterize(V, F, C.c_void_p(p.data_ptr()) if V else None, C.c_void_p(t.data_ptr()) if F else None,
+                                  W, H, C.c_void_p(rast.data_ptr()), C.c_void_p(work.data_ptr()), work.numel(),
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(f"frg_mesh_rasterize failed ({rc}): {_lib.last_error()}")
+    return rast, None
+
+
+def install_as_nvdiffrast():
+    """Make ``import nvdiffrast.torch as dr`` resolve to this module."""
+    pkg = types.ModuleType("nvdiffrast")
+    mod = sys.modules[__name__]
+    pkg.torch = mod
+    sys.modules["nvdiffrast"] = pkg
+    sys.modules["nvdiffrast.torch"] = mod
+    return mod
+
+
+def clip_space_vertices(verts, full_proj_transform):
+    """[v,1] @ full_proj_transform, as frosting_utils/nvdiffrast.py:44-50 builds `pos`."""
+    ones = torch.ones(verts.shape[0], 1, dtype=verts.dtype, device=verts.device)
+    return (torch.cat([verts, ones], dim=1) @ full_proj_transform)[None]
+
+
+def visible_faces(verts, faces, full_proj_transform, height, width, glctx=None):
+    """Indices of the faces seen by at least one pixel (pix_to_face.unique() minus the
+    empty marker; frosting_model.py:1534-1539, refine.py:437-441)."""
+    rast, _ = rasterize(glctx, clip_space_vertices(verts, full_proj_transform), faces, [height, width])
+    ids = rast[..., 3].to(torch.int32).unique() - 1
+    return ids[ids >= 0].long()
+
+
+def occlusion_mask(point_cell_indices, face_idx_to_render, n_faces, n_background=0):
+    """Per-Gaussian keep mask of the Frosting occlusion culling (frosting_model.py:1564-1586):
+    a shell Gaussian survives iff the base face of its cell is visible; background Gaussians
+    are always kept."""
+    face_mask = torch.zeros(n_faces, dtype=torch.bool, device=point_cell_indices.device)
+    face_mask[face_idx_to_render] = True
+    keep = face_mask[point_cell_indices]
+    if n_background:
+        keep = torch.cat([keep, torch.ones(n_background, dtype=torch.bool, device=keep.device)])
+    return keep

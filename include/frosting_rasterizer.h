@@ -129,11 +129,16 @@ void frg_geometry_layout(int P, long long* out);
 void frg_image_layout(int width, int height, long long* out);
 void frg_binning_layout(int R, int max_tile_count, long long* out);
 
-/* ---- triangle occlusion raster (replaces nvdiffrast's dr.rasterize as used by
- * frosting_utils/nvdiffrast.py:53-54 / mesh_rasterization.py:146-156) ----------
- * pos: [V,4] clip-space vertices, tri: [F,3] int32, rast: [H,W,4] float32 =
- * (u, v, z/w, triangle_id+1), 0 where empty.  depth_scratch: H*W uint64. */
-size_t frg_mesh_raster_workspace_bytes(int width, int height);
+/* ---- triangle occlusion raster --------------------------------------------------
+ * Replaces nvdiffrast's dr.rasterize as the reference uses it
+ * (frosting_utils/nvdiffrast.py:53-54, frosting_utils/mesh_rasterization.py:146-156;
+ * nvdiffrast itself is third-party and not in the reference tree).
+ * pos: [V,4] clip-space vertices (= [v,1] @ full_proj_transform), tri: [F,3] int32,
+ * rast: [H,W,4] float32 = (u, v, z/w, triangle_id + 1), all zeros where empty; u, v are
+ * the perspective-correct barycentrics of vertices 0 and 1.  Pixel (col i, row j) is
+ * sampled at NDC ((i+.5)/W*2-1, (j+.5)/H*2-1); -1 <= z/w <= 1; nearest z/w wins, ties go
+ * to the smaller triangle id (deterministic). */
+size_t frg_mesh_raster_workspace_bytes(int F, int width, int height);
 int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width, int height,
                        float* rast, char* workspace, size_t workspace_bytes, void* hip_stream);
 

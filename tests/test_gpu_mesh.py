@@ -1,0 +1,103 @@
+"""GPU tests of the triangle occlusion raster against the CPU
+z-buffer restatement (oracle/mesh_oracle.py; parity for this third-party side op is
+unpinned -- see that file's header)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from frosting_amd import mesh as M
+from frosting_amd import scenes
+from oracle import mesh_oracle as MO
+
+pytestmark = pytest.mark.gpu
+
+
+def sphere_mesh(n_lat, n_lon, radius=1.0):
+    """Lat-long sphere (the C4 shell stand-in of SURVEY 8d)."""
+    th = torch.linspace(0, math.pi, n_lat + 1, dtype=torch.float64)
+    ph = torch.linspace(0, 2 * math.pi, n_lon + 1, dtype=torch.float64)[:-1]
+    T, Pp = torch.meshgrid(th, ph, indexing="ij")
+    v = torch.stack([torch.sin(T) * torch.cos(Pp), torch.cos(T), torch.sin(T) * torch.sin(Pp)], -1).reshape(-1, 3) * radius
+    faces = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+            c, d = (i + 1) * n_lon + j, (i + 1) * n_lon + (j + 1) % n_lon
+            faces += [[a, c, b], [b, c, d]]
+    return v.float(), torch.tensor(faces, dtype=torch.int32)
+
+
+def test_matches_cpu_zbuffer_small_mesh(gpu_device):
+    cam = scenes.ring_camera(1, 96, 64, 80.0, 80.0)
+    verts, faces = sphere_mesh(10, 16)
+    g = torch.Generator().manual_seed(3)
+    verts = verts + 0.01 * torch.randn(verts.shape, generator=g)
+    pos = M.clip_space_vertices(verts.to(gpu_device), cam.projmatrix.to(gpu_device))
+    rast, _ = M.rasterize(M.RasterizeGLContext(), pos, faces.to(gpu_device), [64, 96])
+    ref = MO.rasterize(pos[0].cpu().numpy(), faces.numpy(), 64, 96)
+    got = rast[0].cpu().numpy()
+    ids, rids = got[..., 3].astype(np.int64), ref[..., 3].astype(np.int64)
+    agree = ids == rids
+    assert agree.mean() > 0.995                      # edge pixels may flip between float32 and float64
+    assert set(np.unique(ids)) ^ set(np.unique(rids)) <= set(np.unique(ids[~agree])) | set(np.unique(rids[~agree]))
+    np.testing.assert_allclose(got[..., :3][agree], ref[..., :3][agree], atol=2e-4)
+    covered = ids > 0
+    assert covered.any() and (~covered).any()
+    assert not got[~covered].any()                    # empty pixels are all-zero
+    b = got[covered]
+    assert (b[:, 0] >= -1e-5).all() and (b[:, 1] >= -1e-5).all() and (b[:, 0] + b[:, 1] <= 1 + 1e-5).all()
+
+
+def test_depth_order_near_plane_and_big_triangles(gpu_device):
+    dev = gpu_device
+    # two screen-filling triangles at different depths plus one crossing w = 0
+    pos = torch.tensor([[-3.0, -3.0, 0.5, 1.0], [3.0, -3.0, 0.5, 1.0], [0.0, 3.0, 0.5, 1.0],      # far, covers all
+                        [-0.5, -0.5, 0.2, 1.0], [0.5, -0.5, 0.2, 1.0], [0.0, 0.5, 0.2, 1.0],      # near, small
+                        [-0.2, 0.0, 0.1, 0.5], [0.2, 0.0, 0.1, 0.5], [0.0, 0.3, -0.2, -0.4]],     # crosses the eye plane
+                       device=dev)
+    tri = torch.tensor([[0, 1, 2], [3, 4, 5], [6, 7, 8]], dtype=torch.int32, device=dev)
+    rast, _ = M.rasterize(None, pos[None], tri, [48, 64])
+    ref = MO.rasterize(pos.cpu().numpy(), tri.cpu().numpy(), 48, 64)
+    ids, rids = rast[0, ..., 3].cpu().numpy().astype(int), ref[..., 3].astype(int)
+    assert (ids == rids).mean() > 0.99
+    assert (ids > 0).all()                      # the far triangle covers the whole image
+    assert (ids == 2).sum() > 50                # the near one wins where it is
+    vis = M.visible_faces(pos[:, :3] * 0 + pos[:, :3], tri, torch.eye(4, device=dev), 48, 64)
+    assert set(vis.tolist()) <= {0, 1, 2}
+
+
+def test_occlusion_culling_mask_c4_shape(gpu_device):
+    """BASELINE config 4 plumbing at reduced size: shell Gaussians bound to the faces of a
+    sphere, culling = faces visible from the camera (about the front hemisphere)."""
+    cam = scenes.ring_camera(0, 400, 264, 333.5, 333.5)
+    verts, faces = sphere_mesh(60, 120)          # 14400 triangles
+    dev = gpu_device
+    vis = M.visible_faces(verts.to(dev), faces.to(dev), cam.projmatrix.to(dev), cam.image_height, cam.image_width)
+    F = faces.shape[0]
+    frac = vis.numel() / F
+    assert 0.25 < frac < 0.55                    # ~37 % of the sphere area is visible from distance 4
+    # every visible face must face the camera
+    v = verts[faces.long()]
+    n = torch.linalg.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    centre = v.mean(1)
+    facing = ((cam.campos[None] - centre) * centre).sum(1) > -1e-3   # outward = centre direction on a sphere
+    assert facing[vis.cpu()].float().mean() > 0.99
+    P = 20000
+    g = torch.Generator().manual_seed(0)
+    cell = torch.randint(0, F, (P,), generator=g).to(dev)
+    keep = M.occlusion_mask(cell, vis, F, n_background=100)
+    assert keep.shape[0] == P + 100 and keep[-100:].all()
+    assert abs(keep[:P].float().mean().item() - frac) < 0.02
+
+
+def test_nvdiffrast_module_shim(gpu_device):
+    M.install_as_nvdiffrast()
+    import nvdiffrast.torch as dr
+    ctx = dr.RasterizeGLContext()
+    pos = torch.tensor([[[-1.0, -1.0, 0.0, 1.0], [1.0, -1.0, 0.0, 1.0], [0.0, 1.0, 0.0, 1.0]]], device=gpu_device)
+    rast_out, _ = dr.rasterize(ctx, pos=pos, tri=torch.tensor([[0, 1, 2]], dtype=torch.int32, device=gpu_device),
+                               resolution=[32, 32])
+    bary_coords, zbuf, pix_to_face = rast_out[..., :2], rast_out[..., 2], rast_out[..., 3].int()   # nvdiffrast.py:54
+    assert rast_out.shape == (1, 32, 32, 4) and (pix_to_face.unique() - 1).tolist() == [-1, 0]
