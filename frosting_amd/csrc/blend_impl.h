@@ -40,6 +40,7 @@ struct BlendMath<true> {
     }
     static __device__ __forceinline__ float expo(float p) { return expf(p); }
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
+    static __device__ __forceinline__ float recip(float x) { return 1.0f / x; }
 };
 
 template <>
@@ -51,6 +52,7 @@ struct BlendMath<false> {
     }
     static __device__ __forceinline__ float expo(float p) { return __expf(p); }
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
+    static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
 };
 
 // lane -> pixel of quadrant q inside the tile
@@ -197,7 +199,8 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_step(float v)
 {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    // old = 0 with bound_ctrl: lets the compiler fold the DPP move into v_add_f32_dpp
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
     return v + __int_as_float(t);
 }
 
@@ -334,14 +337,14 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             for (int q = 0; q < 4; q++) {
                 if (__ballot((ok >> q) & 1u) == 0ull) continue;   // wave-uniform
                 if (!((ok >> q) & 1u)) continue;
-                const float one_m = 1.f - alpha[q];
-                Tr[q] = Tr[q] / one_m;                       // transmittance in front of this Gaussian
+                const float rinv = M::recip(1.f - alpha[q]);  // 1 - alpha >= 0.01
+                Tr[q] = Tr[q] * rinv;                        // transmittance in front of this Gaussian
                 const float w = alpha[q] * Tr[q];            // dC/dcolour
                 const float cdot = gc.x * dLp[q][0] + gc.y * dLp[q][1] + gc.z * dLp[q][2];
                 part[0] += w * dLp[q][0];
                 part[1] += w * dLp[q][1];
                 part[2] += w * dLp[q][2];
-                const float dL_dalpha = Tr[q] * cdot - S[q] / one_m;
+                const float dL_dalpha = Tr[q] * cdot - S[q] * rinv;
                 S[q] += w * cdot;
                 const float dL_dG = cco.w * dL_dalpha;
                 const float gdx = G[q] * dxs[q], gdy = G[q] * dys[q];
