@@ -63,32 +63,49 @@ __device__ __forceinline__ void lane_pixel(int lane, int q, int tx, int ty, int&
 }
 
 // Bit q set <=> some pixel of quadrant q of tile (tx,ty) may reach alpha >= 1/255.
-// alpha = min(0.99, o * exp(power)) with power = -1/2 d^T C d <= -1/2 lambda_min |d|^2,
-// so alpha < 1/255 whenever 1/2 lambda_min dist^2 > ln(255 o), dist = distance from
-// the centre to the quadrant's pixel rectangle.  Margins (0.1 % relative, 0.02
-// absolute on a threshold <= 5.6) dominate the rounding of the per-pixel evaluation
-// (|error| <= ~1e-6 * lambda_max * d^2, lambda_max <= 1/0.3 by the low-pass, d^2 <= 512),
-// so the cull never removes a pixel the reference would have blended.
+// alpha = min(0.99, o * exp(power)), power = -1/2 Q(d), Q(d) = a dx^2 + 2 b dx dy + c dy^2, so
+// alpha < 1/255 on the whole quadrant whenever 1/2 min_rect Q > ln(255 o), where the minimum
+// is taken over the continuous rectangle spanned by the quadrant's pixel centres (a superset
+// of the pixels, hence conservative).  Q is convex: if the centre lies inside the rectangle
+// the minimum is 0, otherwise it sits on one of the four edges, where Q restricted to the
+// edge is a 1-D parabola whose clamped vertex gives the edge minimum in closed form.
+// Margins (0.1 % relative, 0.02 absolute on a threshold <= 5.6) dominate the rounding of the
+// per-pixel evaluation (|error| <= ~1e-6 * lambda_max * d^2, lambda_max <= 1/0.3 by the
+// low-pass, d^2 <= 512), so the cull never removes a pixel the reference would have blended.
+__device__ __forceinline__ float rect_min_quadform(float a, float b, float c, float xlo, float xhi, float ylo, float yhi)
+{
+    // offsets are relative to the Gaussian centre: the rectangle is [xlo,xhi] x [ylo,yhi]
+    if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
+    const float ia = 1.0f / a, ic = 1.0f / c;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const float ex = e ? xhi : xlo;                           // vertical edge dx = ex
+        const float dy = fminf(fmaxf(-b * ex * ic, ylo), yhi);
+        best = fminf(best, a * ex * ex + 2.f * b * ex * dy + c * dy * dy);
+        const float ey = e ? yhi : ylo;                           // horizontal edge dy = ey
+        const float dx = fminf(fmaxf(-b * ey * ia, xlo), xhi);
+        best = fminf(best, a * dx * dx + 2.f * b * dx * ey + c * ey * ey);
+    }
+    return best;
+}
+
 __device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float4 co, int tx, int ty)
 {
     const float o = co.w;
     if (!(o >= 1.0f / 255.0f)) return (o != o) ? 0xFu : 0u;  // exp(power) <= 1 => alpha <= o < 1/255 everywhere
     const float a = co.x, b = co.y, c = co.z;
-    const float mid = 0.5f * (a + c), det = a * c - b * b;
-    const float lam_max = mid + sqrtf(fmaxf(mid * mid - det, 0.0f));
-    float lam_min = (det > 0.0f && lam_max > 0.0f) ? det / lam_max : 0.0f;
-    if (!(lam_min == lam_min)) lam_min = 0.0f;
+    // not a proper positive-definite conic (or not finite): no bound, keep everything
+    if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f) || !(a < 3.0e38f) || !(c < 3.0e38f)) return 0xFu;
     const float thr = __logf(255.0f * o) + 0.02f;
-    const float k = 0.5f * lam_min * 0.999f;
-    const float X0 = (float)(tx * FRG_TILE), Y0 = (float)(ty * FRG_TILE);
-    // distances to the two column bands [X0,X0+7], [X0+8,X0+15] and two row bands
-    const float dxl = fmaxf(fmaxf(X0 - x, x - (X0 + 7.0f)), 0.0f), dxr = fmaxf(fmaxf(X0 + 8.0f - x, x - (X0 + 15.0f)), 0.0f);
-    const float dyt = fmaxf(fmaxf(Y0 - y, y - (Y0 + 7.0f)), 0.0f), dyb = fmaxf(fmaxf(Y0 + 8.0f - y, y - (Y0 + 15.0f)), 0.0f);
+    const float X0 = (float)(tx * FRG_TILE) - x, Y0 = (float)(ty * FRG_TILE) - y;  // tile origin relative to the centre
     uint32_t m = 0;
-    if (!(k * (dxl * dxl + dyt * dyt) > thr)) m |= 1u;
-    if (!(k * (dxr * dxr + dyt * dyt) > thr)) m |= 2u;
-    if (!(k * (dxl * dxl + dyb * dyb) > thr)) m |= 4u;
-    if (!(k * (dxr * dxr + dyb * dyb) > thr)) m |= 8u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float xlo = X0 + (float)((q & 1) * 8), ylo = Y0 + (float)((q >> 1) * 8);
+        const float qmin = rect_min_quadform(a, b, c, xlo, xlo + 7.0f, ylo, ylo + 7.0f);
+        if (!(0.5f * 0.999f * qmin > thr)) m |= 1u << q;
+    }
     return m;
 }
 
@@ -152,8 +169,36 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             s_rgb[d] = col;
         }
         __syncthreads();
-        // (A branch-free evaluation of all four quadrants was measured slower here: it needs
-        // 77 VGPRs, dropping from 8 to 6 waves per SIMD, and this loop is latency-bound.)
+#ifdef FRG_FWD_BRANCHFREE
+        for (int j = 0; live != 0 && j < nkeep; j++) {
+            const float4 ca = s_a[j], cco = s_co[j];
+            const uint32_t qm = __float_as_uint(ca.z);
+            const uint32_t contributor = __float_as_uint(ca.w);
+            float alpha[4];
+            uint32_t ok = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float dx, dy;
+                const float power = M::power(ca.x, ca.y, cco, pxf[q], pyf[q], dx, dy);
+                alpha[q] = fminf(0.99f, cco.w * M::expo(power));
+                if (!(power > 0.0f) && !(alpha[q] < 1.0f / 255.0f)) ok |= 1u << q;
+            }
+            ok &= qm & live;
+            if (__ballot(ok != 0) == 0ull) continue;
+            const float4 gc = s_rgb[j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!(ok & (1u << q))) continue;
+                const float test_T = Tr[q] * (1 - alpha[q]);
+                if (test_T < 0.0001f) { live &= ~(1u << q); continue; }
+                C[q][0] += M::mul3(gc.x, alpha[q], Tr[q]);
+                C[q][1] += M::mul3(gc.y, alpha[q], Tr[q]);
+                C[q][2] += M::mul3(gc.z, alpha[q], Tr[q]);
+                Tr[q] = test_T;
+                last[q] = contributor;
+            }
+        }
+#else
         for (int j = 0; live != 0 && j < nkeep; j++) {
             const float4 ga = s_a[j];
             const float4 gco = s_co[j];
@@ -178,6 +223,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                 last[q] = contributor;
             }
         }
+#endif
     }
 
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];

@@ -237,27 +237,65 @@ static hipError_t launch_lds_class(int T, int lo, const uint2* ranges, const uin
     return hipGetLastError();
 }
 
+// The size classes touch disjoint tiles, so they run concurrently: the large-tile
+// classes are forked onto two internal side streams (event fork / join around the
+// caller's stream) instead of queueing behind the small-tile pass.
+struct SortStreams {
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    bool ok = false;
+    bool ensure()
+    {
+        if (ok) return true;
+        for (int i = 0; i < 2; i++) {
+            if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+};
+
 hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
                             uint32_t* point_list, hipStream_t stream)
 {
     if (T <= 0 || max_tile_count <= 0) return hipSuccess;
+    thread_local SortStreams ss;
+    const bool forked = max_tile_count > 2048 && ss.ensure();
+    hipStream_t s1 = stream, s2 = stream;
+    hipError_t e;
+    if (forked) {
+        if ((e = hipEventRecord(ss.fork, stream)) != hipSuccess) return e;
+        s1 = ss.side[0]; s2 = ss.side[1];
+        if ((e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
+        if (max_tile_count > 4096 && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
+    }
     // size classes: (0,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 16 waves, >8192 global ping-pong
-    hipError_t e = launch_lds_class<4, 2048>(T, 0, ranges, pairs, point_list, stream);
-    if (e != hipSuccess) return e;
+    if (max_tile_count > 4096) {  // longest-running class first
+        e = launch_lds_class<16, FRG_SORT_LDS_CAP>(T, 4096, ranges, pairs, point_list, s2);
+        if (e != hipSuccess) return e;
+        if (max_tile_count > FRG_SORT_LDS_CAP) {
+            if (!pairs_tmp) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(T), dim3(1024), 0, s2, T, FRG_SORT_LDS_CAP, ranges, pairs, pairs_tmp, point_list);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    }
     if (max_tile_count > 2048) {
-        e = launch_lds_class<8, 4096>(T, 2048, ranges, pairs, point_list, stream);
+        e = launch_lds_class<8, 4096>(T, 2048, ranges, pairs, point_list, s1);
         if (e != hipSuccess) return e;
     }
-    if (max_tile_count > 4096) {
-        e = launch_lds_class<16, FRG_SORT_LDS_CAP>(T, 4096, ranges, pairs, point_list, stream);
-        if (e != hipSuccess) return e;
+    e = launch_lds_class<4, 2048>(T, 0, ranges, pairs, point_list, stream);
+    if (e != hipSuccess) return e;
+    if (forked) {
+        if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ss.join[0], 0)) != hipSuccess) return e;
+        if (max_tile_count > 4096) {
+            if ((e = hipEventRecord(ss.join[1], s2)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(stream, ss.join[1], 0)) != hipSuccess) return e;
+        }
     }
-    if (max_tile_count > FRG_SORT_LDS_CAP) {
-        if (!pairs_tmp) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(T), dim3(1024), 0, stream, T, FRG_SORT_LDS_CAP, ranges, pairs, pairs_tmp, point_list);
-        e = hipGetLastError();
-    }
-    return e;
+    return hipSuccess;
 }
 
 }  // namespace frg
