@@ -171,18 +171,105 @@ __device__ __forceinline__ PtrT sort_segment(PtrT src, PtrT dst, int n, uint32_t
     return src;
 }
 
-// CAP = LDS capacity in elements; tiles with lo < n <= CAP are handled by this
-// instantiation (the host launches one instantiation per size class; blocks whose
-// tile is outside the class exit immediately).
+// ---- LDS classes: register-staged, in-place passes --------------------------------
+// Each thread owns at most 8 elements of its wave's contiguous strip (CAP = 8 * threads).
+// A pass ranks them from REGISTERS (no LDS reads of the data), scatters them into the
+// single LDS buffer and reloads its strip: one 8-byte buffer instead of a ping-pong pair,
+// so twice the workgroups fit per CU and different size classes can share a CU.
+#define SORT_ITEMS 8
+
+template <int NWAVES, bool BY_INDEX>
+__device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, int begin, int end, int shift,
+                                                uint2* buf, uint32_t* whist, uint32_t* scratch)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* myhist = whist + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; i++) myhist[lane * 4 + i] = 0;   // wave-private: no workgroup barrier needed
+    uint32_t meta[SORT_ITEMS];  // rank within the 64-element step | group size << 8 | digit << 16
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; it++) {
+        meta[it] = 0;
+        if (begin + it * 64 >= end) continue;     // wave-uniform: nothing of the strip in this step
+        const bool valid = begin + it * 64 + lane < end;
+        const uint32_t d = ((BY_INDEX ? e[it].y : e[it].x) >> shift) & 255u;
+        const uint64_t peers = match_digit(d, valid);
+        const uint32_t rank = lanes_below(peers, lane), cnt = (uint32_t)__popcll(peers);
+        meta[it] = rank | (cnt << 8) | (d << 16);
+        if (valid && rank == 0) myhist[d] += cnt;
+    }
+    __syncthreads();
+    // digit totals, exclusive over waves then over digits
+    constexpr int NT = NWAVES * 64;
+    for (int dg = tid; dg < 256; dg += NT) {      // (a 64-thread workgroup covers the 256 digits in 4 steps)
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) {
+            const uint32_t c = whist[w * 256 + dg];
+            whist[w * 256 + dg] = run;
+            run += c;
+        }
+        scratch[dg] = run;
+        if (run == (uint32_t)n) scratch[256] = 1;   // one digit holds everything: nothing to move
+    }
+    __syncthreads();
+    const bool uniform = scratch[256] != 0;
+    __syncthreads();
+    if (uniform) {
+        if (tid == 0) scratch[256] = 0;
+        __syncthreads();
+        return false;
+    }
+    if (tid < 64) {  // exclusive scan of the 256 totals by one wave, 4 per lane
+        uint32_t v0 = scratch[4 * lane], v1 = scratch[4 * lane + 1], v2 = scratch[4 * lane + 2], v3 = scratch[4 * lane + 3];
+        uint32_t s = v0 + v1 + v2 + v3, inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        uint32_t ex = inc - s;
+        scratch[4 * lane] = ex; scratch[4 * lane + 1] = ex + v0;
+        scratch[4 * lane + 2] = ex + v0 + v1; scratch[4 * lane + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    for (int dg = tid; dg < 256; dg += NT) {
+        const uint32_t base = scratch[dg];
+#pragma unroll
+        for (int w = 0; w < NWAVES; w++) whist[w * 256 + dg] += base;
+    }
+    __syncthreads();   // every thread holds its elements in registers: the buffer may be overwritten
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; it++) {
+        if (begin + it * 64 >= end) break;        // wave-uniform
+        const bool valid = begin + it * 64 + lane < end;
+        const uint32_t rank = meta[it] & 255u, cnt = (meta[it] >> 8) & 255u, d = meta[it] >> 16;
+        uint32_t pos = 0;
+        if (valid) pos = myhist[d] + rank;
+        __builtin_amdgcn_wave_barrier();          // all lanes read the cursor before a leader bumps it
+        if (valid && rank == 0) myhist[d] += cnt;
+        if (valid) buf[pos] = e[it];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; it++) {
+        const int i = begin + it * 64 + lane;
+        if (i < end) e[it] = buf[i];
+    }
+    return true;
+}
+
+// CAP = 8 * threads; tiles with lo < n <= CAP are handled by this instantiation (the host
+// launches one instantiation per size class; workgroups whose tile is outside exit at once).
 template <int NWAVES, int CAP>
 __global__ void __launch_bounds__(NWAVES * 64)
 sort_tiles_lds_kernel(int T, int lo, const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
                       uint32_t* __restrict__ point_list)
 {
+    static_assert(CAP == NWAVES * 64 * SORT_ITEMS, "each thread stages SORT_ITEMS elements");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint2* bufA = reinterpret_cast<uint2*>(smem);
-    uint2* bufB = bufA + CAP;
-    uint32_t* whist = reinterpret_cast<uint32_t*>(bufB + CAP);
+    uint2* buf = reinterpret_cast<uint2*>(smem);
+    uint32_t* whist = reinterpret_cast<uint32_t*>(buf + CAP);
     uint32_t* scratch = whist + NWAVES * 256;  // 260 words
     const int tile = blockIdx.x;
     if (tile >= T) return;
@@ -190,13 +277,46 @@ sort_tiles_lds_kernel(int T, int lo, const uint2* __restrict__ ranges, const uin
     const int n = (int)(rg.y - rg.x);
     if (n <= lo || n > CAP) return;
     constexpr int NT = NWAVES * 64;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += NT) bufA[i] = pairs[rg.x + i];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 512
+    const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
+    const int begin = wave * strip, end = min(n, begin + strip);
+    uint2 e[SORT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; it++) {
+        const int i = begin + it * 64 + lane;
+        e[it] = i < end ? pairs[rg.x + i] : make_uint2(0u, 0u);
+    }
     if (tid == 0) scratch[256] = 0;
     __syncthreads();
-    uint2* src = bufA;
-    if (n > 1) src = sort_segment<NWAVES, uint2*>(bufA, bufB, n, whist, scratch);
-    for (int i = tid; i < n; i += NT) point_list[rg.x + i] = src[i].y;
+    bool in_lds = false;
+    if (n > 1) {
+#pragma unroll 1
+        for (int pass = 0; pass < 4; pass++)
+            in_lds |= radix_pass_regs<NWAVES, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+    }
+    if (!in_lds) {   // nothing moved (n == 1 or all keys equal): materialise the strip for the steps below
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; it++) {
+            const int i = begin + it * 64 + lane;
+            if (i < end) buf[i] = e[it];
+        }
+        __syncthreads();
+    }
+    if (n > 1) {
+        const int ties = count_ties<uint2*>(buf, n, NT, scratch);
+        if (ties > 32) {
+            // many equal depths (coplanar scenes): order by index, then by depth again -- LSD
+            // stability turns that into (depth, index)
+#pragma unroll 1
+            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+#pragma unroll 1
+            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+        } else if (ties > 0) {
+            fix_ties<uint2*>(buf, n, NT);
+        }
+    }
+    for (int i = tid; i < n; i += NT) point_list[rg.x + i] = buf[i].y;
 }
 
 // Fallback for tile lists longer than the LDS capacity: same passes, ping-pong
@@ -225,7 +345,7 @@ sort_tiles_global_kernel(int T, int lo, const uint2* __restrict__ ranges, uint2*
 template <int NW, int CAP>
 static hipError_t launch_lds_class(int T, int lo, const uint2* ranges, const uint2* pairs, uint32_t* point_list, hipStream_t stream)
 {
-    const size_t lds = (size_t)CAP * 16 + NW * 1024 + 260 * 4;
+    const size_t lds = (size_t)CAP * 8 + NW * 1024 + 260 * 4;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_tiles_lds_kernel<NW, CAP>),
@@ -271,7 +391,8 @@ hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint
         if ((e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
         if (max_tile_count > 4096 && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
     }
-    // size classes: (0,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 16 waves, >8192 global ping-pong
+    // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 16 waves,
+    // >8192 global ping-pong
     if (max_tile_count > 4096) {  // longest-running class first
         e = launch_lds_class<16, FRG_SORT_LDS_CAP>(T, 4096, ranges, pairs, point_list, s2);
         if (e != hipSuccess) return e;
@@ -285,7 +406,11 @@ hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint
         e = launch_lds_class<8, 4096>(T, 2048, ranges, pairs, point_list, s1);
         if (e != hipSuccess) return e;
     }
-    e = launch_lds_class<4, 2048>(T, 0, ranges, pairs, point_list, stream);
+    if (max_tile_count > 512) {
+        e = launch_lds_class<4, 2048>(T, 512, ranges, pairs, point_list, stream);
+        if (e != hipSuccess) return e;
+    }
+    e = launch_lds_class<1, 512>(T, 0, ranges, pairs, point_list, stream);   // one wave per small tile: no real barriers
     if (e != hipSuccess) return e;
     if (forked) {
         if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;

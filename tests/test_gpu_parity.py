@@ -336,3 +336,26 @@ def test_large_image_binning_path(gpu_device):
         assert torch.equal(img_a, out_b[1])
     finally:
         _lib.set_option("global_bins", 0)
+
+
+@pytest.mark.parametrize("P,spread,planes", [(500, 0.5, 0), (3000, 0.3, 0), (9000, 0.15, 0), (30000, 0.08, 0),
+                                             (40000, 0.05, 3)])
+def test_tile_sort_every_size_class(gpu_device, P, spread, planes):
+    """Tile lists around every LDS size class of the sort (1/4/8/16 waves, global ping-pong),
+    with and without massive depth ties: the output must be ordered by (tile, depth bits, index)."""
+    g = torch.Generator().manual_seed(P)
+    cam = scenes.ring_camera(0, 128, 96, 100.0, 100.0)
+    means = torch.zeros(P, 3)
+    means[:, :2] = spread * torch.randn(P, 2, generator=g)
+    means[:, 2] = 0.5 * torch.rand(P, generator=g)
+    if planes:
+        means[:, 2] = torch.randint(0, planes, (P,), generator=g).float() * 0.1
+    scene = scenes.Scene(means, torch.full((P, 3), 0.01), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                         torch.full((P, 1), 0.02), 0.1 * torch.randn(P, 16, 3, generator=g), 3)
+    out, _ = Hh.run_ours_native(scene, cam, torch.zeros(3), gpu_device)
+    R, color, radii, geom, binning, img = out
+    st = State(P, 128, 96, R, geom, binning, img)
+    keys = st.sort_keys().cpu().numpy()
+    pl = st.point_list.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.lexsort((pl, keys)), np.arange(R))
+    assert np.array_equal(np.bincount(pl, minlength=P), st.tiles_touched.cpu().numpy())
