@@ -35,7 +35,8 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
                const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                const float* __restrict__ colors_precomp,
                float4* __restrict__ xydr, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_clamped,
-               Counters* __restrict__ counters, int prefiltered, int& radius_i, int& x0, int& y0, int& x1, int& y1)
+               Counters* __restrict__ counters, int prefiltered, int& radius_i, int& x0, int& y0, int& x1, int& y1,
+               float3& dir)
 {
     radius_i = 0;
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -72,51 +73,38 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
     const uint32_t touched = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
     if (touched == 0) return 0u;
     radius_i = f2i(my_radius);
-    float r = 0, g = 0, b = 0;
-    uint32_t clamp_bits = 0;
-    if (colors_precomp) {
-        r = colors_precomp[3 * idx]; g = colors_precomp[3 * idx + 1]; b = colors_precomp[3 * idx + 2];
-    } else {
-        // forward.cu:20-71
+    xydr[idx] = make_float4(px, py, p_view.z, my_radius);
+    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+    if (!colors_precomp) {  // unit view direction for the SH colour (forward.cu:25-27)
         float dx = p.x - vmx.campos[0], dy = p.y - vmx.campos[1], dz = p.z - vmx.campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        dx = dx / len; dy = dy / len; dz = dz / len;
-        float w[16];
-        const int n = sh_weights(vp.D, dx, dy, dz, w);
-        const float* sh = shs + (size_t)idx * vp.M * 3;
-        float acc[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) acc[ch] = w[0] * sh[ch];
-        if (n > 1) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-                acc[ch] = acc[ch] - w[1] * sh[3 + ch] + w[2] * sh[6 + ch] - w[3] * sh[9 + ch];
-            if (n > 4) {
-#pragma unroll
-                for (int i = 4; i < 9; i++)
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
-                if (n > 9) {
-#pragma unroll
-                    for (int i = 9; i < 16; i++)
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) acc[ch] = acc[ch] + w[i] * sh[3 * i + ch];
-                }
-            }
-        }
+        dir = make_float3(dx / len, dy / len, dz / len);
+    }
+    return touched;
+}
+
+// SH -> RGB in the reference's left-to-right order (forward.cu:28-70), fed one coefficient at a
+// time (e = 3 * i + ch) so that the coefficients can arrive in storage order.
+struct ShAccum {
+    float acc[3];
+    __device__ __forceinline__ void add(int i, int ch, float w, float s)
+    {
+        if (i == 0) acc[ch] = w * s;
+        else if (i == 1 || i == 3) acc[ch] = acc[ch] - w * s;
+        else acc[ch] = acc[ch] + w * s;
+    }
+    __device__ __forceinline__ float4 finish()
+    {
+        uint32_t clamp_bits = 0;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             acc[ch] += 0.5f;
             if (acc[ch] < 0) clamp_bits |= (1u << ch);
             acc[ch] = fmaxf(acc[ch], 0.0f);
         }
-        r = acc[0]; g = acc[1]; b = acc[2];
+        return make_float4(acc[0], acc[1], acc[2], __uint_as_float(clamp_bits));
     }
-    xydr[idx] = make_float4(px, py, p_view.z, my_radius);
-    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
-    rgb_clamped[idx] = make_float4(r, g, b, __uint_as_float(clamp_bits));
-    return touched;
-}
+};
 
 // block-wide inclusive scan of one uint per thread (NW waves); returns the inclusive
 // value, *total receives the block sum.  wsum: NW words of LDS.
@@ -145,7 +133,17 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* wsum, 
 // workgroup and flushed ONCE, as a row of the (workgroup x tile) count matrix: no
 // global atomics (the first version issued R = 16.4 M of them at C3 and ran 8x over
 // its bandwidth bound).  LDS_BINS=false: T too large for LDS -> global atomics.
-template <bool LDS_BINS>
+#define PRE_SUB 16        // Gaussians per SH transpose step
+#define PRE_ROW_F4 13     // 12 float4 + 1 pad: odd stride, conflict-free ds_read_b128
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool LDS_BINS, bool SH16>
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
 preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
@@ -160,6 +158,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
+    __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
@@ -171,11 +170,12 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int idx = c * FRG_BIN_THREADS + threadIdx.x;
         uint32_t touched = 0;
+        float3 dir = make_float3(0.f, 0.f, 1.f);
         if (idx < P) {
             int radius_i, x0, y0, x1, y1;
             touched = preprocess_one(idx, vp, vmx, means3D, scales, rotations, opacities, shs, cov3D_precomp,
                                      colors_precomp, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
-                                     radius_i, x0, y0, x1, y1);
+                                     radius_i, x0, y0, x1, y1, dir);
             radii[idx] = radius_i;
             tiles_touched[idx] = touched;
             if (touched) {
@@ -185,6 +185,60 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                         else atomicAdd(&tile_count[y * vp.gx + x], 1u);
                     }
             }
+        }
+        // ---- colour ----
+        if (colors_precomp) {
+            if (touched)
+                rgb_clamped[idx] = make_float4(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2],
+                                               __uint_as_float(0u));
+        } else {
+            float w[16];
+            const int ncoef = sh_weights(vp.D, dir.x, dir.y, dir.z, w);
+            ShAccum sa;
+            sa.acc[0] = sa.acc[1] = sa.acc[2] = 0.f;
+            if (SH16) {
+                // the wave's 64 x 48 coefficients are one contiguous stream of 768 float4: read it
+                // coalesced and transpose through LDS, 16 Gaussians at a time
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                float4* shbuf = sh_lds + wave * (PRE_SUB * PRE_ROW_F4);
+                const int idx0 = c * FRG_BIN_THREADS + wave * 64;
+                const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
+                const int nvalid = min(64, P - idx0);
+                const bool wave_needs = __ballot(touched != 0) != 0ull;
+                if (wave_needs) {
+#pragma unroll 1
+                    for (int h = 0; h < 64 / PRE_SUB; h++) {
+                        if ((__ballot(touched != 0) & (0xFFFFull << (h * PRE_SUB))) == 0ull) continue;  // none visible
+#pragma unroll
+                        for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
+                            const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
+                            if (h * PRE_SUB + gl < nvalid) shbuf[gl * PRE_ROW_F4 + j] = src[(size_t)h * PRE_SUB * 12 + f];
+                        }
+                        wave_sync_lds();
+                        if ((lane / PRE_SUB) == h && touched) {
+#pragma unroll
+                            for (int j = 0; j < 12; j++) {
+                                const float4 v = shbuf[(lane % PRE_SUB) * PRE_ROW_F4 + j];
+                                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    const int e = 4 * j + t, i = e / 3, ch = e % 3;
+                                    if (i < ncoef) sa.add(i, ch, w[i], vv[t]);
+                                }
+                            }
+                        }
+                        wave_sync_lds();
+                    }
+                }
+            } else if (touched) {
+                const float* sh = shs + (size_t)idx * vp.M * 3;
+#pragma unroll
+                for (int e = 0; e < 48; e++) {
+                    const int i = e / 3, ch = e % 3;
+                    if (i < ncoef) sa.add(i, ch, w[i], sh[e]);
+                }
+            }
+            if (touched) rgb_clamped[idx] = sa.finish();
         }
         uint32_t total;
         block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
@@ -369,26 +423,31 @@ static hipError_t allow_big_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
-                                 const ImageState& img, int prefiltered, hipStream_t s)
+template <bool LDS_BINS, bool SH16>
+static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
+                                     const ImageState& img, int prefiltered, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
-    if (img.lds_bins) {
-        const size_t lds = (size_t)T * 4;
-        hipError_t e = allow_big_lds(preprocess_fwd_kernel<true>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
-                           in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
-                           in.cov3D_precomp, in.colors_precomp, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
-                           g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
-    } else {
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nb), dim3(FRG_BIN_THREADS), 0, s, P, vp, in.viewmatrix,
-                           in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
-                           in.cov3D_precomp, in.colors_precomp, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
-                           g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
-    }
+    const size_t lds = LDS_BINS ? (size_t)T * 4 : 0;
+    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SH16>, lds + 64 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SH16>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
+                       in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
+                       in.cov3D_precomp, in.colors_precomp, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
+                       g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
     return hipGetLastError();
+}
+
+hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
+                                 const ImageState& img, int prefiltered, hipStream_t s)
+{
+    // float4-streamed SH needs the reference's usual layout: 16 coefficients per channel, 16-byte aligned
+    const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0);
+    if (img.lds_bins) return sh16 ? launch_pre_variant<true, true>(P, vp, in, radii, g, img, prefiltered, s)
+                                  : launch_pre_variant<true, false>(P, vp, in, radii, g, img, prefiltered, s);
+    return sh16 ? launch_pre_variant<false, true>(P, vp, in, radii, g, img, prefiltered, s)
+                : launch_pre_variant<false, false>(P, vp, in, radii, g, img, prefiltered, s);
 }
 
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, hipStream_t s)
