@@ -148,7 +148,10 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     }
 
     for (int base = 0; base < n; base += 64) {
-        if (__ballot(live != 0) == 0ull) break;  // whole tile saturated
+        // quadrants whose 64 pixels have all saturated take no further part
+        const uint32_t alive = (__ballot(live & 1u) ? 1u : 0u) | (__ballot(live & 2u) ? 2u : 0u) |
+                               (__ballot(live & 4u) ? 4u : 0u) | (__ballot(live & 8u) ? 8u : 0u);
+        if (alive == 0) break;                   // whole tile saturated
         const int cnt = min(64, n - base);
         uint32_t m = 0;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
@@ -157,7 +160,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             a = xydr[id];
             co = conic_opacity[id];
             col = rgb_clamped[id];
-            m = quadrant_mask(a.x, a.y, co, tx, ty);
+            m = quadrant_mask(a.x, a.y, co, tx, ty) & alive;
         }
         const uint64_t keep = __ballot(m != 0);
         const int nkeep = __popcll(keep);
@@ -316,9 +319,15 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         for (int ch = 0; ch < 3; ch++) dLp[q][ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
         S[q] = Tr[q] * (bg0 * dLp[q][0] + bg1 * dLp[q][1] + bg2 * dLp[q][2]);
     }
-    // tile-wide number of list entries that can still receive gradient
+    // per-quadrant and tile-wide number of list entries that can still receive gradient
+    uint32_t qmax[4];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, d, 64));
+    for (int q = 0; q < 4; q++) {
+        qmax[q] = lastcon[q];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) qmax[q] = max(qmax[q], (uint32_t)__shfl_xor((int)qmax[q], d, 64));
+    }
+    maxc = max(max(qmax[0], qmax[1]), max(qmax[2], qmax[3]));
     if (maxc == 0) {
         if (lane == 0) cutoff[tile] = make_uint2(0u, 0u);
         return;
@@ -340,7 +349,9 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             a = xydr[id];
             co = conic_opacity[id];
             col = rgb_clamped[id];
-            m = quadrant_mask(a.x, a.y, co, tx, ty);
+            const uint32_t mypos = (uint32_t)(hi - lane);
+            m = quadrant_mask(a.x, a.y, co, tx, ty) &
+                ((mypos < qmax[0] ? 1u : 0u) | (mypos < qmax[1] ? 2u : 0u) | (mypos < qmax[2] ? 4u : 0u) | (mypos < qmax[3] ? 8u : 0u));
             // Gaussian-major slot of this (Gaussian, tile) instance: position in the
             // reference's duplicateWithKeys emission order (rasterizer_impl.cu:98-108)
             int x0, y0, x1, y1;
