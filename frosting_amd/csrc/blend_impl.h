@@ -113,7 +113,7 @@ __device__ __forceinline__ int lanes_before(uint64_t mask, int lane) { return __
 
 // ---------------------------------------------------------------------------
 template <bool EXACT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 6)
 blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
