@@ -1,22 +1,26 @@
 // Front-to-back alpha compositing, forward and backward (the reference's K6 / K7:
 // forward.cu:261-374, backward.cu:399-557), re-designed for CDNA4 wave64:
 //
-//   * one WAVE per 16x16 tile, each lane owns 4 pixels (one per 8x8 quadrant), so a
-//     tile needs no workgroup barrier and no cross-wave reduction, and every LDS
-//     broadcast read of a staged Gaussian is amortised over 4 pixel evaluations;
-//   * instances are staged 64 at a time through LDS from 16-byte per-Gaussian
-//     records (three global_load_dwordx4 gathers per instance);
-//   * EXACT QUADRANT CULLING: while staging, the lane that fetched a Gaussian bounds
-//     its falloff over each 8x8 quadrant (power <= -1/2 lambda_min dist^2) and drops
-//     quadrants -- and, by ballot compaction, whole instances -- where alpha is
-//     provably below the reference's 1/255 cut-off.  The reference's tile lists are
-//     3-sigma squares, so ~40 % of instances and ~70 % of quadrant evaluations go away
-//     while every pixel keeps exactly the value it would have had;
-//   * backward: the per-(tile,Gaussian) gradient is reduced across the wave with a
-//     fixed DPP tree and written ONCE, without atomics, into the instance's
-//     Gaussian-major slot; the per-Gaussian backward kernel sums the slots in a
-//     fixed order.  The reference issues 9 global float atomics per (pixel,
-//     Gaussian) pair (backward.cu:523,545-554) and is not reproducible run to run.
+//   * FORWARD: one WAVE per 8x8 QUADRANT of a 16x16 tile (a 256-thread workgroup = the four
+//     quadrants of one tile; its waves never synchronise with each other), one pixel per
+//     lane: 45 VGPRs, so 8 waves per SIMD hide the LDS / transcendental latency of the
+//     per-Gaussian dependent chain, and a quadrant that saturates retires on its own;
+//   * BACKWARD: one wave per TILE, four pixels per lane (one per quadrant): the nine
+//     gradient components of a (tile, Gaussian) pair are first summed over the lane's
+//     pixels, so the cross-lane reduction -- the single most expensive step -- is paid once
+//     per tile instance instead of once per quadrant instance (measured: 0.72 vs 0.79 ms);
+//   * instances are staged 64 at a time through wave-private LDS from 16-byte
+//     per-Gaussian records (three global_load_dwordx4 gathers per instance);
+//   * EXACT QUADRANT CULLING (quadrant_hit, frg_common.h): while staging, the lane that
+//     fetched a Gaussian bounds its falloff over each quadrant in closed form and the
+//     wave compacts the staged list by ballot.  The reference's tile lists are 3-sigma
+//     squares: more than half of the (quadrant, Gaussian) pairs never reach alpha >= 1/255,
+//     and they are dropped while every pixel keeps exactly its value;
+//   * the backward reduction folds two Gaussians at a time (v_permlane32_swap + one DPP
+//     tree) and stores each (tile, Gaussian) gradient ONCE, without atomics, in the
+//     instance's Gaussian-major slot; the per-Gaussian backward kernel sums the slots in a
+//     fixed order.  The reference issues 9 global float atomics per (pixel, Gaussian)
+//     pair (backward.cu:523,545-554) and is not reproducible run to run.
 //
 // EXACT=true : IEEE operation order of the reference, no contraction, accurate expf
 //              (bit-identical image to the reference built with -ffp-contract=off).
@@ -55,65 +59,21 @@ struct BlendMath<false> {
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
 };
 
-// lane -> pixel of quadrant q inside the tile
-__device__ __forceinline__ void lane_pixel(int lane, int q, int tx, int ty, int& px, int& py)
-{
-    px = tx * FRG_TILE + (q & 1) * 8 + (lane & 7);
-    py = ty * FRG_TILE + (q >> 1) * 8 + (lane >> 3);
-}
-
-// Bit q set <=> some pixel of quadrant q of tile (tx,ty) may reach alpha >= 1/255.
-// alpha = min(0.99, o * exp(power)), power = -1/2 Q(d), Q(d) = a dx^2 + 2 b dx dy + c dy^2, so
-// alpha < 1/255 on the whole quadrant whenever 1/2 min_rect Q > ln(255 o), where the minimum
-// is taken over the continuous rectangle spanned by the quadrant's pixel centres (a superset
-// of the pixels, hence conservative).  Q is convex: if the centre lies inside the rectangle
-// the minimum is 0, otherwise it sits on one of the four edges, where Q restricted to the
-// edge is a 1-D parabola whose clamped vertex gives the edge minimum in closed form.
-// Margins (0.1 % relative, 0.02 absolute on a threshold <= 5.6) dominate the rounding of the
-// per-pixel evaluation (|error| <= ~1e-6 * lambda_max * d^2, lambda_max <= 1/0.3 by the
-// low-pass, d^2 <= 512), so the cull never removes a pixel the reference would have blended.
-__device__ __forceinline__ float rect_min_quadform(float a, float b, float c, float xlo, float xhi, float ylo, float yhi)
-{
-    // offsets are relative to the Gaussian centre: the rectangle is [xlo,xhi] x [ylo,yhi]
-    if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
-    const float ia = 1.0f / a, ic = 1.0f / c;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const float ex = e ? xhi : xlo;                           // vertical edge dx = ex
-        const float dy = fminf(fmaxf(-b * ex * ic, ylo), yhi);
-        best = fminf(best, a * ex * ex + 2.f * b * ex * dy + c * dy * dy);
-        const float ey = e ? yhi : ylo;                           // horizontal edge dy = ey
-        const float dx = fminf(fmaxf(-b * ey * ia, xlo), xhi);
-        best = fminf(best, a * dx * dx + 2.f * b * dx * ey + c * ey * ey);
-    }
-    return best;
-}
-
-__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float4 co, int tx, int ty)
-{
-    const float o = co.w;
-    if (!(o >= 1.0f / 255.0f)) return (o != o) ? 0xFu : 0u;  // exp(power) <= 1 => alpha <= o < 1/255 everywhere
-    const float a = co.x, b = co.y, c = co.z;
-    // not a proper positive-definite conic (or not finite): no bound, keep everything
-    if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f) || !(a < 3.0e38f) || !(c < 3.0e38f)) return 0xFu;
-    const float thr = __logf(255.0f * o) + 0.02f;
-    const float X0 = (float)(tx * FRG_TILE) - x, Y0 = (float)(ty * FRG_TILE) - y;  // tile origin relative to the centre
-    uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float xlo = X0 + (float)((q & 1) * 8), ylo = Y0 + (float)((q >> 1) * 8);
-        const float qmin = rect_min_quadform(a, b, c, xlo, xlo + 7.0f, ylo, ylo + 7.0f);
-        if (!(0.5f * 0.999f * qmin > thr)) m |= 1u << q;
-    }
-    return m;
-}
+#define BLEND_THREADS 256   // 4 waves = the 4 quadrants of one tile
 
 __device__ __forceinline__ int lanes_before(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 
+// wave-private LDS hand-off (no workgroup barrier anywhere in these kernels)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------
 template <bool EXACT>
-__global__ void __launch_bounds__(64, 6)
+__global__ void __launch_bounds__(BLEND_THREADS)
 blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
@@ -124,123 +84,92 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     const int tile = xcd_tile_of_block(blockIdx.x, T);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
 
-    __shared__ float4 s_a[64];    // x, y, quadrant mask bits, contributor (1-based list position)
-    __shared__ float4 s_co[64];   // conic a, b, c, opacity
-    __shared__ float4 s_rgb[64];
+    __shared__ float4 s_a_all[4][64];    // x, y, -, contributor (1-based list position)
+    __shared__ float4 s_co_all[4][64];   // conic a, b, c, opacity
+    __shared__ float4 s_rgb_all[4][64];
+    float4* s_a = s_a_all[q];
+    float4* s_co = s_co_all[q];
+    float4* s_rgb = s_rgb_all[q];
 
-    float pxf[4], pyf[4], Tr[4], C[4][3];
-    uint32_t last[4];
-    int pix[4];
-    uint32_t live = 0;  // bit q set while pixel q still blends
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int px, py;
-        lane_pixel(lane, q, tx, ty, px, py);
-        pxf[q] = (float)px; pyf[q] = (float)py;
-        const bool inside = px < W && py < H;
-        pix[q] = inside ? py * W + px : -1;
-        if (inside) live |= 1u << q;
-        Tr[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.0f; last[q] = 0;
-    }
+    const int qx0 = tx * FRG_TILE + (q & 1) * 8, qy0 = ty * FRG_TILE + (q >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const bool inside = px < W && py < H;
+    bool done = !inside;
+    float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0;
 
     for (int base = 0; base < n; base += 64) {
-        // quadrants whose 64 pixels have all saturated take no further part
-        const uint32_t alive = (__ballot(live & 1u) ? 1u : 0u) | (__ballot(live & 2u) ? 2u : 0u) |
-                               (__ballot(live & 4u) ? 4u : 0u) | (__ballot(live & 8u) ? 8u : 0u);
-        if (alive == 0) break;                   // whole tile saturated
+        if (__ballot(!done) == 0ull) break;      // this quadrant is saturated
         const int cnt = min(64, n - base);
-        uint32_t m = 0;
+        bool hit = false;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
         if (lane < cnt) {
             const uint32_t id = point_list[rg.x + base + lane];
             a = xydr[id];
             co = conic_opacity[id];
             col = rgb_clamped[id];
-            m = quadrant_mask(a.x, a.y, co, tx, ty) & alive;
+            hit = quadrant_hit(a.x, a.y, co, qx0, qy0);
         }
-        const uint64_t keep = __ballot(m != 0);
+        const uint64_t keep = __ballot(hit);
         const int nkeep = __popcll(keep);
-        __syncthreads();
-        if (m != 0) {
+        wave_lds_sync();                          // previous round's readers are done
+        if (hit) {
             const int d = lanes_before(keep, lane);
-            s_a[d] = make_float4(a.x, a.y, __uint_as_float(m), __uint_as_float((uint32_t)(base + lane + 1)));
+            s_a[d] = make_float4(a.x, a.y, 0.f, __uint_as_float((uint32_t)(base + lane + 1)));
             s_co[d] = co;
             s_rgb[d] = col;
         }
-        __syncthreads();
-#ifdef FRG_FWD_BRANCHFREE
-        for (int j = 0; live != 0 && j < nkeep; j++) {
-            const float4 ca = s_a[j], cco = s_co[j];
-            const uint32_t qm = __float_as_uint(ca.z);
-            const uint32_t contributor = __float_as_uint(ca.w);
-            float alpha[4];
-            uint32_t ok = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float dx, dy;
-                const float power = M::power(ca.x, ca.y, cco, pxf[q], pyf[q], dx, dy);
-                alpha[q] = fminf(0.99f, cco.w * M::expo(power));
-                if (!(power > 0.0f) && !(alpha[q] < 1.0f / 255.0f)) ok |= 1u << q;
-            }
-            ok &= qm & live;
-            if (__ballot(ok != 0) == 0ull) continue;
-            const float4 gc = s_rgb[j];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!(ok & (1u << q))) continue;
-                const float test_T = Tr[q] * (1 - alpha[q]);
-                if (test_T < 0.0001f) { live &= ~(1u << q); continue; }
-                C[q][0] += M::mul3(gc.x, alpha[q], Tr[q]);
-                C[q][1] += M::mul3(gc.y, alpha[q], Tr[q]);
-                C[q][2] += M::mul3(gc.z, alpha[q], Tr[q]);
-                Tr[q] = test_T;
-                last[q] = contributor;
-            }
-        }
-#else
-        for (int j = 0; live != 0 && j < nkeep; j++) {
+        wave_lds_sync();
+        for (int j = 0; !done && j < nkeep; j++) {
             const float4 ga = s_a[j];
             const float4 gco = s_co[j];
-            const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(ga.z));
-            const uint32_t contributor = __float_as_uint(ga.w);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!(qm & (1u << q))) continue;       // wave-uniform: quadrant provably untouched
-                if (!(live & (1u << q))) continue;
-                float dx, dy;
-                const float power = M::power(ga.x, ga.y, gco, pxf[q], pyf[q], dx, dy);
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, gco.w * M::expo(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = Tr[q] * (1 - alpha);
-                if (test_T < 0.0001f) { live &= ~(1u << q); continue; }
-                const float4 gc = s_rgb[j];
-                C[q][0] += M::mul3(gc.x, alpha, Tr[q]);
-                C[q][1] += M::mul3(gc.y, alpha, Tr[q]);
-                C[q][2] += M::mul3(gc.z, alpha, Tr[q]);
-                Tr[q] = test_T;
-                last[q] = contributor;
-            }
+            float dx, dy;
+            const float power = M::power(ga.x, ga.y, gco, pxf, pyf, dx, dy);
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, gco.w * M::expo(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = Tr * (1 - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float4 gc = s_rgb[j];
+            C0 += M::mul3(gc.x, alpha, Tr);
+            C1 += M::mul3(gc.y, alpha, Tr);
+            C2 += M::mul3(gc.z, alpha, Tr);
+            Tr = test_T;
+            last = __float_as_uint(ga.w);
         }
-#endif
     }
 
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const size_t plane = (size_t)H * W;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if (pix[q] < 0) continue;
-        const size_t pid = (size_t)pix[q];
-        final_T[pid] = Tr[q];
-        n_contrib[pid] = last[q];
-        out_color[pid] = C[q][0] + Tr[q] * bg0;
-        out_color[plane + pid] = C[q][1] + Tr[q] * bg1;
-        out_color[2 * plane + pid] = C[q][2] + Tr[q] * bg2;
+    if (inside) {
+        const size_t plane = (size_t)H * W;
+        const size_t pid = (size_t)py * W + px;
+        final_T[pid] = Tr;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + Tr * bg[0];
+        out_color[plane + pid] = C1 + Tr * bg[1];
+        out_color[2 * plane + pid] = C2 + Tr * bg[2];
     }
+}
+
+// 4-bit version for the tile-per-wave backward: bit q <=> quadrant q may be touched
+__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float4 co, int tx, int ty)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (quadrant_hit(x, y, co, tx * FRG_TILE + (q & 1) * 8, ty * FRG_TILE + (q >> 1) * 8)) m |= 1u << q;
+    return m;
+}
+
+// lane -> pixel of quadrant q inside the tile (backward: 4 pixels per lane)
+__device__ __forceinline__ void lane_pixel(int lane, int q, int tx, int ty, int& px, int& py)
+{
+    px = tx * FRG_TILE + (q & 1) * 8 + (lane & 7);
+    py = ty * FRG_TILE + (q >> 1) * 8 + (lane >> 3);
 }
 
 // ---------------------------------------------------------------------------

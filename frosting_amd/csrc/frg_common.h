@@ -165,4 +165,43 @@ __device__ __forceinline__ void tile_rect(float px, float py, int max_radius, in
     y1 = min(gy, max(0, f2i((py + max_radius + FRG_TILE - 1) / FRG_TILE)));
 }
 
+// ---- exact quadrant culling ---------------------------------------------------------
+// Can any pixel of the 8x8 quadrant whose first pixel is (qx0, qy0) reach alpha >= 1/255
+// for the Gaussian (centre x,y; conic a,b,c; opacity o)?
+// alpha = min(0.99, o * exp(power)), power = -1/2 Q(d), Q(d) = a dx^2 + 2 b dx dy + c dy^2, so
+// alpha < 1/255 on the whole quadrant whenever 1/2 min_rect Q > ln(255 o), the minimum taken
+// over the continuous rectangle spanned by the quadrant's pixel centres (a superset of the
+// pixels, hence conservative).  Q is convex: if the centre lies inside the rectangle the
+// minimum is 0, otherwise it sits on one of the four edges, where Q restricted to the edge is
+// a 1-D parabola whose clamped vertex gives the edge minimum in closed form.  Margins (0.1 %
+// relative, 0.02 absolute on a threshold <= 5.6) dominate the rounding of the per-pixel
+// evaluation (|error| <= ~1e-6 * lambda_max * d^2, lambda_max <= 1/0.3 by the low-pass,
+// d^2 <= 512), so the cull never removes a pixel the reference would have blended.
+// Evaluated WITHOUT contraction so that the blend kernels and the per-Gaussian backward
+// (which re-derives which quadrant slots exist) agree bit for bit.
+__device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx0, int qy0)
+{
+#pragma clang fp contract(off)
+    const float o = co.w;
+    if (!(o >= 1.0f / 255.0f)) return o != o;  // exp(power) <= 1 => alpha <= o < 1/255 everywhere
+    const float a = co.x, b = co.y, c = co.z;
+    // not a proper positive-definite conic (or not finite): no bound, keep
+    if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f) || !(a < 3.0e38f) || !(c < 3.0e38f)) return true;
+    const float thr = __logf(255.0f * o) + 0.02f;
+    const float xlo = (float)qx0 - x, ylo = (float)qy0 - y, xhi = xlo + 7.0f, yhi = ylo + 7.0f;
+    if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return true;  // centre inside: Q = 0
+    const float ia = 1.0f / a, ic = 1.0f / c;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const float ex = e ? xhi : xlo;                           // vertical edge dx = ex
+        const float dy = fminf(fmaxf(-b * ex * ic, ylo), yhi);
+        best = fminf(best, a * ex * ex + 2.f * b * ex * dy + c * dy * dy);
+        const float ey = e ? yhi : ylo;                           // horizontal edge dy = ey
+        const float dx = fminf(fmaxf(-b * ey * ia, xlo), xhi);
+        best = fminf(best, a * dx * dx + 2.f * b * dx * ey + c * ey * ey);
+    }
+    return !(0.5f * 0.999f * best > thr);
+}
+
 }  // namespace frg
