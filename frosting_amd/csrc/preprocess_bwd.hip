@@ -38,7 +38,7 @@ __device__ __forceinline__ void wave_fence()
 }
 
 template <bool SH16>
-__global__ void __launch_bounds__(BWD_THREADS)
+__global__ void __launch_bounds__(BWD_THREADS, 5)
 preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                       const float* __restrict__ means3D, const int* __restrict__ radii,
@@ -219,14 +219,65 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 
     // ---- 4. SH path (backward.cu:20-139) ----
     if (shs) {
-        float sh[48], wgt[16], dRGB[3] = {0.f, 0.f, 0.f};  // dL/dsh[i][ch] = wgt[i] * dRGB[ch]
-#pragma unroll
-        for (int i = 0; i < 48; i++) sh[i] = 0.0f;
+        // dL/dsh[i][ch] = wgt[i] * dRGB[ch]; the view-direction gradient needs
+        // d(colour)/d(dir) = sum_i dbasis_i/d(dir) * sh[i], accumulated per channel in ddx/ddy/ddz
+        float wgt[16], dRGB[3] = {0.f, 0.f, 0.f};
+        float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
         const int M = vp.M;
+        const int deg = vp.D;
+        float x = 0.f, y = 0.f, z = 1.f, dox = 0.f, doy = 0.f, doz = 1.f;
+        if (visible) {
+            dox = mean.x - vmx.campos[0]; doy = mean.y - vmx.campos[1]; doz = mean.z - vmx.campos[2];
+            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+            x = dox / len; y = doy / len; z = doz / len;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
+        }
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        if (visible) {
+            wgt[0] = kSH0;
+            if (deg > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
+            if (deg > 1) {
+                wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
+                wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
+            }
+            if (deg > 2) {
+                wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
+                wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
+                wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
+            }
+        }
+        // one coefficient (basis i, channel ch, value sv) -> its share of d(colour_ch)/d(dir);
+        // i is a compile-time constant at every call site (unrolled), so only one case survives
+        auto feed = [&](int i, int ch, float sv) {
+            if (i >= 1 && i <= 3 && deg < 1) return;
+            if (i >= 4 && i <= 8 && deg < 2) return;
+            if (i >= 9 && deg < 3) return;
+            switch (i) {
+            case 1: ddy[ch] += -kSH1 * sv; break;
+            case 2: ddz[ch] += kSH1 * sv; break;
+            case 3: ddx[ch] += -kSH1 * sv; break;
+            case 4: ddx[ch] += kSH2[0] * y * sv; ddy[ch] += kSH2[0] * x * sv; break;
+            case 5: ddy[ch] += kSH2[1] * z * sv; ddz[ch] += kSH2[1] * y * sv; break;
+            case 6: ddx[ch] += kSH2[2] * 2.f * -x * sv; ddy[ch] += kSH2[2] * 2.f * -y * sv; ddz[ch] += kSH2[2] * 2.f * 2.f * z * sv; break;
+            case 7: ddx[ch] += kSH2[3] * z * sv; ddz[ch] += kSH2[3] * x * sv; break;
+            case 8: ddx[ch] += kSH2[4] * 2.f * x * sv; ddy[ch] += kSH2[4] * 2.f * -y * sv; break;
+            case 9: ddx[ch] += kSH3[0] * sv * 3.f * 2.f * xy; ddy[ch] += kSH3[0] * sv * 3.f * (xx - yy); break;
+            case 10: ddx[ch] += kSH3[1] * sv * yz; ddy[ch] += kSH3[1] * sv * xz; ddz[ch] += kSH3[1] * sv * xy; break;
+            case 11: ddx[ch] += kSH3[2] * sv * -2.f * xy; ddy[ch] += kSH3[2] * sv * (-3.f * yy + 4.f * zz - xx); ddz[ch] += kSH3[2] * sv * 4.f * 2.f * yz; break;
+            case 12: ddx[ch] += kSH3[3] * sv * -3.f * 2.f * xz; ddy[ch] += kSH3[3] * sv * -3.f * 2.f * yz; ddz[ch] += kSH3[3] * sv * 3.f * (2.f * zz - xx - yy); break;
+            case 13: ddx[ch] += kSH3[4] * sv * (-3.f * xx + 4.f * zz - yy); ddy[ch] += kSH3[4] * sv * -2.f * xy; ddz[ch] += kSH3[4] * sv * 4.f * 2.f * xz; break;
+            case 14: ddx[ch] += kSH3[5] * sv * 2.f * xz; ddy[ch] += kSH3[5] * sv * -2.f * yz; ddz[ch] += kSH3[5] * sv * (xx - yy); break;
+            case 15: ddx[ch] += kSH3[6] * sv * 3.f * (xx - yy); ddy[ch] += kSH3[6] * sv * -3.f * 2.f * xy; break;
+            default: break;
+            }
+        };
         if (SH16) {
-            // coalesced read: the wave's 64 x 48 floats are one contiguous stream of 768 float4
+            // coalesced read: the wave's 64 x 48 floats are one contiguous stream of 768 float4,
+            // transposed through LDS 16 Gaussians at a time and consumed as they arrive
             const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
             const int nvalid = min(64, P - idx0);
 #pragma unroll 1
@@ -237,75 +288,25 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                     if (h * BWD_SUB + gl < nvalid) shbuf[gl * BWD_ROW_F4 + j] = src[(size_t)h * BWD_SUB * 12 + f];
                 }
                 wave_fence();
-                if ((lane / BWD_SUB) == h) {
+                if ((lane / BWD_SUB) == h && visible) {
 #pragma unroll
                     for (int j = 0; j < 12; j++) {
                         const float4 v = shbuf[(lane % BWD_SUB) * BWD_ROW_F4 + j];
-                        sh[4 * j] = v.x; sh[4 * j + 1] = v.y; sh[4 * j + 2] = v.z; sh[4 * j + 3] = v.w;
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int t = 0; t < 4; t++) feed((4 * j + t) / 3, (4 * j + t) % 3, vv[t]);
                     }
                 }
                 wave_fence();
             }
         } else if (visible) {
-            const float* s = shs + (size_t)idx * M * 3;
+            const float* sp = shs + (size_t)idx * M * 3;
             const int n = min(M, 16) * 3;
 #pragma unroll
-            for (int i = 0; i < 48; i++)
-                if (i < n) sh[i] = s[i];
+            for (int e = 0; e < 48; e++)
+                if (e < n) feed(e / 3, e % 3, sp[e]);
         }
         if (visible) {
-            const float dox = mean.x - vmx.campos[0], doy = mean.y - vmx.campos[1], doz = mean.z - vmx.campos[2];
-            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-            const float x = dox / len, y = doy / len, z = doz / len;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
-            float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
-            const int deg = vp.D;
-#define SH_(i, ch) sh[(i) * 3 + (ch)]
-#define OUT_(i, wv) wgt[i] = (wv)
-            OUT_(0, kSH0);
-            if (deg > 0) {
-                const float w1 = -kSH1 * y, w2 = kSH1 * z, w3 = -kSH1 * x;
-                OUT_(1, w1); OUT_(2, w2); OUT_(3, w3);
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    ddx[ch] = -kSH1 * SH_(3, ch); ddy[ch] = -kSH1 * SH_(1, ch); ddz[ch] = kSH1 * SH_(2, ch);
-                }
-                if (deg > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    const float w4 = kSH2[0] * xy, w5 = kSH2[1] * yz, w6 = kSH2[2] * (2.f * zz - xx - yy);
-                    const float w7 = kSH2[3] * xz, w8 = kSH2[4] * (xx - yy);
-                    OUT_(4, w4); OUT_(5, w5); OUT_(6, w6); OUT_(7, w7); OUT_(8, w8);
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        ddx[ch] += kSH2[0] * y * SH_(4, ch) + kSH2[2] * 2.f * -x * SH_(6, ch) + kSH2[3] * z * SH_(7, ch) + kSH2[4] * 2.f * x * SH_(8, ch);
-                        ddy[ch] += kSH2[0] * x * SH_(4, ch) + kSH2[1] * z * SH_(5, ch) + kSH2[2] * 2.f * -y * SH_(6, ch) + kSH2[4] * 2.f * -y * SH_(8, ch);
-                        ddz[ch] += kSH2[1] * y * SH_(5, ch) + kSH2[2] * 2.f * 2.f * z * SH_(6, ch) + kSH2[3] * x * SH_(7, ch);
-                    }
-                    if (deg > 2) {
-                        const float w9 = kSH3[0] * y * (3.f * xx - yy), w10 = kSH3[1] * xy * z;
-                        const float w11 = kSH3[2] * y * (4.f * zz - xx - yy), w12 = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                        const float w13 = kSH3[4] * x * (4.f * zz - xx - yy), w14 = kSH3[5] * z * (xx - yy);
-                        const float w15 = kSH3[6] * x * (xx - 3.f * yy);
-                        OUT_(9, w9); OUT_(10, w10); OUT_(11, w11); OUT_(12, w12); OUT_(13, w13); OUT_(14, w14); OUT_(15, w15);
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            ddx[ch] += (kSH3[0] * SH_(9, ch) * 3.f * 2.f * xy + kSH3[1] * SH_(10, ch) * yz + kSH3[2] * SH_(11, ch) * -2.f * xy +
-                                        kSH3[3] * SH_(12, ch) * -3.f * 2.f * xz + kSH3[4] * SH_(13, ch) * (-3.f * xx + 4.f * zz - yy) +
-                                        kSH3[5] * SH_(14, ch) * 2.f * xz + kSH3[6] * SH_(15, ch) * 3.f * (xx - yy));
-                            ddy[ch] += (kSH3[0] * SH_(9, ch) * 3.f * (xx - yy) + kSH3[1] * SH_(10, ch) * xz +
-                                        kSH3[2] * SH_(11, ch) * (-3.f * yy + 4.f * zz - xx) + kSH3[3] * SH_(12, ch) * -3.f * 2.f * yz +
-                                        kSH3[4] * SH_(13, ch) * -2.f * xy + kSH3[5] * SH_(14, ch) * -2.f * yz +
-                                        kSH3[6] * SH_(15, ch) * -3.f * 2.f * xy);
-                            ddz[ch] += (kSH3[1] * SH_(10, ch) * xy + kSH3[2] * SH_(11, ch) * 4.f * 2.f * yz +
-                                        kSH3[3] * SH_(12, ch) * 3.f * (2.f * zz - xx - yy) + kSH3[4] * SH_(13, ch) * 4.f * 2.f * xz +
-                                        kSH3[5] * SH_(14, ch) * (xx - yy));
-                        }
-                    }
-                }
-            }
-#undef SH_
-#undef OUT_
             const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
             const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
             const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
