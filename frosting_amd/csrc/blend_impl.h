@@ -326,7 +326,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                 uint32_t ok = 0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    G[q] = 0.f; alpha[q] = 0.f; dxs[q] = 0.f; dys[q] = 0.f;
                     if (!(qm & (1u << q))) continue;
                     const float power = M::power(ca.x, ca.y, cco, pxf[q], pyf[q], dxs[q], dys[q]);
                     G[q] = M::expo(power);
@@ -362,16 +361,20 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                 }
             }
             if (!(any_a || any_b)) continue;
+            // step-major order: the nine chains advance together, so every DPP add has eight
+            // independent instructions between it and its consumer (no s_nop padding)
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) {
-                float v = fold_two(pa[c], pb[c]);     // lanes 0-31: a[l] + a[l+32], lanes 32-63: b[l-32] + b[l]
-                v = dpp_step<0xB1, 0xf>(v);           // quad_perm [1,0,3,2]
-                v = dpp_step<0x4E, 0xf>(v);           // quad_perm [2,3,0,1]
-                v = dpp_step<0x141, 0xf>(v);          // row_half_mirror
-                v = dpp_step<0x140, 0xf>(v);          // row_mirror
-                v = dpp_step<0x142, 0xa>(v);          // row_bcast:15 -> lane 31 holds sum(a), lane 63 sum(b)
-                pa[c] = v;
-            }
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = fold_two(pa[c], pb[c]);  // lanes 0-31: a[l]+a[l+32], 32-63: b
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0xB1, 0xf>(pa[c]);   // quad_perm [1,0,3,2]
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x4E, 0xf>(pa[c]);   // quad_perm [2,3,0,1]
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x141, 0xf>(pa[c]);  // row_half_mirror
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x140, 0xf>(pa[c]);  // row_mirror
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x142, 0xa>(pa[c]);  // row_bcast:15 -> lane 31: sum(a), lane 63: sum(b)
             if (lane == 31 && any_a) {
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[k * FRG_SLOT_FLOATS + c] = pa[c];
