@@ -26,6 +26,46 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+// Walk all (Gaussian, tile) instances of the wave's 64 Gaussians with the 64 lanes in
+// lock-step: lane l of step k handles instance 64 k + l of the wave's concatenated tile
+// rectangles (owner found by binary search over the per-lane starts in LDS).  A per-lane
+// `for y, for x` loop instead runs for as long as the LARGEST rectangle in the wave
+// (heavy-tailed: ~50 iterations against an average of 6.5 instances per Gaussian).
+// lds_start: 65 words, lds_info: 64 int4, both private to the wave.
+template <typename F>
+__device__ __forceinline__ void wave_for_each_instance(uint32_t touched, int x0, int y0, int rect_w, uint32_t payload,
+                                                        uint32_t* lds_start, int4* lds_info, int gx, F&& f)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t incl = wave_incl_scan(touched, lane);
+    const uint32_t S = (uint32_t)__shfl((int)incl, 63, 64);
+    if (S == 0) return;   // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    lds_start[lane] = incl - touched;
+    if (lane == 0) lds_start[64] = S;
+    lds_info[lane] = make_int4(x0, y0, rect_w, (int)payload);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        if (s < S) {
+            int owner = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int mid = owner + step;
+                if (mid < 64 && lds_start[mid] <= s) owner = mid;
+            }
+            const int4 info = lds_info[owner];
+            const uint32_t k = s - lds_start[owner];
+            const uint32_t w = (uint32_t)info.z;
+            const uint32_t ry = k / w, rx = k - ry * w;
+            f(owner, (info.y + (int)ry) * gx + info.x + (int)rx, (uint32_t)info.w);
+        }
+    }
+}
+
 // Per-Gaussian forward math (forward.cu:155-256).  Returns tiles_touched; fills the
 // three 16-byte records and the tile rectangle when the Gaussian is kept.
 __device__ __forceinline__ uint32_t
@@ -159,6 +199,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
+    __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
+    __shared__ int4 emit_info[FRG_BIN_THREADS];
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
@@ -170,6 +212,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int idx = c * FRG_BIN_THREADS + threadIdx.x;
         uint32_t touched = 0;
+        int rx0 = 0, ry0 = 0, rw = 1;
         float3 dir = make_float3(0.f, 0.f, 1.f);
         if (idx < P) {
             int radius_i, x0, y0, x1, y1;
@@ -178,13 +221,15 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                                      radius_i, x0, y0, x1, y1, dir);
             radii[idx] = radius_i;
             tiles_touched[idx] = touched;
-            if (touched) {
-                for (int y = y0; y < y1; y++)
-                    for (int x = x0; x < x1; x++) {
-                        if (LDS_BINS) atomicAdd(&lds_bins[y * vp.gx + x], 1u);   // ds_add_u32
-                        else atomicAdd(&tile_count[y * vp.gx + x], 1u);
-                    }
-            }
+            rx0 = x0; ry0 = y0; rw = x1 - x0;
+        }
+        {   // per-tile instance counts
+            const int wave = threadIdx.x >> 6;
+            wave_for_each_instance(touched, rx0, ry0, rw, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
+                                   [&](int, int t, uint32_t) {
+                                       if (LDS_BINS) atomicAdd(&lds_bins[t], 1u);   // ds_add_u32
+                                       else atomicAdd(&tile_count[t], 1u);
+                                   });
         }
         // ---- colour ----
         if (colors_precomp) {
@@ -365,6 +410,8 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
+    __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
+    __shared__ int4 emit_info[FRG_BIN_THREADS];
     const int T = gx * gy;
     if (LDS_BINS) {
         const uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
@@ -378,19 +425,22 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
         uint32_t total;
         const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
         if (idx < P) point_offsets[idx] = chunk_prefix[c] + inc;
-        if (touched == 0) continue;
-        const float4 g = xydr[idx];
-        int x0, y0, x1, y1;
-        tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
-        const uint2 rec = make_uint2(__float_as_uint(g.z), (uint32_t)idx);
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
-                const int t = y * gx + x;
-                uint32_t pos;
-                if (LDS_BINS) pos = atomicAdd(&lds_bins[t], 1u);             // ds_add_rtn_u32
-                else pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
-                pairs[pos] = rec;
-            }
+        int x0 = 0, y0 = 0, x1 = 1, y1 = 0;
+        uint32_t dbits = 0;
+        if (touched) {
+            const float4 g = xydr[idx];
+            tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
+            dbits = __float_as_uint(g.z);
+        }
+        const int wave = threadIdx.x >> 6;
+        const uint32_t idx0 = (uint32_t)(c * FRG_BIN_THREADS + wave * 64);
+        wave_for_each_instance(touched, x0, y0, x1 - x0, dbits, emit_start + wave * 68, emit_info + wave * 64, gx,
+                               [&](int owner, int t, uint32_t depth_bits) {
+                                   uint32_t pos;
+                                   if (LDS_BINS) pos = atomicAdd(&lds_bins[t], 1u);             // ds_add_rtn_u32
+                                   else pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
+                                   pairs[pos] = make_uint2(depth_bits, idx0 + (uint32_t)owner);
+                               });
     }
 }
 
@@ -419,7 +469,7 @@ static int bin_blocks(int P)
 template <typename K>
 static hipError_t allow_big_lds(K kernel, size_t bytes)
 {
-    if (bytes <= 48 * 1024) return hipSuccess;
+    if (bytes <= 16 * 1024) return hipSuccess;   // (static LDS of these kernels is large: ask early)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
@@ -430,7 +480,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
     const size_t lds = LDS_BINS ? (size_t)T * 4 : 0;
-    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SH16>, lds + 64 * 1024);
+    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SH16>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SH16>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,

@@ -100,7 +100,7 @@ int frg_backward(int P, int D, int M, int R,
  * The per-Gaussian stages are always evaluated in the exact order, so radii,
  * tile counts and sort keys never depend on this switch.  "profile": see
  * frg_stage_times.  "global_bins": 1 forces the binning path used for images with
- * more than 24576 tiles (global atomics instead of LDS histograms; test hook).
+ * more than 20480 tiles (global atomics instead of LDS histograms; test hook).
  * Returns the previous value or FRG_EINVAL for an unknown name. */
 int frg_set_option(const char* name, int value);
 int frg_get_option(const char* name);
