@@ -50,6 +50,19 @@ def stage_bytes(P, V, R, N, T):
     }
 
 
+def pmc_traffic(stage: str, cfg_name: str, P: int):
+    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes of this very
+    workload (profiles/r01_pmc_traffic.json; counters cannot be read from inside the process).
+    None when the run is not the profiled configuration."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"] or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["per_launch"][stage]["hbm_bytes_corrected"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg_name: str, P: int):
     """C restatement of the reference (oracle/gs_oracle.c, OpenMP) timed on the host
     cores for ONE forward+backward of the same workload -- reported, not a target."""
@@ -162,7 +175,7 @@ def main():
             dom = max(avg, key=avg.get)
             ach = B[dom] / (avg[dom] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.config, P),
                                "algorithmic_bytes_per_launch": B[dom], "avg_launch_ms": avg[dom]}
             out["stage_ms"] = avg
         if not args.no_cpu_baseline and world == 1:

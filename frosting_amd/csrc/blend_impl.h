@@ -350,14 +350,16 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                     part[2] += w * dLp[q][2];
                     const float dL_dalpha = Tr[q] * cdot - S[q] * rinv;
                     S[q] += w * cdot;
-                    const float dL_dG = cco.w * dL_dalpha;
-                    const float gdx = G[q] * dxs[q], gdy = G[q] * dys[q];
-                    part[3] -= dL_dG * (gdx * cco.x + gdy * cco.y);
-                    part[4] -= dL_dG * (gdy * cco.z + gdx * cco.y);
-                    part[5] += gdx * dxs[q] * dL_dG;
-                    part[6] += gdx * dys[q] * dL_dG;
-                    part[7] += gdy * dys[q] * dL_dG;
-                    part[8] += G[q] * dL_dalpha;
+                    // moments of v = G dL/dalpha over the pixels; opacity, conic and the NDC factors
+                    // are applied once per (tile, Gaussian) at the write-out below
+                    const float v = G[q] * dL_dalpha;
+                    const float vx = v * dxs[q], vy = v * dys[q];
+                    part[3] += vx;
+                    part[4] += vy;
+                    part[5] += vx * dxs[q];
+                    part[6] += vx * dys[q];
+                    part[7] += vy * dys[q];
+                    part[8] += v;
                 }
             }
             if (!(any_a || any_b)) continue;
@@ -388,16 +390,20 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         if (lane < nkeep) {
             const uint32_t slot = __float_as_uint(s_rgb[lane].w);
             float* dst = slots + (size_t)slot * FRG_SLOT_FLOATS;
+            float m[FRG_SLOT_FLOATS];
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) {
-                float v = s_part[lane * FRG_SLOT_FLOATS + c];
-                // constant factors hoisted out of the pixel loop: d(pixel)/d(NDC) for the mean
-                // (backward.cu:460-461) and -1/2 for the conic terms (backward.cu:549-551)
-                if (c == 3) v *= ddelx_dx;
-                if (c == 4) v *= ddely_dy;
-                if (c >= 5 && c <= 7) v *= -0.5f;
-                dst[c] = v;
-            }
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) m[c] = s_part[lane * FRG_SLOT_FLOATS + c];
+            // from pixel moments to the reference's per-Gaussian terms (backward.cu:536-554):
+            //   dL/dG = o dL/dalpha, dG/d(delta) = -G (a dx + b dy, c dy + b dx), d(delta)/d(NDC) = (W/2, H/2)
+            const float4 kc = s_co[lane];
+            const float o = kc.w;
+            dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2];
+            dst[3] = -o * (kc.x * m[3] + kc.y * m[4]) * ddelx_dx;
+            dst[4] = -o * (kc.z * m[4] + kc.y * m[3]) * ddely_dy;
+            dst[5] = -0.5f * o * m[5];
+            dst[6] = -0.5f * o * m[6];
+            dst[7] = -0.5f * o * m[7];
+            dst[8] = m[8];
         }
     }
 }
