@@ -1,7 +1,7 @@
 // C ABI of libfrosting_rasterizer.so (include/frosting_rasterizer.h): host-side
 // orchestration of the forward / backward kernel sequence on the caller's HIP
 // stream.  Mirrors the reference's Rasterizer::forward / backward control flow
-// (rasterizer_impl.cu:198-336, :340-434) -- one blocking 16-byte read-back for
+// (rasterizer_impl.cu:198-336, :340-434) -- one blocking 48-byte read-back for
 // num_rendered, everything else asynchronous.
 #include "../../include/frosting_rasterizer.h"
 #include "kernels.h"
@@ -70,7 +70,7 @@ int exact_blend()
     return v;
 }
 
-// One pinned 16-byte landing pad per host thread for the counters read-back.
+// One pinned landing pad per host thread for the counters read-back.
 frg::Counters* pinned_counters()
 {
     thread_local frg::Counters* p = nullptr;
@@ -246,7 +246,7 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
 
     if (R > 0) {
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, max_tile, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
     } else {
         // point_offsets must still be defined for backward
         FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");

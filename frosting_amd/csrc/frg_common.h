@@ -50,12 +50,19 @@ struct GeomState {
 };
 
 // ---- image chunk ----------------------------------------------------------
-struct Counters {            // written by the scan kernel, 16 bytes read back by the host
+#define FRG_SORT_CLASSES 5    // tile-list size classes of the sort: <=512, <=2048, <=4096, <=8192, >8192
+struct Counters {            // written by the scan kernel, 48 bytes read back by the host
     uint32_t num_rendered;
     uint32_t max_tile_count;
     uint32_t filtered;       // prefiltered assertion (auxiliary.h:154-162)
     uint32_t pad;
+    uint32_t class_count[FRG_SORT_CLASSES];  // number of tiles per sort size class
+    uint32_t pad2[3];
 };
+__host__ __device__ inline int sort_class_of(uint32_t n)
+{
+    return n <= 512 ? 0 : n <= 2048 ? 1 : n <= 4096 ? 2 : n <= 8192 ? 3 : 4;
+}
 
 struct ImageState {
     float* final_T;          // accum_alpha in the reference (rasterizer_impl.h:47)
@@ -68,6 +75,7 @@ struct ImageState {
     uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts -> scatter bases
     uint32_t* seg_sums;      // [FRG_BIN_SEGS][T]
     bool lds_bins;           // false: image too large for LDS histograms -> global-atomic binning
+    uint32_t* class_tiles;   // [FRG_SORT_CLASSES][T] tile ids per sort size class (non-empty tiles only)
     size_t zero_begin, zero_bytes;  // region [tile_count .. counters] cleared with one memset
     size_t bytes;
     __host__ static ImageState carve(char* base, int W, int H, bool force_global_bins = false)
@@ -85,6 +93,7 @@ struct ImageState {
         s.tile_fill = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
+        s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
         s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;
         s.bin_matrix = nullptr; s.seg_sums = nullptr;
         if (s.lds_bins) {

@@ -17,8 +17,8 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
                           const BinningState& b, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
 
-hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
-                            uint32_t* point_list, hipStream_t stream);
+hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* class_tiles, const uint2* ranges,
+                            uint2* pairs, uint2* pairs_tmp, uint32_t* point_list, hipStream_t stream);
 
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                   const float* bg, float* out_color, hipStream_t s);

@@ -318,13 +318,16 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
 // per-segment sums become per-segment start offsets for colbase_kernel.
 __global__ void __launch_bounds__(1024)
 scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
-            uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, Counters* __restrict__ counters)
+            uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
+            Counters* __restrict__ counters)
 {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t maxc_s;
+    __shared__ uint32_t cls_s[FRG_SORT_CLASSES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { carry_s = 0; maxc_s = 0; }
+    if (tid < FRG_SORT_CLASSES) cls_s[tid] = 0;
     __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
         const int n = pass == 0 ? nchunks : T;
@@ -352,6 +355,10 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
                 if (pass == 0) block_sums[i] = excl;
                 else {
                     ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
+                    if (v) {  // work list of the sort: only non-empty tiles, grouped by size class
+                        const int cls = sort_class_of(v);
+                        class_tiles[(size_t)cls * T + atomicAdd(&cls_s[cls], 1u)] = (uint32_t)i;
+                    }
                     if (use_segs) {  // segment s of tile i starts at excl + sum of earlier segments
                         uint32_t run = excl;
 #pragma unroll
@@ -375,6 +382,7 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
         __syncthreads();
     }
     if (tid == 0) counters->max_tile_count = maxc_s;
+    if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = cls_s[tid];
 }
 
 // Turns the count matrix into the base matrix in place: base[b][t] = first position
@@ -508,7 +516,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     if (img.lds_bins)
         hipLaunchKernelGGL(colsum_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
-                       img.lds_bins ? 1 : 0, img.ranges, img.counters);
+                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters);
     if (img.lds_bins)
         hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     return hipGetLastError();

@@ -263,19 +263,18 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
 // launches one instantiation per size class; workgroups whose tile is outside exit at once).
 template <int NWAVES, int CAP>
 __global__ void __launch_bounds__(NWAVES * 64)
-sort_tiles_lds_kernel(int T, int lo, const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
-                      uint32_t* __restrict__ point_list)
+sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __restrict__ ranges,
+                      const uint2* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
     static_assert(CAP == NWAVES * 64 * SORT_ITEMS, "each thread stages SORT_ITEMS elements");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* buf = reinterpret_cast<uint2*>(smem);
     uint32_t* whist = reinterpret_cast<uint32_t*>(buf + CAP);
     uint32_t* scratch = whist + NWAVES * 256;  // 260 words
-    const int tile = blockIdx.x;
-    if (tile >= T) return;
+    const int tile = (int)tile_list[blockIdx.x];   // the grid covers exactly the tiles of this size class
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
-    if (n <= lo || n > CAP) return;
+    if (n > CAP) return;
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 512
@@ -323,16 +322,14 @@ sort_tiles_lds_kernel(int T, int lo, const uint2* __restrict__ ranges, const uin
 // in global memory (pairs <-> pairs_tmp); only histograms live in LDS.
 template <int NWAVES>
 __global__ void __launch_bounds__(NWAVES * 64)
-sort_tiles_global_kernel(int T, int lo, const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_tmp,
-                         uint32_t* __restrict__ point_list)
+sort_tiles_global_kernel(const uint32_t* __restrict__ tile_list, const uint2* __restrict__ ranges, uint2* pairs,
+                         uint2* pairs_tmp, uint32_t* __restrict__ point_list)
 {
     __shared__ uint32_t whist[NWAVES * 256];
     __shared__ uint32_t scratch[260];
-    const int tile = blockIdx.x;
-    if (tile >= T) return;
+    const int tile = (int)tile_list[blockIdx.x];
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
-    if (n <= lo) return;
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x;
     if (tid == 0) scratch[256] = 0;
@@ -343,8 +340,10 @@ sort_tiles_global_kernel(int T, int lo, const uint2* __restrict__ ranges, uint2*
 
 // Host-side launcher (called from api.hip)
 template <int NW, int CAP>
-static hipError_t launch_lds_class(int T, int lo, const uint2* ranges, const uint2* pairs, uint32_t* point_list, hipStream_t stream)
+static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const uint2* ranges, const uint2* pairs,
+                                   uint32_t* point_list, hipStream_t stream)
 {
+    if (count <= 0) return hipSuccess;
     const size_t lds = (size_t)CAP * 8 + NW * 1024 + 260 * 4;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
@@ -353,13 +352,15 @@ static hipError_t launch_lds_class(int T, int lo, const uint2* ranges, const uin
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((sort_tiles_lds_kernel<NW, CAP>), dim3(T), dim3(NW * 64), lds, stream, T, lo, ranges, pairs, point_list);
+    hipLaunchKernelGGL((sort_tiles_lds_kernel<NW, CAP>), dim3(count), dim3(NW * 64), lds, stream, tile_list, ranges, pairs, point_list);
     return hipGetLastError();
 }
 
 // The size classes touch disjoint tiles, so they run concurrently: the large-tile
 // classes are forked onto two internal side streams (event fork / join around the
-// caller's stream) instead of queueing behind the small-tile pass.
+// caller's stream) instead of queueing behind the small-tile pass.  Each launch covers
+// exactly the tiles of its class (lists built by scan_kernel): a grid of all T tiles with
+// early exits was dominated by dispatching ~6000 no-op 1024-thread workgroups.
 struct SortStreams {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
@@ -377,45 +378,40 @@ struct SortStreams {
     }
 };
 
-hipError_t launch_tile_sort(int T, int max_tile_count, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
-                            uint32_t* point_list, hipStream_t stream)
+hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* class_tiles, const uint2* ranges,
+                            uint2* pairs, uint2* pairs_tmp, uint32_t* point_list, hipStream_t stream)
 {
-    if (T <= 0 || max_tile_count <= 0) return hipSuccess;
+    const int c0 = (int)class_count[0], c1 = (int)class_count[1], c2 = (int)class_count[2], c3 = (int)class_count[3],
+              c4 = (int)class_count[4];
+    if (T <= 0 || c0 + c1 + c2 + c3 + c4 == 0) return hipSuccess;
     thread_local SortStreams ss;
-    const bool forked = max_tile_count > 2048 && ss.ensure();
+    const bool big = (c2 + c3 + c4) > 0;
+    const bool forked = big && ss.ensure();
     hipStream_t s1 = stream, s2 = stream;
     hipError_t e;
     if (forked) {
         if ((e = hipEventRecord(ss.fork, stream)) != hipSuccess) return e;
         s1 = ss.side[0]; s2 = ss.side[1];
-        if ((e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
-        if (max_tile_count > 4096 && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
+        if (c2 && (e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
+        if ((c3 + c4) && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
     }
     // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 16 waves,
-    // >8192 global ping-pong
-    if (max_tile_count > 4096) {  // longest-running class first
-        e = launch_lds_class<16, FRG_SORT_LDS_CAP>(T, 4096, ranges, pairs, point_list, s2);
-        if (e != hipSuccess) return e;
-        if (max_tile_count > FRG_SORT_LDS_CAP) {
-            if (!pairs_tmp) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(T), dim3(1024), 0, s2, T, FRG_SORT_LDS_CAP, ranges, pairs, pairs_tmp, point_list);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
+    // >8192 global ping-pong; longest-running classes first
+    if (c4) {
+        if (!pairs_tmp) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(c4), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, ranges, pairs, pairs_tmp, point_list);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (max_tile_count > 2048) {
-        e = launch_lds_class<8, 4096>(T, 2048, ranges, pairs, point_list, s1);
-        if (e != hipSuccess) return e;
-    }
-    if (max_tile_count > 512) {
-        e = launch_lds_class<4, 2048>(T, 512, ranges, pairs, point_list, stream);
-        if (e != hipSuccess) return e;
-    }
-    e = launch_lds_class<1, 512>(T, 0, ranges, pairs, point_list, stream);   // one wave per small tile: no real barriers
-    if (e != hipSuccess) return e;
+    if ((e = launch_lds_class<16, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, ranges, pairs, point_list, s2)) != hipSuccess) return e;
+    if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, ranges, pairs, point_list, s1)) != hipSuccess) return e;
+    if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, ranges, pairs, point_list, stream)) != hipSuccess) return e;
+    if ((e = launch_lds_class<1, 512>(c0, class_tiles, ranges, pairs, point_list, stream)) != hipSuccess) return e;
     if (forked) {
-        if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(stream, ss.join[0], 0)) != hipSuccess) return e;
-        if (max_tile_count > 4096) {
+        if (c2) {
+            if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(stream, ss.join[0], 0)) != hipSuccess) return e;
+        }
+        if (c3 + c4) {
             if ((e = hipEventRecord(ss.join[1], s2)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, ss.join[1], 0)) != hipSuccess) return e;
         }

@@ -61,7 +61,7 @@ int frg_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * out_color is [3,H,W] planar and fully written; radii is [P] int32 and fully
  * written.  The three chunks obtained through the callbacks are opaque state for
  * frg_backward (layout: frg_*_layout below, for tests only).  One device->host
- * read of 16 bytes (num_rendered) is the only host synchronisation. */
+ * read of 48 bytes (num_rendered, sort work-list sizes) is the only host synchronisation. */
 int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
                 int P, int D, int M,
                 const float* background, int width, int height,
