@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
+    ap.add_argument("--sync-exchange", action="store_true",
+                    help="N>1: wait for the gradient all-reduce at the end of every step (no overlap with the next render)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,13 +124,33 @@ def main():
     gpix, _ = scenes.l1_target_grad(image.cpu(), 20241022 + rank)
     gpix = gpix.to(dev)
 
+    # Software-pipelined exchange (N > 1): the all-reduce of step k is enqueued right behind its
+    # backward and only waited for when its gradient buffer is needed again (two buffers), so it
+    # overlaps the render of step k+1.  Every step still performs its full forward, backward and
+    # all-reduce, and all of them have completed when the timer stops.  --sync-exchange waits at
+    # the end of every step instead.
+    counter = [0]
+
     def step():
+        slot = counter[0] % 2
+        counter[0] += 1
         vpr.forward(cam_d, bg_d)
-        vpr.backward(gpix)       # writes straight into the flat gradient buffer
-        vpr.allreduce_grads()    # no-op at world size 1
+        if world > 1 and not args.sync_exchange:
+            vpr.wait_exchange(slot)          # the exchange launched two steps ago on this buffer
+        vpr.backward(gpix, slot)             # writes straight into the flat gradient buffer
+        if world > 1:
+            vpr.start_exchange(slot)
+            if args.sync_exchange:
+                vpr.wait_exchange(slot)
+
+    def drain():
+        if world > 1:
+            vpr.wait_exchange(0)
+            vpr.wait_exchange(1)
 
     for _ in range(args.warmup):
         step()
+    drain()
     stage_acc = {}
     if dist:
         dist.barrier()
@@ -140,6 +162,7 @@ def main():
             # hipEvent stage timers of this step (events only; no extra kernels)
             for k, v in _lib.stage_times().items():
                 stage_acc.setdefault(k, []).append(v)
+    drain()
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -165,6 +188,8 @@ def main():
             "config": {"workload": f"{args.config}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, "
                                    f"forward+backward, 1 view per GPU per step", "P": P, "visible": V,
                        "num_rendered": R, "tiles": T, "parallelism": f"view-parallel x{world}",
+                       "exchange": ("none" if world == 1 else "all-reduce, synchronous" if args.sync_exchange
+                                    else "all-reduce, overlapped with the next step's render (2 gradient buffers)"),
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"]},
             "op_hbm": {"algorithmic_bytes_per_view": total_bytes,
                        "achieved_GBps_per_gpu": total_bytes / (dt / args.steps) / 1e9,

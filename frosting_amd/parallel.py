@@ -44,12 +44,30 @@ class GradientExchange:
         return self.numel * 4
 
     def all_reduce(self):
+        """Blocking (stream-ordered) SUM over the group; returns the flat buffer."""
+        self.start()
+        return self.wait()
+
+    def start(self):
+        """Enqueue the all-reduce behind the work already on the current stream and return at
+        once (torch.distributed async_op): the collective runs on the backend's own stream, so
+        kernels enqueued afterwards on the compute stream overlap with it."""
         import torch.distributed as dist
+        self._work = None
         if self.group is None or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return self.flat
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        if self.average:
-            self.flat.mul_(1.0 / dist.get_world_size(self.group))
+            return None
+        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return self._work
+
+    def wait(self):
+        """Make the current stream (CPU backends: the caller) wait for the pending all-reduce."""
+        import torch.distributed as dist
+        work = getattr(self, "_work", None)
+        if work is not None:
+            work.wait()
+            self._work = None
+            if self.average:
+                self.flat.mul_(1.0 / dist.get_world_size(self.group))
         return self.flat
 
 
@@ -86,9 +104,11 @@ class ViewParallelRasterizer:
         self.scene = scene
         P, K = scene.means3D.shape[0], scene.shs.shape[1]
         self.P, self.K = P, K
-        self.exchange = GradientExchange(
-            dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3)),
-            self.dev, process_group, average)
+        shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
+        # two gradient buffers: the exchange of step k may still be in flight on the
+        # collective stream while step k+1 renders and writes the other buffer
+        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average) for _ in range(2)]
+        self.exchange = self.exchanges[0]
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.dev)
         # rank-local (not exchanged) backward outputs
         self.dL_dmeans2D, self.dL_dconic, self.dL_dcolors, self.dL_dcov3D = f(P, 3), f(P, 4), f(P, 3), f(P, 6)
@@ -118,11 +138,13 @@ class ViewParallelRasterizer:
         self._view = (cam, bg)
         return self.out_color, self.radii
 
-    def backward(self, dL_dimage):
+    def backward(self, dL_dimage, slot: int = 0):
+        """Gradients of the last forward, written in place into exchange buffer `slot`."""
         L = _lib.lib()
         s = self.scene
         cam, bg = self._view
         H, W = cam.image_height, cam.image_width
+        self.exchange = self.exchanges[slot]
         g = self.exchange.views
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
@@ -140,5 +162,15 @@ class ViewParallelRasterizer:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
         return g
 
-    def allreduce_grads(self):
-        return self.exchange.all_reduce()
+    def allreduce_grads(self, slot: int = 0):
+        """Synchronous form: SUM over ranks, stream-ordered."""
+        return self.exchanges[slot].all_reduce()
+
+    def start_exchange(self, slot: int):
+        """Launch the all-reduce of buffer `slot` behind its backward; returns immediately."""
+        return self.exchanges[slot].start()
+
+    def wait_exchange(self, slot: int):
+        """Order the current stream after the pending all-reduce of buffer `slot` (call before
+        reading its gradients or before the next backward that overwrites it)."""
+        return self.exchanges[slot].wait()

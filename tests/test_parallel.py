@@ -27,7 +27,13 @@ def _worker(rank, world, port, P, K, q):
     g = torch.Generator().manual_seed(100 + rank)
     for k in PARAM_ORDER:  # a rank-specific "per-view gradient"
         ex.views[k].copy_(torch.randn(shapes[k], generator=g))
-    ex.all_reduce()
+    if rank % 2:
+        ex.all_reduce()                      # synchronous form
+    else:
+        assert ex.start() is not None        # asynchronous form: start, do something else, wait
+        _ = torch.ones(10).sum()
+        ex.wait()
+    assert ex.wait() is ex.flat              # idempotent
     q.put((rank, {k: ex.views[k].numpy().copy() for k in PARAM_ORDER}))  # numpy: plain pickling
     dist.barrier()
     dist.destroy_process_group()
