@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
+    ap.add_argument("--exchange", default="factored", choices=["factored", "allreduce"],
+                    help="N>1: 'allreduce' = one all-reduce of all 59 floats per Gaussian; 'factored' = all-reduce of the "
+                         "11 non-SH floats + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
+                         "every rank (frosting_amd/parallel.py)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the exchange path on a single-rank RCCL group when launched without torch.distributed.run")
     ap.add_argument("--sync-exchange", action="store_true",
                     help="N>1: wait for the gradient all-reduce at the end of every step (no overlap with the next render)")
     args = ap.parse_args()
@@ -104,10 +110,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -116,7 +123,9 @@ def main():
     scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
     _lib.set_option("exact_blend", 1 if args.exact else 0)
     _lib.set_option("profile", 1)
-    vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD if dist else None)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD if dist else None,
+                                 factor_sh=(args.exchange == "factored"))
+    exchanging = dist is not None
     cam_d = cam.to(dev)
     bg_d = bg.to(dev)
 
@@ -135,16 +144,16 @@ def main():
         slot = counter[0] % 2
         counter[0] += 1
         vpr.forward(cam_d, bg_d)
-        if world > 1 and not args.sync_exchange:
+        if exchanging and not args.sync_exchange:
             vpr.wait_exchange(slot)          # the exchange launched two steps ago on this buffer
         vpr.backward(gpix, slot)             # writes straight into the flat gradient buffer
-        if world > 1:
+        if exchanging:
             vpr.start_exchange(slot)
             if args.sync_exchange:
                 vpr.wait_exchange(slot)
 
     def drain():
-        if world > 1:
+        if exchanging:
             vpr.wait_exchange(0)
             vpr.wait_exchange(1)
 
@@ -158,7 +167,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world == 1:
+        if not exchanging:
             # hipEvent stage timers of this step (events only; no extra kernels)
             for k, v in _lib.stage_times().items():
                 stage_acc.setdefault(k, []).append(v)
@@ -188,8 +197,13 @@ def main():
             "config": {"workload": f"{args.config}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, "
                                    f"forward+backward, 1 view per GPU per step", "P": P, "visible": V,
                        "num_rendered": R, "tiles": T, "parallelism": f"view-parallel x{world}",
-                       "exchange": ("none" if world == 1 else "all-reduce, synchronous" if args.sync_exchange
-                                    else "all-reduce, overlapped with the next step's render (2 gradient buffers)"),
+                       "exchange": ("none" if not exchanging else
+                                    ("all-reduce of 59 floats/Gaussian" if args.exchange == "allreduce" else
+                                     "factored: all-reduce of 11 floats/Gaussian + all-gather of dRGB (3 floats), "
+                                     "summed SH gradient rebuilt per rank") +
+                                    (", synchronous" if args.sync_exchange else
+                                     ", overlapped with the next step's render (2 gradient buffers)")),
+                       "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"]},
             "op_hbm": {"algorithmic_bytes_per_view": total_bytes,
                        "achieved_GBps_per_gpu": total_bytes / (dt / args.steps) / 1e9,

@@ -81,6 +81,10 @@ def lib():
     L.frg_mesh_raster_workspace_bytes.argtypes = [i, i, i]
     L.frg_mesh_rasterize.restype = i
     L.frg_mesh_rasterize.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
+    L.frg_sh_color_grad.restype = i
+    L.frg_sh_color_grad.argtypes = [i, vp, vp, vp, vp, vp]
+    L.frg_sh_grad_from_views.restype = i
+    L.frg_sh_grad_from_views.argtypes = [i, i, i, i, vp, vp, C.c_longlong, vp, C.c_longlong, vp, vp]
     _lib = L
     return L
 
@@ -111,5 +115,5 @@ EXPORTED_SYMBOLS = [
     "frg_version", "frg_last_error", "frg_mark_visible", "frg_forward", "frg_backward_workspace_bytes",
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
-    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize",
+    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_sh_color_grad", "frg_sh_grad_from_views",
 ]

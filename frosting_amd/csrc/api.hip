@@ -279,7 +279,7 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
         return fail(FRG_EINVAL, "null required pointer");
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
         return fail(FRG_EINVAL, "null gradient output");
-    if ((shs && !dL_dsh) || (scales && (!dL_dscale || !dL_drot || !rotations)))
+    if ((scales && (!dL_dscale || !dL_drot || !rotations)))
         return fail(FRG_EINVAL, "null gradient output for a provided input");
     if (workspace_bytes < frg_backward_workspace_bytes(P, R) || !workspace)
         return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_backward_workspace_bytes(P, R));
@@ -302,6 +302,30 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
     { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, stream), "preprocess_bwd"); }
+    return FRG_OK;
+}
+
+int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,
+                      float* out_drgb, void* hip_stream)
+{
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!geom_buffer || !radii || !dL_dcolors || !out_drgb) return fail(FRG_EINVAL, "null pointer");
+    const frg::GeomState g = frg::GeomState::carve(const_cast<char*>(geom_buffer), P);
+    FRG_HIP(frg::launch_sh_color_grad(P, g, radii, dL_dcolors, out_drgb, (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D,
+                           const float* campos, long long campos_stride,
+                           const float* drgb, long long view_stride, float* dL_dsh, void* hip_stream)
+{
+    if (P < 0 || n_views < 0 || D < 0 || D > 3) return fail(FRG_EINVAL, "bad sizes P=%d views=%d D=%d", P, n_views, D);
+    if (M < (D + 1) * (D + 1)) return fail(FRG_EINVAL, "degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
+    if (P == 0) return FRG_OK;
+    if (!means3D || !dL_dsh || (n_views > 0 && (!campos || !drgb))) return fail(FRG_EINVAL, "null pointer");
+    FRG_HIP(frg::launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, drgb, view_stride, dL_dsh,
+                                           (hipStream_t)hip_stream));
     return FRG_OK;
 }
 

@@ -35,4 +35,10 @@ struct BwdOutputs {
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, hipStream_t s);
 
+// view-parallel exchange helpers (view_exchange.hip)
+hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);
+hipError_t launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                                     long long campos_stride, const float* drgb, long long view_stride, float* dL_dsh,
+                                     hipStream_t s);
+
 }  // namespace frg

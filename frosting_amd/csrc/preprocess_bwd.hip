@@ -317,8 +317,11 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             dmean[1] += (-dox * doy * dd0 + (sum2 - doy * doy) * dd1 - doz * doy * dd2) * invsum32;
             dmean[2] += (-dox * doz * dd0 - doy * doz * dd1 + (sum2 - doz * doz) * dd2) * invsum32;
         }
-        // gradient rows: coefficients above the active degree and culled Gaussians are zero
-        if (SH16) {
+        // gradient rows: coefficients above the active degree and culled Gaussians are zero.
+        // dL_dsh == nullptr: the caller rebuilds the (summed) SH gradient from the colour gradient
+        // (view_exchange.hip) and the 192 B/Gaussian row is not materialised per view.
+        if (!dL_dsh) {
+        } else if (SH16) {
             float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)idx0 * 12;
             const int nvalid = min(64, P - idx0);
 #pragma unroll 1

@@ -364,16 +364,27 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
 struct SortStreams {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-    bool ok = false;
+    int device = -1;
     bool ensure()
     {
-        if (ok) return true;
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev == device) return true;
+        // first use on this thread, or the caller switched devices: (re)create on the current one
+        for (int i = 0; i < 2; i++) {
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+            if (join[i]) (void)hipEventDestroy(join[i]);
+            side[i] = nullptr; join[i] = nullptr;
+        }
+        if (fork) (void)hipEventDestroy(fork);
+        fork = nullptr;
+        device = -1;
         for (int i = 0; i < 2; i++) {
             if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return false;
             if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
         }
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-        ok = true;
+        device = dev;
         return true;
     }
 };

@@ -22,11 +22,37 @@ from . import _lib
 PARAM_ORDER = ("means3D", "scales", "rotations", "opacities", "shs")
 
 
-class GradientExchange:
-    """Flat fp32 gradient buffer with named per-parameter views and a single
-    all-reduce.  Backend-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
+def _hip_sh_reducer(ex: "GradientExchange"):
+    """dL_dsh <- sum over views of basis(mean - campos_v) (x) dRGB_v (frg_sh_grad_from_views)."""
+    if ex.flat.device.type != "cuda":
+        raise RuntimeError("the factored SH exchange rebuilds dL_dsh with a HIP kernel: gradients must live on the GPU "
+                           "(no CPU path; tests inject their own reducer)")
+    L = _lib.lib()
+    P, K = ex.shapes["shs"][0], ex.shapes["shs"][1]
+    stride = ex.gathered.shape[1]
+    stream = C.c_void_p(torch.cuda.current_stream(ex.flat.device).cuda_stream)
+    base = ex.gathered.data_ptr()
+    rc = L.frg_sh_grad_from_views(P, ex.sh_degree, K, ex.gathered.shape[0], _p(ex.means3D),
+                                  C.c_void_p(base + 4 * 3 * P), stride, C.c_void_p(base), stride,
+                                  _p(ex.views["shs"]), stream)
+    if rc < 0:
+        raise RuntimeError(f"frg_sh_grad_from_views failed ({rc}): {_lib.last_error()}")
 
-    def __init__(self, shapes: dict, device, process_group=None, average: bool = False):
+
+class GradientExchange:
+    """Flat fp32 gradient buffer with named per-parameter views.  Backend-agnostic (RCCL on
+    GPUs, gloo in the CPU tests).
+
+    Two exchange plans, both yielding the SUM over ranks of every per-Gaussian gradient:
+      * plain:    one all-reduce of the whole buffer (59 floats per Gaussian at SH degree 3);
+      * factored: the SH gradient of one view is rank one per Gaussian -- basis(view dir) (x) dRGB,
+        backward.cu:20-139 -- and the basis depends on replicated data only, so ranks all-gather
+        dRGB (3 floats) and all-reduce the 11 other floats, then rebuild sum_v dL_dsh_v locally
+        (csrc/view_exchange.hip).  2.6x fewer bytes over xGMI; identical on every rank and
+        independent of the collective's reduction order for the SH part."""
+
+    def __init__(self, shapes: dict, device, process_group=None, average: bool = False,
+                 factor_sh: bool = False, sh_reducer=None):
         self.shapes = {k: tuple(shapes[k]) for k in PARAM_ORDER if k in shapes}
         self.device = torch.device(device)
         self.group = process_group
@@ -38,10 +64,36 @@ class GradientExchange:
         for k, n in sizes.items():
             self.views[k] = self.flat[o:o + n].view(self.shapes[k])
             o += n
+        self.factor_sh = bool(factor_sh) and "shs" in self.shapes
+        self._works = []
+        if self.factor_sh:
+            # "shs" is last in PARAM_ORDER: the dense prefix is everything before it
+            self.dense = self.flat[: self.numel - sizes["shs"]]
+            P = self.shapes["shs"][0]
+            self.payload_numel = 3 * P + 4                  # dRGB[P,3], camera centre[3], pad
+            self.own = torch.zeros(self.payload_numel, dtype=torch.float32, device=self.device)
+            self.own_drgb = self.own[: 3 * P].view(P, 3)
+            self.own_campos = self.own[3 * P: 3 * P + 3]
+            self.gathered = None                            # [world, payload_numel], sized at first start()
+            self.sh_reducer = sh_reducer or _hip_sh_reducer
+            self.means3D, self.sh_degree = None, 0
+
+    def set_sh_context(self, means3D: torch.Tensor, sh_degree: int):
+        """Replicated inputs the SH rebuild needs (factored plan)."""
+        self.means3D, self.sh_degree = means3D, int(sh_degree)
 
     @property
     def nbytes(self) -> int:
         return self.numel * 4
+
+    @property
+    def wire_floats_per_rank(self) -> int:
+        """Floats each rank contributes to the collectives of one exchange."""
+        return (self.dense.numel() + self.payload_numel) if self.factor_sh else self.numel
+
+    def _active(self):
+        import torch.distributed as dist
+        return self.group is not None and dist.is_initialized()
 
     def all_reduce(self):
         """Blocking (stream-ordered) SUM over the group; returns the flat buffer."""
@@ -49,23 +101,35 @@ class GradientExchange:
         return self.wait()
 
     def start(self):
-        """Enqueue the all-reduce behind the work already on the current stream and return at
-        once (torch.distributed async_op): the collective runs on the backend's own stream, so
-        kernels enqueued afterwards on the compute stream overlap with it."""
+        """Enqueue the collectives behind the work already on the current stream and return at
+        once (torch.distributed async_op): they run on the backend's own stream, so kernels
+        enqueued afterwards on the compute stream overlap with them."""
         import torch.distributed as dist
-        self._work = None
-        if self.group is None or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        self._works = []
+        if not self._active():
             return None
-        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return self._work
+        if self.factor_sh:
+            world = dist.get_world_size(self.group)
+            if self.gathered is None or self.gathered.shape[0] != world:
+                self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
+            self._works.append(dist.all_gather_into_tensor(self.gathered.view(-1), self.own, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(self.dense, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return self._works
 
     def wait(self):
-        """Make the current stream (CPU backends: the caller) wait for the pending all-reduce."""
+        """Make the current stream (CPU backends: the caller) wait for the pending collectives;
+        in the factored plan, then rebuild the summed SH gradient on the current stream."""
         import torch.distributed as dist
-        work = getattr(self, "_work", None)
-        if work is not None:
-            work.wait()
-            self._work = None
+        if self._works:
+            for w in self._works:
+                w.wait()
+            self._works = []
+            if self.factor_sh:
+                if self.means3D is None:
+                    raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
+                self.sh_reducer(self)
             if self.average:
                 self.flat.mul_(1.0 / dist.get_world_size(self.group))
         return self.flat
@@ -99,7 +163,7 @@ class ViewParallelRasterizer:
     """Replicated scene + per-rank view render through the C ABI, gradients written
     in place into the flat exchange buffer (no copies, no zero-fill)."""
 
-    def __init__(self, scene, device, process_group=None, average: bool = False):
+    def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False):
         self.dev = torch.device(device)
         self.scene = scene
         P, K = scene.means3D.shape[0], scene.shs.shape[1]
@@ -107,7 +171,10 @@ class ViewParallelRasterizer:
         shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
         # two gradient buffers: the exchange of step k may still be in flight on the
         # collective stream while step k+1 renders and writes the other buffer
-        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average) for _ in range(2)]
+        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average, factor_sh=factor_sh) for _ in range(2)]
+        for ex in self.exchanges:
+            if ex.factor_sh:
+                ex.set_sh_context(scene.means3D, scene.sh_degree)
         self.exchange = self.exchanges[0]
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.dev)
         # rank-local (not exchanged) backward outputs
@@ -139,13 +206,17 @@ class ViewParallelRasterizer:
         return self.out_color, self.radii
 
     def backward(self, dL_dimage, slot: int = 0):
-        """Gradients of the last forward, written in place into exchange buffer `slot`."""
+        """Gradients of the last forward, written in place into exchange buffer `slot`.  In the
+        factored plan under a process group, views["shs"] is only valid after wait_exchange(slot)."""
         L = _lib.lib()
         s = self.scene
         cam, bg = self._view
         H, W = cam.image_height, cam.image_width
-        self.exchange = self.exchanges[slot]
-        g = self.exchange.views
+        self.exchange = ex = self.exchanges[slot]
+        g = ex.views
+        # factored plan with live collectives: the per-view SH rows are not materialised -- wait()
+        # rebuilds their sum over views from the exchanged colour gradients
+        defer_sh = ex.factor_sh and ex._active()
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -156,10 +227,16 @@ class ViewParallelRasterizer:
                             float(cam.tanfovx), float(cam.tanfovy), _p(self.radii),
                             _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
                             _p(self.dL_dmeans2D), _p(self.dL_dconic), _p(g["opacities"]), _p(self.dL_dcolors),
-                            _p(g["means3D"]), _p(self.dL_dcov3D), _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
+                            _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
                             _p(work), work.numel(), 0, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
+        if ex.factor_sh:
+            # this view's share of the factored SH exchange: masked colour gradient + camera centre
+            rc = L.frg_sh_color_grad(self.P, _p(self.geom.buf), _p(self.radii), _p(self.dL_dcolors), _p(ex.own_drgb), stream)
+            if rc < 0:
+                raise RuntimeError(f"frg_sh_color_grad failed ({rc}): {_lib.last_error()}")
+            ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
         return g
 
     def allreduce_grads(self, slot: int = 0):

@@ -80,7 +80,9 @@ size_t frg_backward_workspace_bytes(int P, int R);
  * rasterize_points.cu:151-159).  dL_dmean2D is [P,3] (z stays 0), dL_dconic
  * [P,4] = (a, b, -, c), dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3],
  * dL_dcov3D [P,6], dL_dsh [P,M,3] (ignored when shs==NULL), dL_dscale [P,3],
- * dL_drot [P,4] (ignored when scales==NULL).  Summation order is fixed, so
+ * dL_drot [P,4] (ignored when scales==NULL).  dL_dsh may be NULL with shs given: the
+ * SH row is then not materialised (its view-direction term still reaches dL_dmean3D) and
+ * the caller rebuilds it from dL_dcolor -- frg_sh_color_grad / frg_sh_grad_from_views below.  Summation order is fixed, so
  * results are bit-reproducible run to run (the reference's atomics are not). */
 int frg_backward(int P, int D, int M, int R,
                  const float* background, int width, int height,
@@ -141,6 +143,24 @@ void frg_binning_layout(int R, int max_tile_count, long long* out);
 size_t frg_mesh_raster_workspace_bytes(int F, int width, int height);
 int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width, int height,
                        float* rast, char* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ---- view-parallel gradient exchange helpers ---------------------------------------
+ * No counterpart in the (single-GPU) reference; SURVEY.md 8(e).  The per-view SH gradient
+ * is rank one per Gaussian, dL_dsh_v[i][ch] = basis_i(normalize(mean - campos_v)) * dRGB_v[ch]
+ * (backward.cu:20-139), with dRGB_v the colour gradient after the clamp mask (backward.cu:31-34),
+ * so ranks exchange dRGB (3 floats) instead of dL_dsh (3*M floats) and rebuild the summed
+ * SH gradient locally, term by term bit-identical to the per-view kernels.
+ *
+ * frg_sh_color_grad: out_drgb[P,3] = dL_dcolors * (clamped ? 0 : 1) using the clamp flags the
+ * forward left in geom_buffer; rows with radii <= 0 are zero.
+ * frg_sh_grad_from_views: dL_dsh[P,M,3] = sum_{v < n_views} basis(D, mean - campos_v) (x) drgb_v,
+ * summed in view order; campos_v = campos + v*campos_stride, drgb_v = drgb + v*view_stride
+ * (strides in floats).  Coefficients >= (D+1)^2 are written as zeros. */
+int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,
+                      float* out_drgb, void* hip_stream);
+int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D,
+                           const float* campos, long long campos_stride,
+                           const float* drgb, long long view_stride, float* dL_dsh, void* hip_stream);
 
 #ifdef __cplusplus
 }

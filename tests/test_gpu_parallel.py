@@ -1,0 +1,112 @@
+"""View-parallel path on one GPU: the factored SH exchange (csrc/view_exchange.hip) against the
+plain sum of per-view gradients, and the collective plumbing on a single-rank RCCL group."""
+import os
+import socket
+
+import pytest
+import torch
+
+from frosting_amd import scenes
+from frosting_amd.parallel import GradientExchange, ViewParallelRasterizer, PARAM_ORDER
+
+pytestmark = pytest.mark.gpu
+
+K_SH0 = 0.28209479177387814
+
+
+def _per_view(vpr, name, views, dev, P=None):
+    """Render `views` one after the other; per-view gradients and exchange payloads."""
+    grads, payloads = [], []
+    for k in views:
+        scene, cam, bg = scenes.config_scene(name, k, P=P)
+        img, _ = vpr.forward(cam.to(dev), bg.to(dev))
+        gpix, _ = scenes.l1_target_grad(img.cpu(), 555 + k)
+        g = vpr.backward(gpix.to(dev), 0)
+        grads.append({n: g[n].clone() for n in PARAM_ORDER})
+        payloads.append(vpr.exchange.own.clone())
+    return grads, payloads
+
+
+@pytest.mark.parametrize("P", [5000, 4807])
+def test_rebuilt_sh_gradient_is_the_sum_of_view_gradients_bit_exact(gpu_device, P):
+    dev = gpu_device
+    scene, _, _ = scenes.config_scene("mini", 0, P=P)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, factor_sh=True)
+    views = [0, 3, 5, 6]
+    grads, payloads = _per_view(vpr, "mini", views, dev, P=P)
+    ex = vpr.exchange
+    # the payload's colour gradient is the masked one: DC coefficient = kSH0 * dRGB (backward.cu:36-38)
+    for g, pay in zip(grads, payloads):
+        drgb = pay[: 3 * P].view(P, 3)
+        assert torch.equal(drgb * K_SH0, g["shs"][:, 0, :])
+        assert (drgb != 0).any()
+    ex.gathered = torch.stack(payloads)
+    ex.sh_reducer(ex)                               # HIP: frg_sh_grad_from_views
+    want = grads[0]["shs"].clone()
+    for g in grads[1:]:
+        want = want + g["shs"]                      # view order, like the kernel
+    got = ex.views["shs"]
+    assert torch.equal(got, want)
+    assert float(want.abs().max()) > 0
+
+
+def test_rebuild_lower_degree_and_zero_views(gpu_device):
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("mini", 0, P=3000)
+    scene.sh_degree = 1
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, factor_sh=True)
+    img, _ = vpr.forward(cam.to(dev), bg.to(dev))
+    gpix, _ = scenes.l1_target_grad(img.cpu(), 9)
+    g = vpr.backward(gpix.to(dev), 0)
+    want = g["shs"].clone()
+    assert float(want[:, 4:].abs().max()) == 0.0 and float(want[:, 1:4].abs().max()) > 0
+    ex = vpr.exchange
+    ex.gathered = ex.own.clone()[None]
+    ex.views["shs"].fill_(123.0)
+    ex.sh_reducer(ex)
+    assert torch.equal(ex.views["shs"], want)
+    ex.gathered = ex.gathered[:0]                    # no views: all zeros
+    ex.sh_reducer(ex)
+    assert float(ex.views["shs"].abs().max()) == 0.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
+    """Both exchange plans through RCCL (world size 1): the collectives run, the pipelined
+    start/wait protocol works on HIP streams and a 1-rank sum is the view's own gradient."""
+    import torch.distributed as dist
+    dev = gpu_device
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        scene, cam, bg = scenes.config_scene("mini", 2, P=6000)
+        ref = None
+        for factored in (False, True):
+            vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored)
+            img, _ = vpr.forward(cam.to(dev), bg.to(dev))
+            gpix, _ = scenes.l1_target_grad(img.cpu(), 77)
+            gpix = gpix.to(dev)
+            for step in range(4):                    # two buffers, exchange of step k waited at step k+2
+                slot = step % 2
+                vpr.forward(cam.to(dev), bg.to(dev))
+                vpr.wait_exchange(slot)
+                vpr.backward(gpix, slot)
+                assert vpr.start_exchange(slot) is not None
+            outs = [vpr.wait_exchange(s).clone() for s in (0, 1)]
+            torch.cuda.synchronize(dev)
+            assert torch.equal(outs[0], outs[1])
+            if ref is None:
+                ref = outs[0]
+            else:
+                assert torch.equal(outs[0], ref)     # factored == plain, bit for bit, at one view
+            assert float(ref.abs().max()) > 0
+    finally:
+        dist.destroy_process_group()

@@ -70,3 +70,93 @@ def test_allreduce_sums_per_view_gradients_gloo():
     for r in range(world):
         for k in PARAM_ORDER:
             torch.testing.assert_close(torch.from_numpy(res[r][k]), expect[k], rtol=1e-6, atol=1e-6)
+
+
+# ---- factored SH exchange: all-gather of dRGB + all-reduce of the 11 dense floats ----------------
+
+def torch_sh_reducer(ex):
+    """Test-side stand-in for csrc/view_exchange.hip (the product reducer is HIP-only)."""
+    from frosting_amd.sh import sh_basis
+    P, K = ex.shapes["shs"][:2]
+    out = torch.zeros(P, K, 3)
+    for v in range(ex.gathered.shape[0]):
+        row = ex.gathered[v]
+        drgb, campos = row[: 3 * P].view(P, 3), row[3 * P: 3 * P + 3]
+        d = ex.means3D - campos
+        basis = sh_basis(ex.sh_degree, d / d.norm(dim=1, keepdim=True))
+        out[:, : basis.shape[1]] += basis[:, :, None] * drgb[:, None, :]
+    ex.views["shs"].copy_(out)
+
+
+def _view_inputs(rank, P, K, deg):
+    """Per-view gradient of rank `rank`: random dense part, rank-one SH part."""
+    from frosting_amd.sh import sh_basis
+    g = torch.Generator().manual_seed(7)
+    means = torch.randn(P, 3, generator=g)
+    g = torch.Generator().manual_seed(200 + rank)
+    campos = 4.0 * torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0)
+    drgb = torch.randn(P, 3, generator=g)
+    drgb[torch.rand(P, generator=g) < 0.3] = 0.0            # culled / clamped rows
+    dense = {k: torch.randn(s, generator=g) for k, s in
+             dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1)).items()}
+    d = means - campos
+    basis = sh_basis(deg, d / d.norm(dim=1, keepdim=True))
+    shs = torch.zeros(P, K, 3)
+    shs[:, : basis.shape[1]] = basis[:, :, None] * drgb[:, None, :]
+    return means, campos, drgb, dense, shs
+
+
+def _factored_worker(rank, world, port, P, K, deg, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
+    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=True, sh_reducer=torch_sh_reducer)
+    means, campos, drgb, dense, shs = _view_inputs(rank, P, K, deg)
+    ex.set_sh_context(means, deg)
+    for k, v in dense.items():
+        ex.views[k].copy_(v)
+    ex.views["shs"].copy_(shs)                   # what the backward leaves there; replaced by the rebuild
+    ex.own_drgb.copy_(drgb)
+    ex.own_campos.copy_(campos)
+    assert ex.wire_floats_per_rank == 11 * P + 3 * P + 4
+    ex.start()
+    ex.wait()
+    q.put((rank, {k: ex.views[k].numpy().copy() for k in PARAM_ORDER}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("deg,K", [(3, 16), (1, 16)])
+def test_factored_sh_exchange_equals_sum_of_view_gradients_gloo(deg, K):
+    world, P = 2, 193
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, P, K, deg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    expect = None
+    for r in range(world):
+        _, _, _, dense, shs = _view_inputs(r, P, K, deg)
+        cur = dict(dense, shs=shs)
+        expect = cur if expect is None else {k: expect[k] + cur[k] for k in cur}
+    for r in range(world):
+        for k in PARAM_ORDER:
+            torch.testing.assert_close(torch.from_numpy(res[r][k]), expect[k], rtol=1e-6, atol=1e-6)
+    assert (res[0]["shs"] == res[1]["shs"]).all()          # rebuilt identically on every rank
+
+
+def test_factored_exchange_needs_gpu_reducer():
+    ex = GradientExchange(dict(means3D=(4, 3), scales=(4, 3), rotations=(4, 4), opacities=(4, 1), shs=(4, 16, 3)),
+                          "cpu", factor_sh=True)
+    ex.set_sh_context(torch.zeros(4, 3), 3)
+    ex.gathered = torch.zeros(1, ex.payload_numel)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ex.sh_reducer(ex)
