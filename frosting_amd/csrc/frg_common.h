@@ -11,7 +11,7 @@
 #define FRG_NUM_XCD 8
 #define FRG_SLOT_FLOATS 9   // per-instance backward partial: rgb(3) mean2D(2) conic(3) opacity(1)
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
-#define FRG_BIN_MAX_BLOCKS 512   // rows of the (workgroup x tile) count matrix
+#define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
 #define FRG_BIN_SEGS 8           // row segments of the column scan
 #define FRG_BIN_MAX_LDS_TILES 20480  // T*4 bytes of LDS bins beside 53 KiB of SH staging and the scan scratch (160 KiB/CU)
 
@@ -62,6 +62,17 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
 __host__ __device__ inline int sort_class_of(uint32_t n)
 {
     return n <= 512 ? 0 : n <= 2048 ? 1 : n <= 4096 ? 2 : n <= 8192 ? 3 : 4;
+}
+
+// class * 8 + bucket, bucket 0 = the longest eighth of the class's size range
+__host__ __device__ inline int sort_subclass_of(uint32_t n)
+{
+    const int cls = sort_class_of(n);
+    const uint32_t lo = cls == 0 ? 0u : cls == 1 ? 512u : cls == 2 ? 2048u : cls == 3 ? 4096u : 8192u;
+    const uint32_t span = cls == 0 ? 512u : cls == 1 ? 1536u : cls == 2 ? 2048u : cls == 3 ? 4096u : 65536u;
+    uint32_t k = (n - lo - 1u) * 8u / span;
+    if (k > 7u) k = 7u;
+    return cls * 8 + (7 - (int)k);
 }
 
 struct ImageState {

@@ -303,11 +303,12 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    const int per = (nrows + FRG_BIN_SEGS - 1) / FRG_BIN_SEGS;
-    const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+    // segment s = the workgroups the dispatcher places on XCD s (round robin, FRG_BIN_SEGS == 8):
+    // a tile's runs written by one XCD are then adjacent in memory, so partially written lines
+    // are completed inside that XCD's L2 instead of being written back piecemeal by eight L2s
     uint32_t s = 0;
 #pragma unroll 8
-    for (int r = r0; r < r1; r++) s += bin_matrix[(size_t)r * T + t];
+    for (int r = blockIdx.y; r < nrows; r += FRG_BIN_SEGS) s += bin_matrix[(size_t)r * T + t];
     seg_sums[(size_t)blockIdx.y * T + t] = s;
 }
 
@@ -325,9 +326,11 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
     __shared__ uint32_t carry_s;
     __shared__ uint32_t maxc_s;
     __shared__ uint32_t cls_s[FRG_SORT_CLASSES];
+    __shared__ uint32_t sub_s[FRG_SORT_CLASSES * 8], sub_cur[FRG_SORT_CLASSES * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { carry_s = 0; maxc_s = 0; }
     if (tid < FRG_SORT_CLASSES) cls_s[tid] = 0;
+    if (tid < FRG_SORT_CLASSES * 8) { sub_s[tid] = 0; sub_cur[tid] = 0; }
     __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
         const int n = pass == 0 ? nchunks : T;
@@ -355,10 +358,7 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
                 if (pass == 0) block_sums[i] = excl;
                 else {
                     ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
-                    if (v) {  // work list of the sort: only non-empty tiles, grouped by size class
-                        const int cls = sort_class_of(v);
-                        class_tiles[(size_t)cls * T + atomicAdd(&cls_s[cls], 1u)] = (uint32_t)i;
-                    }
+                    if (v) atomicAdd(&sub_s[sort_subclass_of(v)], 1u);
                     if (use_segs) {  // segment s of tile i starts at excl + sum of earlier segments
                         uint32_t run = excl;
 #pragma unroll
@@ -381,6 +381,21 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
         }
         __syncthreads();
     }
+    // work lists of the sort: only non-empty tiles, grouped by size class and, inside a class,
+    // by size in eight descending buckets (longest tiles are dispatched first: the last round of
+    // workgroups then holds the short ones instead of a straggler)
+    if (tid < FRG_SORT_CLASSES) {
+        uint32_t run = 0;
+        for (int k = 0; k < 8; k++) { const uint32_t c = sub_s[tid * 8 + k]; sub_s[tid * 8 + k] = run; run += c; }
+        cls_s[tid] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) {
+        const uint32_t v = tile_count[i];
+        if (!v) continue;
+        const int key = sort_subclass_of(v);
+        class_tiles[(size_t)(key >> 3) * T + sub_s[key] + atomicAdd(&sub_cur[key], 1u)] = (uint32_t)i;
+    }
     if (tid == 0) counters->max_tile_count = maxc_s;
     if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = cls_s[tid];
 }
@@ -392,11 +407,9 @@ colbase_kernel(int T, int nrows, uint32_t* __restrict__ bin_matrix, const uint32
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    const int per = (nrows + FRG_BIN_SEGS - 1) / FRG_BIN_SEGS;
-    const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
     uint32_t run = seg_start[(size_t)blockIdx.y * T + t];
 #pragma unroll 8
-    for (int r = r0; r < r1; r++) {
+    for (int r = blockIdx.y; r < nrows; r += FRG_BIN_SEGS) {
         const uint32_t c = bin_matrix[(size_t)r * T + t];
         bin_matrix[(size_t)r * T + t] = run;
         run += c;

@@ -172,13 +172,11 @@ __device__ __forceinline__ PtrT sort_segment(PtrT src, PtrT dst, int n, uint32_t
 }
 
 // ---- LDS classes: register-staged, in-place passes --------------------------------
-// Each thread owns at most 8 elements of its wave's contiguous strip (CAP = 8 * threads).
+// Each thread owns CAP / threads (8 or 16) elements of its wave's contiguous strip.
 // A pass ranks them from REGISTERS (no LDS reads of the data), scatters them into the
 // single LDS buffer and reloads its strip: one 8-byte buffer instead of a ping-pong pair,
 // so twice the workgroups fit per CU and different size classes can share a CU.
-#define SORT_ITEMS 8
-
-template <int NWAVES, bool BY_INDEX>
+template <int NWAVES, int SORT_ITEMS, bool BY_INDEX>
 __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, int begin, int end, int shift,
                                                 uint2* buf, uint32_t* whist, uint32_t* scratch)
 {
@@ -266,7 +264,8 @@ __global__ void __launch_bounds__(NWAVES * 64)
 sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __restrict__ ranges,
                       const uint2* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
-    static_assert(CAP == NWAVES * 64 * SORT_ITEMS, "each thread stages SORT_ITEMS elements");
+    constexpr int SORT_ITEMS = CAP / (NWAVES * 64);   // elements staged per thread
+    static_assert(CAP == NWAVES * 64 * SORT_ITEMS && SORT_ITEMS >= 1, "CAP must be a multiple of the workgroup size");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* buf = reinterpret_cast<uint2*>(smem);
     uint32_t* whist = reinterpret_cast<uint32_t*>(buf + CAP);
@@ -277,7 +276,7 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __res
     if (n > CAP) return;
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 512
+    // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 64 * SORT_ITEMS
     const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
     const int begin = wave * strip, end = min(n, begin + strip);
     uint2 e[SORT_ITEMS];
@@ -292,7 +291,7 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __res
     if (n > 1) {
 #pragma unroll 1
         for (int pass = 0; pass < 4; pass++)
-            in_lds |= radix_pass_regs<NWAVES, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+            in_lds |= radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
     }
     if (!in_lds) {   // nothing moved (n == 1 or all keys equal): materialise the strip for the steps below
 #pragma unroll
@@ -308,9 +307,9 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __res
             // many equal depths (coplanar scenes): order by index, then by depth again -- LSD
             // stability turns that into (depth, index)
 #pragma unroll 1
-            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
 #pragma unroll 1
-            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
         } else if (ties > 0) {
             fix_ties<uint2*>(buf, n, NT);
         }
@@ -406,14 +405,16 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
         if (c2 && (e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
         if ((c3 + c4) && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
     }
-    // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 16 waves,
+    // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 8 waves x 16 elements,
     // >8192 global ping-pong; longest-running classes first
     if (c4) {
         if (!pairs_tmp) return hipErrorInvalidValue;
         hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(c4), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, ranges, pairs, pairs_tmp, point_list);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if ((e = launch_lds_class<16, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, ranges, pairs, point_list, s2)) != hipSuccess) return e;
+    // (4096,8192]: 8 waves x 16 staged elements rather than 16 x 8 -- two workgroups fit a CU and
+    // one's barrier stalls overlap the other's ranking (0.286 -> 0.256 ms at C3)
+    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, ranges, pairs, point_list, s2)) != hipSuccess) return e;
     if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, ranges, pairs, point_list, s1)) != hipSuccess) return e;
     if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, ranges, pairs, point_list, stream)) != hipSuccess) return e;
     if ((e = launch_lds_class<1, 512>(c0, class_tiles, ranges, pairs, point_list, stream)) != hipSuccess) return e;
