@@ -197,18 +197,19 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
-    __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
-    if (LDS_BINS) {
-        for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = 0;
-        __syncthreads();
-    }
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    if (LDS_BINS)
+        for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = 0;
+    // the chunk totals of this workgroup's chunks are accumulated with atomics below
+    for (int c = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; c < nchunks; c += FRG_BIN_THREADS * (int)gridDim.x) block_sums[c] = 0;
+    __threadfence_block();
+    __syncthreads();
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int idx = c * FRG_BIN_THREADS + threadIdx.x;
         uint32_t touched = 0;
@@ -251,14 +252,34 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 const int nvalid = min(64, P - idx0);
                 const bool wave_needs = __ballot(touched != 0) != 0ull;
                 if (wave_needs) {
+                    // sub-batches that hold a visible Gaussian (wave-uniform 4-bit mask)
+                    const uint64_t vis = __ballot(touched != 0);
+                    uint32_t need = 0;
+#pragma unroll
+                    for (int h = 0; h < 64 / PRE_SUB; h++)
+                        if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
+                    // software pipeline: the loads of the next needed sub-batch are in flight while
+                    // the current one is consumed (registers pre[] -> LDS -> per-lane rows)
+                    float4 pre[PRE_SUB * 12 / 64];
+                    auto issue = [&](int h) {
+#pragma unroll
+                        for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
+                            const int f = k * 64 + lane, gl = f / 12;
+                            pre[k] = (h * PRE_SUB + gl < nvalid) ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    };
+                    int h = __builtin_ctz(need);
+                    issue(h);
 #pragma unroll 1
-                    for (int h = 0; h < 64 / PRE_SUB; h++) {
-                        if ((__ballot(touched != 0) & (0xFFFFull << (h * PRE_SUB))) == 0ull) continue;  // none visible
+                    while (h < 64 / PRE_SUB) {
 #pragma unroll
                         for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
                             const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                            if (h * PRE_SUB + gl < nvalid) shbuf[gl * PRE_ROW_F4 + j] = src[(size_t)h * PRE_SUB * 12 + f];
+                            shbuf[gl * PRE_ROW_F4 + j] = pre[k];
                         }
+                        const uint32_t rest = need >> (h + 1);
+                        const int hn = rest ? h + 1 + __builtin_ctz(rest) : 64 / PRE_SUB;
+                        if (hn < 64 / PRE_SUB) issue(hn);
                         wave_sync_lds();
                         if ((lane / PRE_SUB) == h && touched) {
 #pragma unroll
@@ -273,6 +294,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                             }
                         }
                         wave_sync_lds();
+                        h = hn;
                     }
                 }
             } else if (touched) {
@@ -285,9 +307,11 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             }
             if (touched) rgb_clamped[idx] = sa.finish();
         }
-        uint32_t total;
-        block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
-        if (threadIdx.x == 0) block_sums[c] = total;
+        // chunk total: one atomic per wave into this workgroup's own (pre-zeroed) entry.  No
+        // workgroup barrier in the chunk loop: the 16 waves drift apart, so one wave's SH
+        // streaming overlaps another's covariance math instead of all waves changing phase together.
+        const uint32_t wtotal = wave_incl_scan(touched, threadIdx.x & 63);
+        if ((threadIdx.x & 63) == 63 && wtotal) atomicAdd(&block_sums[c], wtotal);
     }
     if (LDS_BINS) {
         __syncthreads();

@@ -38,7 +38,7 @@ __device__ __forceinline__ void wave_fence()
 }
 
 template <bool SH16>
-__global__ void __launch_bounds__(BWD_THREADS, 5)
+__global__ void __launch_bounds__(BWD_THREADS, 4)
 preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                       const float* __restrict__ means3D, const int* __restrict__ radii,
@@ -88,16 +88,17 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
     for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
     wave_fence();
-    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+    // one batch = 64 consecutive slots of the wave's run, one per lane: owner by binary search
+    // (own_start / own_info do not change inside the loop), cutoff test, then the 36-byte row
+    auto fetch = [&](uint32_t s0, int& owner, bool& in_run, float (&part)[FRG_SLOT_FLOATS]) {
         const uint32_t s = s0 + lane;
-        const bool in_run = s < S;
-        int owner = 0;
+        in_run = s < S;
+        owner = 0;
 #pragma unroll
         for (int step = 32; step >= 1; step >>= 1) {
             const int mid = owner + step;
             if (mid < 64 && own_start[mid] <= s) owner = mid;
         }
-        float part[FRG_SLOT_FLOATS];
 #pragma unroll
         for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
         if (in_run) {
@@ -116,6 +117,19 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         } else {
             owner = 64 + lane;  // unique: never merges with a neighbour
         }
+    };
+    // software pipeline: the next batch's cutoff and slot loads are in flight during the scan
+    int owner_n = 0;
+    bool in_run_n = false;
+    float part_n[FRG_SLOT_FLOATS];
+    if (S > 0) fetch(0, owner_n, in_run_n, part_n);
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        int owner = owner_n;
+        const bool in_run = in_run_n;
+        float part[FRG_SLOT_FLOATS];
+#pragma unroll
+        for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = part_n[c];
+        if (s0 + 64 < S) fetch(s0 + 64, owner_n, in_run_n, part_n);
         // segmented inclusive scan over lanes (owners are non-decreasing with the lane)
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -280,13 +294,24 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             // transposed through LDS 16 Gaussians at a time and consumed as they arrive
             const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
             const int nvalid = min(64, P - idx0);
+            // software pipeline: sub-batch h + 1 is in flight while sub-batch h is consumed
+            float4 pre[BWD_SUB * 12 / 64];
+            auto issue = [&](int h) {
+#pragma unroll
+                for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
+                    const int f = k * 64 + lane, gl = f / 12;
+                    pre[k] = (h * BWD_SUB + gl < nvalid) ? src[(size_t)h * BWD_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            issue(0);
 #pragma unroll 1
             for (int h = 0; h < 64 / BWD_SUB; h++) {
 #pragma unroll
                 for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
                     const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                    if (h * BWD_SUB + gl < nvalid) shbuf[gl * BWD_ROW_F4 + j] = src[(size_t)h * BWD_SUB * 12 + f];
+                    shbuf[gl * BWD_ROW_F4 + j] = pre[k];
                 }
+                if (h + 1 < 64 / BWD_SUB) issue(h + 1);
                 wave_fence();
                 if ((lane / BWD_SUB) == h && visible) {
 #pragma unroll
