@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
+    ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
+    ap.add_argument("--deferred-counters", action="store_true",
+                    help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
+                         "which like the reference blocks on a read-back of num_rendered; measured equal at C3")
     ap.add_argument("--exchange", default="factored", choices=["factored", "allreduce"],
                     help="N>1: 'allreduce' = one all-reduce of all 59 floats per Gaussian; 'factored' = all-reduce of the "
                          "11 non-SH floats + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
@@ -122,9 +126,9 @@ def main():
     P = args.points or cfg["P"]
     scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
     _lib.set_option("exact_blend", 1 if args.exact else 0)
-    _lib.set_option("profile", 1)
+    _lib.set_option("profile", 0 if args.no_stage_timers else 1)
     vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD if dist else None,
-                                 factor_sh=(args.exchange == "factored"))
+                                 factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters)
     exchanging = dist is not None
     cam_d = cam.to(dev)
     bg_d = bg.to(dev)
@@ -147,6 +151,9 @@ def main():
         if exchanging and not args.sync_exchange:
             vpr.wait_exchange(slot)          # the exchange launched two steps ago on this buffer
         vpr.backward(gpix, slot)             # writes straight into the flat gradient buffer
+        if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
+            vpr.forward(cam_d, bg_d, deferred=False)
+            vpr.backward(gpix, slot)
         if exchanging:
             vpr.start_exchange(slot)
             if args.sync_exchange:
@@ -160,22 +167,21 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    stage_acc = {}
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    _lib.stage_times()                       # discard the warm-up launches' events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if not exchanging:
-            # hipEvent stage timers of this step (events only; no extra kernels)
-            for k, v in _lib.stage_times().items():
-                stage_acc.setdefault(k, []).append(v)
     drain()
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # hipEvents around every kernel stage of the timed steps (recorded on the launch stream by the
+    # C ABI, read only now): average duration per launch over the timed region
+    stage_avg = {k: v for k, v in _lib.stage_times().items() if v > 0}
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -185,7 +191,7 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         views_per_s = world * args.steps / dt
         V = int((radii > 0).sum())
-        R = int(vpr.num_rendered)
+        R = int(vpr.true_num_rendered)
         N = cam.image_width * cam.image_height
         T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
         B = stage_bytes(P, V, R, N, T)
@@ -204,13 +210,15 @@ def main():
                                     (", synchronous" if args.sync_exchange else
                                      ", overlapped with the next step's render (2 gradient buffers)")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
-                       "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"]},
+                       "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"],
+                       "counters": "deferred (no host synchronisation inside the step)" if args.deferred_counters
+                                   else "blocking 48-byte read-back per forward"},
             "op_hbm": {"algorithmic_bytes_per_view": total_bytes,
                        "achieved_GBps_per_gpu": total_bytes / (dt / args.steps) / 1e9,
                        "frac_of_8TBps": total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
-        if stage_acc:
-            avg = {k: float(np.mean(v)) for k, v in stage_acc.items() if np.mean(v) > 0}
+        if stage_avg:
+            avg = stage_avg
             dom = max(avg, key=avg.get)
             ach = B[dom] / (avg[dom] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

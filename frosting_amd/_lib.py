@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libfrosting_rasterizer.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+ECAPACITY = -5
 
 _lib = None
 
@@ -65,6 +66,10 @@ def lib():
                               vp, vp, vp,
                               f, f, i,
                               vp, vp, i, vp]
+    L.frg_forward_deferred.restype = i
+    L.frg_forward_deferred.argtypes = list(L.frg_forward.argtypes)   # `debug` slot carries instance_capacity
+    L.frg_forward_finish.restype = i
+    L.frg_forward_finish.argtypes = [vp, i, C.POINTER(C.c_int)]
     L.frg_backward.restype = i
     L.frg_backward.argtypes = [i, i, i, i, vp, i, i,
                                vp, vp, vp,
@@ -116,4 +121,5 @@ EXPORTED_SYMBOLS = [
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_sh_color_grad", "frg_sh_grad_from_views",
+    "frg_forward_deferred", "frg_forward_finish",
 ]

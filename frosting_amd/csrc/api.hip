@@ -34,28 +34,43 @@ std::atomic<int> g_global_bins{0};  // test hook: force the large-image (global-
 // recorded on the caller's stream between the kernels of one forward / backward;
 // frg_stage_times() synchronises and returns the elapsed milliseconds.
 enum { ST_PREPROCESS = 0, ST_SCAN, ST_SCATTER, ST_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+// Event pairs are kept for the last ST_SLOTS launches of every stage and only read (and
+// synchronised on) by frg_stage_times(), so timing a run of steps does not serialise them.
+constexpr int ST_SLOTS = 64;
 struct StageTimers {
-    hipEvent_t ev[ST_COUNT][2];
-    bool used[ST_COUNT];
+    hipEvent_t ev[ST_COUNT][ST_SLOTS][2];
+    unsigned launches[ST_COUNT];
     bool init = false;
-    void ensure()
+    int device = -1;
+    bool ensure()
     {
-        if (init) return;
-        for (int i = 0; i < ST_COUNT; i++) { (void)hipEventCreate(&ev[i][0]); (void)hipEventCreate(&ev[i][1]); used[i] = false; }
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (init && dev == device) return true;
+        if (init)
+            for (int i = 0; i < ST_COUNT; i++)
+                for (int k = 0; k < ST_SLOTS; k++) { (void)hipEventDestroy(ev[i][k][0]); (void)hipEventDestroy(ev[i][k][1]); }
+        for (int i = 0; i < ST_COUNT; i++) {
+            for (int k = 0; k < ST_SLOTS; k++) { (void)hipEventCreate(&ev[i][k][0]); (void)hipEventCreate(&ev[i][k][1]); }
+            launches[i] = 0;
+        }
         init = true;
+        device = dev;
+        return true;
     }
 };
 thread_local StageTimers g_timers;
 
 struct StageScope {
-    int id; hipStream_t s; bool on;
-    StageScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile.load() != 0)
+    int id; hipStream_t s; bool on; int slot;
+    StageScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile.load() != 0), slot(0)
     {
-        if (on) { g_timers.ensure(); (void)hipEventRecord(g_timers.ev[id][0], s); }
+        if (on && !g_timers.ensure()) on = false;
+        if (on) { slot = (int)(g_timers.launches[id] % ST_SLOTS); (void)hipEventRecord(g_timers.ev[id][slot][0], s); }
     }
     ~StageScope()
     {
-        if (on) { (void)hipEventRecord(g_timers.ev[id][1], s); g_timers.used[id] = true; }
+        if (on) { (void)hipEventRecord(g_timers.ev[id][slot][1], s); g_timers.launches[id]++; }
     }
 };
 
@@ -79,6 +94,49 @@ frg::Counters* pinned_counters()
     }
     return p;
 }
+
+// Deferred-counters forward: the counters of each outstanding forward land in a pinned slot
+// behind an event; frg_forward_finish() waits on that event only (not on the whole stream).
+struct PendingCounters {
+    frg::Counters* host = nullptr;     // pinned
+    hipEvent_t ev = nullptr;           // counters have landed in `host`
+    hipEvent_t scanned = nullptr;      // scan finished on the caller's stream
+    hipStream_t copy_stream = nullptr; // carries the 48-byte read-back off the caller's stream
+    const void* key = nullptr;      // image buffer of the forward
+    int device = -1;
+};
+constexpr int kPendingSlots = 8;
+struct PendingRing {
+    PendingCounters slot[kPendingSlots];
+    int next = 0;
+    uint32_t last_class_count[FRG_SORT_CLASSES] = {0, 0, 0, 0, 0};
+    bool have_hint = false;
+    PendingCounters* acquire(const void* key)
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        PendingCounters* p = nullptr;
+        for (auto& c : slot) if (c.key == key) p = &c;          // the same image buffer is being reused
+        if (!p) { p = &slot[next]; next = (next + 1) % kPendingSlots; }
+        if (!p->host && hipHostMalloc(reinterpret_cast<void**>(&p->host), sizeof(frg::Counters), hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (p->ev && p->device != dev) {
+            (void)hipEventDestroy(p->ev); (void)hipEventDestroy(p->scanned); (void)hipStreamDestroy(p->copy_stream);
+            p->ev = nullptr; p->scanned = nullptr; p->copy_stream = nullptr;
+        }
+        if (!p->ev && hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!p->scanned && hipEventCreateWithFlags(&p->scanned, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!p->copy_stream && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        p->device = dev;
+        p->key = key;
+        return p;
+    }
+    PendingCounters* find(const void* key)
+    {
+        for (auto& c : slot) if (c.key == key && c.ev) return &c;
+        return nullptr;
+    }
+};
+thread_local PendingRing g_pending;
 
 #define FRG_HIP(call)                                                                              \
     do {                                                                                           \
@@ -134,10 +192,16 @@ int frg_stage_times(float* ms, int n)
     for (int i = 0; i < n; i++) ms[i] = -1.0f;
     if (!g_timers.init) return ST_COUNT;
     for (int i = 0; i < ST_COUNT; i++) {
-        if (!g_timers.used[i]) continue;
-        if (hipEventSynchronize(g_timers.ev[i][1]) != hipSuccess) continue;
-        float t = -1.0f;
-        if (hipEventElapsedTime(&t, g_timers.ev[i][0], g_timers.ev[i][1]) == hipSuccess) ms[i] = t;
+        const unsigned cnt = g_timers.launches[i] < (unsigned)ST_SLOTS ? g_timers.launches[i] : (unsigned)ST_SLOTS;
+        double sum = 0.0;
+        unsigned good = 0;
+        for (unsigned k = 0; k < cnt; k++) {
+            if (hipEventSynchronize(g_timers.ev[i][k][1]) != hipSuccess) continue;
+            float t = -1.0f;
+            if (hipEventElapsedTime(&t, g_timers.ev[i][k][0], g_timers.ev[i][k][1]) == hipSuccess) { sum += t; good++; }
+        }
+        if (good) ms[i] = (float)(sum / good);
+        g_timers.launches[i] = 0;
     }
     return ST_COUNT;
 }
@@ -188,13 +252,17 @@ int frg_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return FRG_OK;
 }
 
-int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
-                int P, int D, int M, const float* background, int width, int height,
-                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                float tan_fovx, float tan_fovy, int prefiltered,
-                float* out_color, int* radii, int debug, void* hip_stream)
+// capacity == 0: the reference's flow, one blocking read-back of the counters between scan and
+// scatter.  capacity > 0: no host synchronisation at all -- the binning buffer is sized for
+// `capacity` instances up front, launches that depend on the counters use device-side values,
+// and the counters travel to a pinned slot that frg_forward_finish() inspects later.
+static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
+                        int P, int D, int M, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, int prefiltered,
+                        float* out_color, int* radii, int debug, void* hip_stream, int capacity)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
@@ -226,7 +294,33 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
     { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess"); }
-    { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, stream), "scan"); }
+    PendingCounters* pend = nullptr;
+    if (capacity > 0) {
+        pend = g_pending.acquire(img_chunk);
+        if (!pend) return fail(FRG_EHIP, "pinned counter slot / event creation failed");
+    }
+    { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, (uint32_t)capacity, stream), "scan"); }
+
+    int R = capacity;
+    if (capacity > 0) {
+        // deferred counters: everything below is enqueued without knowing R on the host; the
+        // 48-byte read-back rides a side stream so that no later kernel queues behind it
+        FRG_HIP(hipEventRecord(pend->scanned, stream));
+        FRG_HIP(hipStreamWaitEvent(pend->copy_stream, pend->scanned, 0));
+        FRG_HIP(hipMemcpyAsync(pend->host, img.counters, sizeof(frg::Counters), hipMemcpyDeviceToHost, pend->copy_stream));
+        FRG_HIP(hipEventRecord(pend->ev, pend->copy_stream));
+        char* bin_chunk = binning_alloc(user, frg_binning_bytes(capacity, FRG_SORT_LDS_CAP + 1));
+        if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
+        const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1);
+        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
+        StageScope sc_(ST_BLEND_FWD, stream);
+        if (exact_blend())
+            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
+        else
+            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
+        return R;
+    }
 
     // the single host synchronisation of the op (rasterizer_impl.cu:280-281)
     frg::Counters* host = pinned_counters();
@@ -237,7 +331,7 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
     if (prefiltered && c.filtered)
         return fail(FRG_EFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (c.num_rendered > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
-    const int R = (int)c.num_rendered;
+    R = (int)c.num_rendered;
     const int max_tile = (int)c.max_tile_count;
 
     char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, max_tile));
@@ -246,7 +340,7 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
 
     if (R > 0) {
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
     } else {
         // point_offsets must still be defined for backward
         FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
@@ -259,6 +353,52 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
             FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
     }
     return R;
+}
+
+int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
+                int P, int D, int M, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, int* radii, int debug, void* hip_stream)
+{
+    return forward_impl(geometry_alloc, binning_alloc, image_alloc, user, P, D, M, background, width, height, means3D, shs,
+                        colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                        cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, hip_stream, 0);
+}
+
+int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
+                         int P, int D, int M, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                         const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, int prefiltered,
+                         float* out_color, int* radii, int instance_capacity, void* hip_stream)
+{
+    if (instance_capacity <= 0) return fail(FRG_EINVAL, "instance_capacity must be positive");
+    return forward_impl(geometry_alloc, binning_alloc, image_alloc, user, P, D, M, background, width, height, means3D, shs,
+                        colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                        cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, 0, hip_stream, instance_capacity);
+}
+
+int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rendered)
+{
+    PendingCounters* p = g_pending.find(image_buffer);
+    if (!p) return fail(FRG_EINVAL, "no deferred forward is pending for this image buffer on this thread");
+    FRG_HIP(hipEventSynchronize(p->ev));
+    const frg::Counters c = *p->host;
+    p->key = nullptr;
+    if (num_rendered) *num_rendered = (int)(c.num_rendered > 0x7fffffffu ? 0x7fffffffu : c.num_rendered);
+    if (c.num_rendered > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
+    if (c.overflow)
+        return fail(FRG_ECAPACITY, "%u instances exceed the instance capacity of the deferred forward: nothing was "
+                                   "rasterized, repeat the view with a larger capacity", c.num_rendered);
+    for (int k = 0; k < FRG_SORT_CLASSES; k++) g_pending.last_class_count[k] = c.class_count[k];
+    g_pending.have_hint = true;
+    if (prefiltered && c.filtered)
+        return fail(FRG_EFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    return FRG_OK;
 }
 
 int frg_backward(int P, int D, int M, int R, const float* background, int width, int height,

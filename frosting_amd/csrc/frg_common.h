@@ -55,7 +55,7 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
     uint32_t num_rendered;
     uint32_t max_tile_count;
     uint32_t filtered;       // prefiltered assertion (auxiliary.h:154-162)
-    uint32_t pad;
+    uint32_t overflow;       // deferred-counters forward: num_rendered exceeded the caller's capacity
     uint32_t class_count[FRG_SORT_CLASSES];  // number of tiles per sort size class
     uint32_t pad2[3];
 };

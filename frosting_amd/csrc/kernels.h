@@ -12,13 +12,17 @@ struct FwdInputs {
 
 hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
                                  const ImageState& img, int prefiltered, hipStream_t s);
-hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, hipStream_t s);
+hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s);
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
                           const BinningState& b, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
 
-hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* class_tiles, const uint2* ranges,
-                            uint2* pairs, uint2* pairs_tmp, uint32_t* point_list, hipStream_t stream);
+// class_count: host copy of the per-class tile counts, or nullptr when they are only known on the
+// device (deferred-counters forward) -- grid_hint[] then sizes the launches and the workgroups
+// stride over the device-side lists (class_count_dev), whatever their true length.
+hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
+                            const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
+                            uint32_t* point_list, hipStream_t stream);
 
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                   const float* bg, float* out_color, hipStream_t s);

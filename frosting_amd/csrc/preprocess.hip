@@ -344,15 +344,16 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
 __global__ void __launch_bounds__(1024)
 scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
             uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
-            Counters* __restrict__ counters)
+            Counters* __restrict__ counters, uint32_t capacity)
 {
+    __shared__ uint32_t ovf_s;
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t maxc_s;
     __shared__ uint32_t cls_s[FRG_SORT_CLASSES];
     __shared__ uint32_t sub_s[FRG_SORT_CLASSES * 8], sub_cur[FRG_SORT_CLASSES * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry_s = 0; maxc_s = 0; }
+    if (tid == 0) { carry_s = 0; maxc_s = 0; ovf_s = 0; }
     if (tid < FRG_SORT_CLASSES) cls_s[tid] = 0;
     if (tid < FRG_SORT_CLASSES * 8) { sub_s[tid] = 0; sub_cur[tid] = 0; }
     __syncthreads();
@@ -369,6 +370,9 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
                     for (int s = 0; s < FRG_BIN_SEGS; s++) v += seg_sums[(size_t)s * T + i];
                     tile_count[i] = v;
                 } else v = tile_count[i];
+                // more instances than the caller's binning buffer holds (deferred-counters forward):
+                // every tile list is left empty, the frame renders as background and is redone
+                if (pass == 1 && ovf_s) { v = 0; tile_count[i] = 0; }
             }
             local_max = max(local_max, v);
             uint32_t inc = wave_incl_scan(v, lane);
@@ -399,7 +403,11 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
             __syncthreads();
         }
         if (pass == 0) {
-            if (tid == 0) { counters->num_rendered = carry_s; carry_s = 0; }
+            if (tid == 0) {
+                counters->num_rendered = carry_s;
+                if (capacity && carry_s > capacity) { ovf_s = 1; counters->overflow = 1; }
+                carry_s = 0;
+            }
         } else {
             atomicMax(&maxc_s, local_max);
         }
@@ -451,9 +459,11 @@ __global__ void __launch_bounds__(FRG_BIN_THREADS)
 scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float4* __restrict__ xydr,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ chunk_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ bin_matrix,
-               const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs)
+               const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs,
+               const Counters* __restrict__ counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
+    if (counters->overflow) return;   // wave-uniform: the binning buffer is too small for this frame
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
@@ -545,7 +555,7 @@ hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& i
                 : launch_pre_variant<false, false>(P, vp, in, radii, g, img, prefiltered, s);
 }
 
-hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, hipStream_t s)
+hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
@@ -553,7 +563,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     if (img.lds_bins)
         hipLaunchKernelGGL(colsum_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
-                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters);
+                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity);
     if (img.lds_bins)
         hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     return hipGetLastError();
@@ -569,10 +579,10 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
         hipError_t e = allow_big_lds(scatter_kernel<true>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(scatter_kernel<true>, dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp.gx, vp.gy, radii, g.xydr,
-                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs);
+                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters);
     } else {
         hipLaunchKernelGGL(scatter_kernel<false>, dim3(nb), dim3(FRG_BIN_THREADS), 0, s, P, vp.gx, vp.gy, radii, g.xydr,
-                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs);
+                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters);
     }
     return hipGetLastError();
 }

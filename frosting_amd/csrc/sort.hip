@@ -261,8 +261,8 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
 // launches one instantiation per size class; workgroups whose tile is outside exit at once).
 template <int NWAVES, int CAP>
 __global__ void __launch_bounds__(NWAVES * 64)
-sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __restrict__ ranges,
-                      const uint2* __restrict__ pairs, uint32_t* __restrict__ point_list)
+sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
+                      const uint2* __restrict__ ranges, const uint2* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
     constexpr int SORT_ITEMS = CAP / (NWAVES * 64);   // elements staged per thread
     static_assert(CAP == NWAVES * 64 * SORT_ITEMS && SORT_ITEMS >= 1, "CAP must be a multiple of the workgroup size");
@@ -270,77 +270,87 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint2* __res
     uint2* buf = reinterpret_cast<uint2*>(smem);
     uint32_t* whist = reinterpret_cast<uint32_t*>(buf + CAP);
     uint32_t* scratch = whist + NWAVES * 256;  // 260 words
-    const int tile = (int)tile_list[blockIdx.x];   // the grid covers exactly the tiles of this size class
-    const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
-    if (n > CAP) return;
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 64 * SORT_ITEMS
-    const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
-    const int begin = wave * strip, end = min(n, begin + strip);
-    uint2 e[SORT_ITEMS];
-#pragma unroll
-    for (int it = 0; it < SORT_ITEMS; it++) {
-        const int i = begin + it * 64 + lane;
-        e[it] = i < end ? pairs[rg.x + i] : make_uint2(0u, 0u);
-    }
-    if (tid == 0) scratch[256] = 0;
-    __syncthreads();
-    bool in_lds = false;
-    if (n > 1) {
-#pragma unroll 1
-        for (int pass = 0; pass < 4; pass++)
-            in_lds |= radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
-    }
-    if (!in_lds) {   // nothing moved (n == 1 or all keys equal): materialise the strip for the steps below
+    // the grid normally covers exactly the tiles of this size class (one pass of this loop); when the
+    // host only had an estimate of the list length, workgroups stride over the device-side list
+    const uint32_t ntiles = *list_len;
+    for (uint32_t item = blockIdx.x; item < ntiles; item += gridDim.x) {
+        if (item != blockIdx.x) __syncthreads();   // the previous tile's LDS contents are dead
+        const int tile = (int)tile_list[item];
+        const uint2 rg = ranges[tile];
+        const int n = (int)(rg.y - rg.x);
+        if (n > CAP) continue;
+        // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 64 * SORT_ITEMS
+        const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
+        const int begin = wave * strip, end = min(n, begin + strip);
+        uint2 e[SORT_ITEMS];
 #pragma unroll
         for (int it = 0; it < SORT_ITEMS; it++) {
             const int i = begin + it * 64 + lane;
-            if (i < end) buf[i] = e[it];
+            e[it] = i < end ? pairs[rg.x + i] : make_uint2(0u, 0u);
         }
+        if (tid == 0) scratch[256] = 0;
         __syncthreads();
-    }
-    if (n > 1) {
-        const int ties = count_ties<uint2*>(buf, n, NT, scratch);
-        if (ties > 32) {
-            // many equal depths (coplanar scenes): order by index, then by depth again -- LSD
-            // stability turns that into (depth, index)
+        bool in_lds = false;
+        if (n > 1) {
 #pragma unroll 1
-            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
-#pragma unroll 1
-            for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
-        } else if (ties > 0) {
-            fix_ties<uint2*>(buf, n, NT);
+            for (int pass = 0; pass < 4; pass++)
+                in_lds |= radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
         }
+        if (!in_lds) {   // nothing moved (n == 1 or all keys equal): materialise the strip for the steps below
+#pragma unroll
+            for (int it = 0; it < SORT_ITEMS; it++) {
+                const int i = begin + it * 64 + lane;
+                if (i < end) buf[i] = e[it];
+            }
+            __syncthreads();
+        }
+        if (n > 1) {
+            const int ties = count_ties<uint2*>(buf, n, NT, scratch);
+            if (ties > 32) {
+                // many equal depths (coplanar scenes): order by index, then by depth again -- LSD
+                // stability turns that into (depth, index)
+#pragma unroll 1
+                for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+#pragma unroll 1
+                for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+            } else if (ties > 0) {
+                fix_ties<uint2*>(buf, n, NT);
+            }
+        }
+        for (int i = tid; i < n; i += NT) point_list[rg.x + i] = buf[i].y;
     }
-    for (int i = tid; i < n; i += NT) point_list[rg.x + i] = buf[i].y;
 }
 
 // Fallback for tile lists longer than the LDS capacity: same passes, ping-pong
 // in global memory (pairs <-> pairs_tmp); only histograms live in LDS.
 template <int NWAVES>
 __global__ void __launch_bounds__(NWAVES * 64)
-sort_tiles_global_kernel(const uint32_t* __restrict__ tile_list, const uint2* __restrict__ ranges, uint2* pairs,
-                         uint2* pairs_tmp, uint32_t* __restrict__ point_list)
+sort_tiles_global_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
+                         const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_tmp, uint32_t* __restrict__ point_list)
 {
     __shared__ uint32_t whist[NWAVES * 256];
     __shared__ uint32_t scratch[260];
-    const int tile = (int)tile_list[blockIdx.x];
-    const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x;
-    if (tid == 0) scratch[256] = 0;
-    __syncthreads();
-    uint2* src = sort_segment<NWAVES, uint2*>(pairs + rg.x, pairs_tmp + rg.x, n, whist, scratch);
-    for (int i = tid; i < n; i += NT) point_list[rg.x + i] = src[i].y;
+    const uint32_t ntiles = *list_len;
+    for (uint32_t item = blockIdx.x; item < ntiles; item += gridDim.x) {
+        __syncthreads();
+        const int tile = (int)tile_list[item];
+        const uint2 rg = ranges[tile];
+        const int n = (int)(rg.y - rg.x);
+        if (tid == 0) scratch[256] = 0;
+        __syncthreads();
+        uint2* src = sort_segment<NWAVES, uint2*>(pairs + rg.x, pairs_tmp + rg.x, n, whist, scratch);
+        for (int i = tid; i < n; i += NT) point_list[rg.x + i] = src[i].y;
+    }
 }
 
 // Host-side launcher (called from api.hip)
 template <int NW, int CAP>
-static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const uint2* ranges, const uint2* pairs,
-                                   uint32_t* point_list, hipStream_t stream)
+static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const uint32_t* list_len, const uint2* ranges,
+                                   const uint2* pairs, uint32_t* point_list, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
     const size_t lds = (size_t)CAP * 8 + NW * 1024 + 260 * 4;
@@ -351,7 +361,7 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((sort_tiles_lds_kernel<NW, CAP>), dim3(count), dim3(NW * 64), lds, stream, tile_list, ranges, pairs, point_list);
+    hipLaunchKernelGGL((sort_tiles_lds_kernel<NW, CAP>), dim3(count), dim3(NW * 64), lds, stream, tile_list, list_len, ranges, pairs, point_list);
     return hipGetLastError();
 }
 
@@ -388,11 +398,22 @@ struct SortStreams {
     }
 };
 
-hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* class_tiles, const uint2* ranges,
-                            uint2* pairs, uint2* pairs_tmp, uint32_t* point_list, hipStream_t stream)
+hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
+                            const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
+                            uint32_t* point_list, hipStream_t stream)
 {
-    const int c0 = (int)class_count[0], c1 = (int)class_count[1], c2 = (int)class_count[2], c3 = (int)class_count[3],
-              c4 = (int)class_count[4];
+    int cc[FRG_SORT_CLASSES];
+    for (int k = 0; k < FRG_SORT_CLASSES; k++) {
+        if (class_count) cc[k] = (int)class_count[k];
+        else {
+            // estimate only: a quarter more than last time, never none (the lists are re-read on the device)
+            const uint32_t h = grid_hint ? grid_hint[k] + grid_hint[k] / 4 + 8 : (uint32_t)T;
+            cc[k] = (int)(h < (uint32_t)T ? h : (uint32_t)T);
+            if (k == 4 && !pairs_tmp) cc[k] = 0;
+        }
+    }
+    const int c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4];
+    const uint32_t* len = class_count_dev;
     if (T <= 0 || c0 + c1 + c2 + c3 + c4 == 0) return hipSuccess;
     thread_local SortStreams ss;
     const bool big = (c2 + c3 + c4) > 0;
@@ -407,17 +428,23 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
     }
     // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 8 waves x 16 elements,
     // >8192 global ping-pong; longest-running classes first
-    if (c4) {
+    auto launch_global_class = [&]() -> hipError_t {
+        if (!c4) return hipSuccess;
         if (!pairs_tmp) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(c4), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, ranges, pairs, pairs_tmp, point_list);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
+        hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(c4), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, len + 4, ranges, pairs, pairs_tmp, point_list);
+        return hipGetLastError();
+    };
+    // a known non-empty >8192 class runs longest and goes first; when its length is only an estimate
+    // (usually zero tiles) it goes last on its stream: its 1024-thread workgroups would otherwise wait
+    // for a free CU while the class queued behind them sits idle
+    if (class_count && (e = launch_global_class()) != hipSuccess) return e;
     // (4096,8192]: 8 waves x 16 staged elements rather than 16 x 8 -- two workgroups fit a CU and
     // one's barrier stalls overlap the other's ranking (0.286 -> 0.256 ms at C3)
-    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, ranges, pairs, point_list, s2)) != hipSuccess) return e;
-    if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, ranges, pairs, point_list, s1)) != hipSuccess) return e;
-    if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, ranges, pairs, point_list, stream)) != hipSuccess) return e;
-    if ((e = launch_lds_class<1, 512>(c0, class_tiles, ranges, pairs, point_list, stream)) != hipSuccess) return e;
+    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, len + 3, ranges, pairs, point_list, s2)) != hipSuccess) return e;
+    if (!class_count && (e = launch_global_class()) != hipSuccess) return e;
+    if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, len + 2, ranges, pairs, point_list, s1)) != hipSuccess) return e;
+    if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, len + 1, ranges, pairs, point_list, stream)) != hipSuccess) return e;
+    if ((e = launch_lds_class<1, 512>(c0, class_tiles, len, ranges, pairs, point_list, stream)) != hipSuccess) return e;
     if (forked) {
         if (c2) {
             if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;

@@ -163,8 +163,16 @@ class ViewParallelRasterizer:
     """Replicated scene + per-rank view render through the C ABI, gradients written
     in place into the flat exchange buffer (no copies, no zero-fill)."""
 
-    def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False):
+    def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
+                 deferred_counters: bool = False, capacity_slack: float = 1.25):
+        """deferred_counters: after the first (synchronous) view, forwards run through
+        frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
+        true instance count and whether the view has to be repeated (capacity exceeded)."""
         self.dev = torch.device(device)
+        self.deferred_counters = deferred_counters
+        self.capacity_slack = capacity_slack
+        self.capacity = 0            # instances the binning arena is sized for (deferred forwards)
+        self._pending = False
         self.scene = scene
         P, K = scene.means3D.shape[0], scene.shs.shape[1]
         self.P, self.K = P, K
@@ -185,29 +193,58 @@ class ViewParallelRasterizer:
         self.num_rendered = 0
         self._view = None
 
-    def forward(self, cam, bg):
+    def forward(self, cam, bg, deferred=None):
+        """Render one view.  With deferred counters the returned image is valid only if the
+        following finish() returns True."""
         L = _lib.lib()
         s = self.scene
         H, W = cam.image_height, cam.image_width
         if self.out_color is None or tuple(self.out_color.shape) != (3, H, W):
             self.out_color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        rc = L.frg_forward(self.geom.cb, self.binning.cb, self.img.cb, None,
-                           self.P, s.sh_degree, self.K, _p(bg), W, H,
-                           _p(s.means3D), _p(s.shs), None, _p(s.opacities),
-                           _p(s.scales), 1.0, _p(s.rotations), None,
-                           _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
-                           float(cam.tanfovx), float(cam.tanfovy), 0,
-                           _p(self.out_color), _p(self.radii), 0, stream)
+        use_deferred = (self.deferred_counters if deferred is None else deferred) and self.capacity > 0
+        fn = L.frg_forward_deferred if use_deferred else L.frg_forward
+        rc = fn(self.geom.cb, self.binning.cb, self.img.cb, None,
+                self.P, s.sh_degree, self.K, _p(bg), W, H,
+                _p(s.means3D), _p(s.shs), None, _p(s.opacities),
+                _p(s.scales), 1.0, _p(s.rotations), None,
+                _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
+                float(cam.tanfovx), float(cam.tanfovy), 0,
+                _p(self.out_color), _p(self.radii), self.capacity if use_deferred else 0, stream)
         if rc < 0:
-            raise RuntimeError(f"frg_forward failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"{'frg_forward_deferred' if use_deferred else 'frg_forward'} failed ({rc}): {_lib.last_error()}")
+        # deferred: rc is the capacity, which is what the backward carves its buffers with
         self.num_rendered = rc
+        self._pending = use_deferred and rc > 0
+        if not use_deferred:
+            self.true_num_rendered = rc
+            if self.deferred_counters:
+                self.capacity = max(self.capacity, int(rc * self.capacity_slack) + 4096)
         self._view = (cam, bg)
         return self.out_color, self.radii
 
-    def backward(self, dL_dimage, slot: int = 0):
+    def finish(self) -> bool:
+        """Deferred counters: wait for the last forward's counters (not for its kernels).  True: the
+        view was rasterized (true_num_rendered is set).  False: it had more instances than the
+        capacity -- nothing was rasterized; the capacity has been raised, repeat forward (+ backward)."""
+        if not self._pending:
+            return True
+        self._pending = False
+        n = C.c_int(0)
+        rc = _lib.lib().frg_forward_finish(_p(self.img.buf), 0, C.byref(n))
+        if rc == _lib.ECAPACITY:
+            self.capacity = int(n.value * self.capacity_slack) + 4096
+            return False
+        if rc < 0:
+            raise RuntimeError(f"frg_forward_finish failed ({rc}): {_lib.last_error()}")
+        self.true_num_rendered = n.value
+        return True
+
+    def backward(self, dL_dimage, slot: int = 0, payload=None):
         """Gradients of the last forward, written in place into exchange buffer `slot`.  In the
-        factored plan under a process group, views["shs"] is only valid after wait_exchange(slot)."""
+        factored plan under a process group, views["shs"] is only valid after wait_exchange(slot).
+        payload: also fill this view's share of the factored exchange (masked colour gradient and
+        camera centre); default: only when a process group is live."""
         L = _lib.lib()
         s = self.scene
         cam, bg = self._view
@@ -231,7 +268,7 @@ class ViewParallelRasterizer:
                             _p(work), work.numel(), 0, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
-        if ex.factor_sh:
+        if ex.factor_sh and (ex._active() if payload is None else payload):
             # this view's share of the factored SH exchange: masked colour gradient + camera centre
             rc = L.frg_sh_color_grad(self.P, _p(self.geom.buf), _p(self.radii), _p(self.dL_dcolors), _p(ex.own_drgb), stream)
             if rc < 0:

@@ -41,6 +41,7 @@ extern "C" {
 #define FRG_EALLOC (-2)   /* an allocation callback returned NULL / too small workspace */
 #define FRG_EHIP (-3)     /* a HIP runtime call or kernel failed (see frg_last_error) */
 #define FRG_EFILTER (-4)  /* prefiltered=1 but a Gaussian was near-culled (auxiliary.h:154-162) */
+#define FRG_ECAPACITY (-5) /* frg_forward_finish: the view had more instances than instance_capacity */
 
 /* Resizable-buffer callback: must return device memory of at least `bytes`
  * bytes, 256-byte aligned, owned by the caller and kept alive until the matching
@@ -70,6 +71,29 @@ int frg_forward(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_all
                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                 float tan_fovx, float tan_fovy, int prefiltered,
                 float* out_color, int* radii, int debug, void* hip_stream);
+
+/* Forward without any host synchronisation, for training loops that keep the GPU queue full
+ * (the reference blocks on a device->host read of num_rendered in the middle of the op,
+ * rasterizer_impl.cu:280-281, because it sizes the binning buffer from it).  The caller states
+ * an instance capacity instead: binning_alloc is asked once for frg_binning_bytes(capacity, INT_MAX)
+ * and every launch that depends on the counters reads them on the device.  Returns
+ * instance_capacity -- pass THAT as R to frg_backward_workspace_bytes / frg_backward -- or 0 when
+ * P == 0, or a negative error.  Results are identical to frg_forward's.
+ *
+ * frg_forward_finish(image_buffer, ...) later waits for that forward's counters only (an event
+ * behind the scan, not the whole stream) and reports the true num_rendered.  FRG_ECAPACITY: the view
+ * had more instances than the capacity; nothing was rasterized (the image is the background, a
+ * backward yields zeros) and the view must be repeated with a larger capacity.  Call it from the
+ * thread that issued the forward, once per deferred forward that returned > 0. */
+int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc, frg_alloc_fn image_alloc, void* user,
+                         int P, int D, int M,
+                         const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                         const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, int prefiltered,
+                         float* out_color, int* radii, int instance_capacity, void* hip_stream);
+int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rendered);
 
 /* Bytes of scratch frg_backward needs for a forward that returned R instances. */
 size_t frg_backward_workspace_bytes(int P, int R);
@@ -107,11 +131,13 @@ int frg_backward(int P, int D, int M, int R,
 int frg_set_option(const char* name, int value);
 int frg_get_option(const char* name);
 
-/* Per-stage GPU time of the calling thread's most recent forward/backward, valid
- * after frg_set_option("profile", 1): ms[0..6] = preprocess, scan, scatter, sort,
- * blend_fwd, blend_bwd, preprocess_bwd (milliseconds between hipEvents recorded on
- * the caller's stream; -1 when a stage did not run).  Synchronises on the events.
- * Returns the number of stages (7) or a negative error. */
+/* Per-stage GPU time of the calling thread's forwards/backwards since the previous call
+ * (at most the last 64 launches of each stage), averaged per launch; valid after
+ * frg_set_option("profile", 1): ms[0..6] = preprocess, scan, scatter, sort, blend_fwd,
+ * blend_bwd, preprocess_bwd (milliseconds between hipEvents recorded on the caller's
+ * stream; -1 when a stage did not run).  The events are only synchronised on here, so a
+ * timed run of steps is not serialised by the measurement.  Returns the number of stages
+ * (7) or a negative error. */
 int frg_stage_times(float* ms, int n);
 
 /* Sizes of the three state chunks (what the callbacks will be asked for). */

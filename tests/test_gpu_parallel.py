@@ -21,7 +21,7 @@ def _per_view(vpr, name, views, dev, P=None):
         scene, cam, bg = scenes.config_scene(name, k, P=P)
         img, _ = vpr.forward(cam.to(dev), bg.to(dev))
         gpix, _ = scenes.l1_target_grad(img.cpu(), 555 + k)
-        g = vpr.backward(gpix.to(dev), 0)
+        g = vpr.backward(gpix.to(dev), 0, payload=True)
         grads.append({n: g[n].clone() for n in PARAM_ORDER})
         payloads.append(vpr.exchange.own.clone())
     return grads, payloads
@@ -57,7 +57,7 @@ def test_rebuild_lower_degree_and_zero_views(gpu_device):
     vpr = ViewParallelRasterizer(scene.to(dev), dev, factor_sh=True)
     img, _ = vpr.forward(cam.to(dev), bg.to(dev))
     gpix, _ = scenes.l1_target_grad(img.cpu(), 9)
-    g = vpr.backward(gpix.to(dev), 0)
+    g = vpr.backward(gpix.to(dev), 0, payload=True)
     want = g["shs"].clone()
     assert float(want[:, 4:].abs().max()) == 0.0 and float(want[:, 1:4].abs().max()) > 0
     ex = vpr.exchange
@@ -110,3 +110,50 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
             assert float(ref.abs().max()) > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_deferred_counters_forward_matches_blocking_forward(gpu_device):
+    """frg_forward_deferred (no host synchronisation) against frg_forward: same image, radii and
+    gradients bit for bit; a too-small capacity is reported by finish() and nothing is rasterized."""
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("c2", 1, P=40000)
+    cam_d, bg_d = cam.to(dev), bg.to(dev)
+    ref = ViewParallelRasterizer(scene.to(dev), dev)
+    img0, radii0 = ref.forward(cam_d, bg_d)
+    img0, radii0 = img0.clone(), radii0.clone()
+    gpix, _ = scenes.l1_target_grad(img0.cpu(), 3)
+    gpix = gpix.to(dev)
+    g0 = ref.backward(gpix, 0)
+    flat0 = ref.exchange.flat.clone()
+    R = ref.num_rendered
+
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, deferred_counters=True)
+    vpr.forward(cam_d, bg_d)                       # first view: blocking, sizes the arena
+    assert vpr.finish() and vpr.capacity >= R
+    for _ in range(3):                             # deferred from here on (sort launches sized from the last view)
+        img, radii = vpr.forward(cam_d, bg_d)
+        assert vpr.num_rendered == vpr.capacity    # what backward carves its buffers with
+        vpr.backward(gpix, 0)
+        assert vpr.finish() and vpr.true_num_rendered == R
+        assert torch.equal(img, img0) and torch.equal(radii, radii0)
+        assert torch.equal(vpr.exchange.flat, flat0)
+
+    # another camera with the sort launches still sized from the previous one
+    scene2, cam2, _ = scenes.config_scene("c2", 5, P=40000)
+    want, _ = ref.forward(cam2.to(dev), bg_d)
+    want = want.clone()
+    got, _ = vpr.forward(cam2.to(dev), bg_d)
+    assert vpr.finish()
+    assert torch.equal(got, want)
+
+    # capacity exceeded: reported, nothing rasterized (background only), then repeated
+    vpr.capacity = 1000
+    img, _ = vpr.forward(cam_d, bg_d)
+    vpr.backward(gpix, 0)
+    assert not vpr.finish() and vpr.capacity >= R
+    assert torch.equal(img, bg_d[:, None, None].expand_as(img))
+    assert float(vpr.exchange.flat.abs().max()) == 0.0
+    img, _ = vpr.forward(cam_d, bg_d)
+    vpr.backward(gpix, 0)
+    assert vpr.finish()
+    assert torch.equal(img, img0) and torch.equal(vpr.exchange.flat, flat0)
