@@ -28,6 +28,7 @@ int fail(int code, const char* fmt, ...)
 
 std::atomic<int> g_exact_blend{-1};
 std::atomic<int> g_profile{0};
+std::atomic<int> g_profile_stage{-1};  // -1: every stage; k: only stage k gets events (each record costs ~3 us of stream time)
 std::atomic<int> g_global_bins{0};  // test hook: force the large-image (global-atomic) binning path
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
@@ -65,6 +66,8 @@ struct StageScope {
     int id; hipStream_t s; bool on; int slot;
     StageScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile.load() != 0), slot(0)
     {
+        const int only = g_profile_stage.load();
+        if (only >= 0 && only != id) on = false;
         if (on && !g_timers.ensure()) on = false;
         if (on) { slot = (int)(g_timers.launches[id] % ST_SLOTS); (void)hipEventRecord(g_timers.ev[id][slot][0], s); }
     }
@@ -182,6 +185,7 @@ int frg_set_option(const char* name, int value)
         return old;
     }
     if (name && strcmp(name, "profile") == 0) return g_profile.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.exchange(value < 0 || value >= ST_COUNT ? -1 : value);
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -210,6 +214,7 @@ int frg_get_option(const char* name)
 {
     if (name && strcmp(name, "exact_blend") == 0) return exact_blend();
     if (name && strcmp(name, "profile") == 0) return g_profile.load();
+    if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.load();
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }

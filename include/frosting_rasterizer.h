@@ -125,7 +125,8 @@ int frg_backward(int P, int D, int M, int R,
  * images to the reference built the same way); 0 (default) = FMA + native exp2.
  * The per-Gaussian stages are always evaluated in the exact order, so radii,
  * tile counts and sort keys never depend on this switch.  "profile": see
- * frg_stage_times.  "global_bins": 1 forces the binning path used for images with
+ * frg_stage_times; "profile_stage": k in 0..6 restricts the events to stage k (each event
+ * record costs a few microseconds of stream time), -1 (default) = every stage.  "global_bins": 1 forces the binning path used for images with
  * more than 20480 tiles (global atomics instead of LDS histograms; test hook).
  * Returns the previous value or FRG_EINVAL for an unknown name. */
 int frg_set_option(const char* name, int value);
