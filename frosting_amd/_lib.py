@@ -20,6 +20,28 @@ ECAPACITY = -5
 _lib = None
 
 
+class ForwardArgs(C.Structure):
+    """frg_forward_args (include/frosting_rasterizer.h)."""
+    _fields_ = [("struct_size", C.c_size_t),
+                ("geometry_alloc", ALLOC_FN), ("binning_alloc", ALLOC_FN), ("image_alloc", ALLOC_FN),
+                ("user", C.c_void_p),
+                ("P", C.c_int), ("D", C.c_int), ("M", C.c_int),
+                ("background", C.c_void_p),
+                ("width", C.c_int), ("height", C.c_int),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("scale_modifier", C.c_float),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("prefiltered", C.c_int),
+                ("out_color", C.c_void_p), ("radii", C.c_void_p),
+                ("debug", C.c_int),
+                ("hip_stream", C.c_void_p),
+                ("instance_capacity", C.c_int),
+                ("keep_mask", C.c_void_p)]
+
+
 def build(verbose: bool = False) -> str:
     """Compile every HIP translation unit for gfx950 (hipcc cross-compiles on CPU-only hosts)."""
     out = None if verbose else subprocess.DEVNULL
@@ -68,6 +90,8 @@ def lib():
                               vp, vp, i, vp]
     L.frg_forward_deferred.restype = i
     L.frg_forward_deferred.argtypes = list(L.frg_forward.argtypes)   # `debug` slot carries instance_capacity
+    L.frg_forward_ex.restype = i
+    L.frg_forward_ex.argtypes = [C.POINTER(ForwardArgs)]
     L.frg_forward_finish.restype = i
     L.frg_forward_finish.argtypes = [vp, i, C.POINTER(C.c_int)]
     L.frg_backward.restype = i
@@ -121,5 +145,5 @@ EXPORTED_SYMBOLS = [
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_sh_color_grad", "frg_sh_grad_from_views",
-    "frg_forward_deferred", "frg_forward_finish",
+    "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex",
 ]

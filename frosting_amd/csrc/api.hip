@@ -267,7 +267,8 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
                         const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, int prefiltered,
-                        float* out_color, int* radii, int debug, void* hip_stream, int capacity)
+                        float* out_color, int* radii, int debug, void* hip_stream, int capacity,
+                        const unsigned char* keep_mask = nullptr)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
@@ -298,6 +299,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
+    in.keep_mask = keep_mask;
     { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess"); }
     PendingCounters* pend = nullptr;
     if (capacity > 0) {
@@ -385,6 +387,19 @@ int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc
     return forward_impl(geometry_alloc, binning_alloc, image_alloc, user, P, D, M, background, width, height, means3D, shs,
                         colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
                         cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, 0, hip_stream, instance_capacity);
+}
+
+int frg_forward_ex(const frg_forward_args* a)
+{
+    if (!a || a->struct_size != sizeof(frg_forward_args))
+        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_forward_args));
+    if (a->instance_capacity < 0) return fail(FRG_EINVAL, "instance_capacity < 0");
+    return forward_impl(a->geometry_alloc, a->binning_alloc, a->image_alloc, a->user, a->P, a->D, a->M, a->background,
+                        a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales,
+                        a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->cam_pos,
+                        a->tan_fovx, a->tan_fovy, a->prefiltered, a->out_color, a->radii,
+                        a->instance_capacity > 0 ? 0 : a->debug, a->hip_stream, a->instance_capacity, a->keep_mask);
 }
 
 int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rendered)

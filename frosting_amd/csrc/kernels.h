@@ -8,6 +8,7 @@ namespace frg {
 struct FwdInputs {
     const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
+    const unsigned char* keep_mask = nullptr;   // optional per-Gaussian skip flag (0 = not in this view)
 };
 
 hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,

@@ -73,12 +73,13 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
                const float* __restrict__ means3D, const float* __restrict__ scales,
                const float* __restrict__ rotations, const float* __restrict__ opacities,
                const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-               const float* __restrict__ colors_precomp,
+               const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask,
                float4* __restrict__ xydr, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_clamped,
                Counters* __restrict__ counters, int prefiltered, int& radius_i, int& x0, int& y0, int& x1, int& y1,
                float3& dir)
 {
     radius_i = 0;
+    if (keep_mask && !keep_mask[idx]) return 0u;   // occlusion-culled by the caller: not part of this view
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     const float4 p_hom = xform44(p, vmx.proj);
     const float3 p_view = xform43(p, vmx.view);
@@ -190,7 +191,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-                      const float* __restrict__ colors_precomp,
+                      const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask,
                       int* __restrict__ radii, float4* __restrict__ xydr, float4* __restrict__ conic_opacity,
                       float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched,
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
@@ -218,7 +219,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         if (idx < P) {
             int radius_i, x0, y0, x1, y1;
             touched = preprocess_one(idx, vp, vmx, means3D, scales, rotations, opacities, shs, cov3D_precomp,
-                                     colors_precomp, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
+                                     colors_precomp, keep_mask, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
                                      radius_i, x0, y0, x1, y1, dir);
             radii[idx] = radius_i;
             tiles_touched[idx] = touched;
@@ -539,7 +540,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SH16>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
-                       in.cov3D_precomp, in.colors_precomp, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
+                       in.cov3D_precomp, in.colors_precomp, in.keep_mask, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
     return hipGetLastError();
 }

@@ -71,7 +71,10 @@ class _NativeOps:
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, debug):
+                            campos, prefiltered, debug, keep_mask=None):
+        """keep_mask (extension, optional bool/uint8 [P]): Gaussians with a zero entry are left out of this
+        view as if culled -- Frosting's occlusion culling without the boolean compaction of every
+        per-Gaussian tensor (frosting_scene/frosting_model.py:1564-1586)."""
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
         if not means3D.is_cuda:
@@ -88,13 +91,32 @@ class _NativeOps:
                      opac=_f32c(opacity, dev), scales=_f32c(scales, dev), rots=_f32c(rotations, dev),
                      cov=_f32c(cov3D_precomp, dev), view=_f32c(viewmatrix, dev), proj=_f32c(projmatrix, dev),
                      sh=_f32c(sh, dev), campos=_f32c(campos, dev))
-            rc = L.frg_forward(bufs.cb_geom, bufs.cb_binning, bufs.cb_img, None,
-                               P, int(degree), M, _ptr(t["bg"]), W, H,
-                               _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]), _ptr(t["opac"]),
-                               _ptr(t["scales"]), float(scale_modifier), _ptr(t["rots"]), _ptr(t["cov"]),
-                               _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
-                               float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                               _ptr(out_color), _ptr(radii) if P else None, int(bool(debug)), _stream_ptr(dev))
+            if keep_mask is None:
+                rc = L.frg_forward(bufs.cb_geom, bufs.cb_binning, bufs.cb_img, None,
+                                   P, int(degree), M, _ptr(t["bg"]), W, H,
+                                   _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]), _ptr(t["opac"]),
+                                   _ptr(t["scales"]), float(scale_modifier), _ptr(t["rots"]), _ptr(t["cov"]),
+                                   _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
+                                   float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                                   _ptr(out_color), _ptr(radii) if P else None, int(bool(debug)), _stream_ptr(dev))
+            else:
+                if keep_mask.shape != (P,) or keep_mask.device != dev or keep_mask.dtype not in (torch.bool, torch.uint8):
+                    raise RuntimeError("keep_mask must be a bool / uint8 tensor of shape (num_points,) on the Gaussians' device")
+                mask = keep_mask.contiguous()
+
+                def vp(x):
+                    return None if x is None else x.value
+                a = _lib.ForwardArgs(
+                    struct_size=C.sizeof(_lib.ForwardArgs), geometry_alloc=bufs.cb_geom, binning_alloc=bufs.cb_binning,
+                    image_alloc=bufs.cb_img, user=None, P=P, D=int(degree), M=M, background=vp(_ptr(t["bg"])), width=W,
+                    height=H, means3D=vp(_ptr(t["means"])), shs=vp(_ptr(t["sh"])), colors_precomp=vp(_ptr(t["colors"])),
+                    opacities=vp(_ptr(t["opac"])), scales=vp(_ptr(t["scales"])), scale_modifier=float(scale_modifier),
+                    rotations=vp(_ptr(t["rots"])), cov3D_precomp=vp(_ptr(t["cov"])), viewmatrix=vp(_ptr(t["view"])),
+                    projmatrix=vp(_ptr(t["proj"])), cam_pos=vp(_ptr(t["campos"])), tan_fovx=float(tan_fovx),
+                    tan_fovy=float(tan_fovy), prefiltered=int(bool(prefiltered)), out_color=out_color.data_ptr(),
+                    radii=radii.data_ptr() if P else None, debug=int(bool(debug)), hip_stream=_stream_ptr(dev).value,
+                    instance_capacity=0, keep_mask=mask.data_ptr() if P else None)
+                rc = L.frg_forward_ex(C.byref(a))
         if rc < 0:
             raise RuntimeError(f"frg_forward failed ({rc}): {_lib.last_error()}")
         return rc, out_color, radii, bufs.geom, bufs.binning, bufs.img
@@ -187,7 +209,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, keep_mask=None):
         s = raster_settings
         native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh,
@@ -195,13 +217,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if s.debug:
             saved = _snapshot(native_args)
             try:
-                out = _C.rasterize_gaussians(*native_args)
+                out = _C.rasterize_gaussians(*native_args, keep_mask=keep_mask)
             except Exception:
                 torch.save(saved, "snapshot_fw.dump")  # same replay fixture as the reference (:83-90)
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            out = _C.rasterize_gaussians(*native_args)
+            out = _C.rasterize_gaussians(*native_args, keep_mask=keep_mask)
         num_rendered, color, radii, geom, binning, img = out
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
@@ -227,13 +249,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             grads = _C.rasterize_gaussians_backward(*native_args)
         g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots = grads
-        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, keep_mask=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, keep_mask)
 
 
 class GaussianRasterizer(nn.Module):
@@ -250,7 +272,9 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, keep_mask=None):
+        """keep_mask: extension over the reference signature (optional bool [P]); see
+        _NativeOps.rasterize_gaussians."""
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         have_sr = scales is not None and rotations is not None
@@ -266,4 +290,4 @@ class GaussianRasterizer(nn.Module):
             empty if scales is None else scales,
             empty if rotations is None else rotations,
             empty if cov3D_precomp is None else cov3D_precomp,
-            self.raster_settings)
+            self.raster_settings, keep_mask)

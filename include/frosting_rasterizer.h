@@ -95,6 +95,36 @@ int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc
                          float* out_color, int* radii, int instance_capacity, void* hip_stream);
 int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rendered);
 
+/* Every forward option in one call.  Fields up to hip_stream mean what the frg_forward
+ * parameters of the same name mean; set struct_size = sizeof(frg_forward_args).
+ *   instance_capacity > 0   deferred counters (frg_forward_deferred); `debug` is then ignored.
+ *   keep_mask != NULL       one byte per Gaussian; 0 = leave it out of this view exactly as if it had
+ *                           been culled (radii 0, no instances, zero gradient rows).  This is Frosting's
+ *                           mesh occlusion culling (frosting_scene/frosting_model.py:1564-1586) as a skip
+ *                           flag: the reference compacts five per-Gaussian tensors with a boolean mask
+ *                           before every render; the result for the kept Gaussians is bit-identical
+ *                           (compaction preserves index order, hence the depth-tie order). */
+typedef struct frg_forward_args {
+    size_t struct_size;
+    frg_alloc_fn geometry_alloc, binning_alloc, image_alloc;
+    void* user;
+    int P, D, M;
+    const float* background;
+    int width, height;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales;
+    float scale_modifier;
+    const float *rotations, *cov3D_precomp, *viewmatrix, *projmatrix, *cam_pos;
+    float tan_fovx, tan_fovy;
+    int prefiltered;
+    float* out_color;
+    int* radii;
+    int debug;
+    void* hip_stream;
+    int instance_capacity;
+    const unsigned char* keep_mask;
+} frg_forward_args;
+int frg_forward_ex(const frg_forward_args* args);
+
 /* Bytes of scratch frg_backward needs for a forward that returned R instances. */
 size_t frg_backward_workspace_bytes(int P, int R);
 

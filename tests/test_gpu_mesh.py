@@ -101,3 +101,55 @@ def test_nvdiffrast_module_shim(gpu_device):
                                resolution=[32, 32])
     bary_coords, zbuf, pix_to_face = rast_out[..., :2], rast_out[..., 2], rast_out[..., 3].int()   # nvdiffrast.py:54
     assert rast_out.shape == (1, 32, 32, 4) and (pix_to_face.unique() - 1).tolist() == [-1, 0]
+
+
+def test_keep_mask_equals_boolean_compaction(gpu_device):
+    """Occlusion culling as a skip flag (frg_forward_ex keep_mask) against the reference's way --
+    boolean compaction of every per-Gaussian tensor before the render
+    (frosting_scene/frosting_model.py:1564-1586): same image and radii bit for bit, same gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from helpers import settings_for
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("mini", 4, P=6000)
+    g = torch.Generator().manual_seed(11)
+    keep = (torch.rand(scene.P, generator=g) < 0.6).to(dev)
+    sc = scene.to(dev)
+    rast = GaussianRasterizer(settings_for(cam, bg, scene.sh_degree, dev))
+    names = ("means3D", "opacities", "shs", "scales", "rotations")
+
+    def leaves(sel):
+        out = {}
+        for n in names:
+            t = getattr(sc, n)
+            out[n] = (t[sel] if sel is not None else t).clone().requires_grad_(True)
+        return out
+
+    a = leaves(keep)                       # the reference's way: compact, then render
+    m2d_a = torch.zeros_like(a["means3D"], requires_grad=True)
+    img_a, radii_a = rast(means3D=a["means3D"], means2D=m2d_a, opacities=a["opacities"], shs=a["shs"],
+                          scales=a["scales"], rotations=a["rotations"])
+    b = leaves(None)                       # ours: full tensors + skip flag
+    m2d_b = torch.zeros_like(b["means3D"], requires_grad=True)
+    img_b, radii_b = rast(means3D=b["means3D"], means2D=m2d_b, opacities=b["opacities"], shs=b["shs"],
+                          scales=b["scales"], rotations=b["rotations"], keep_mask=keep)
+    assert torch.equal(img_a, img_b)
+    assert torch.equal(radii_b[keep], radii_a) and int(radii_b[~keep].abs().max()) == 0
+    assert int((radii_a > 0).sum()) > 100
+    gpix, _ = scenes.l1_target_grad(img_a.detach().cpu(), 5)
+    gpix = gpix.to(dev)
+    img_a.backward(gpix)
+    img_b.backward(gpix)
+    # gradients: same sums, but the per-Gaussian reduction groups 64 consecutive Gaussians per wave, so
+    # its association order follows the indexing (compacted vs full) -- equal to float32 rounding
+    from helpers import rel_l2
+    for n in names:
+        assert rel_l2(b[n].grad[keep], a[n].grad) < 5e-5, n
+        assert float(b[n].grad[~keep].abs().max()) == 0.0, n
+    assert rel_l2(m2d_b.grad[keep], m2d_a.grad) < 5e-5
+    # uint8 masks work too; a bad shape is rejected
+    img_c, _ = rast(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs,
+                    scales=sc.scales, rotations=sc.rotations, keep_mask=keep.to(torch.uint8))
+    assert torch.equal(img_c, img_a)
+    with pytest.raises(RuntimeError, match="keep_mask"):
+        rast(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs,
+             scales=sc.scales, rotations=sc.rotations, keep_mask=keep[:-1])

@@ -36,30 +36,41 @@ bg = torch.zeros(3, device=dev)
 verts_d, faces_d, cell_d = verts.to(dev), faces.to(dev), cell.to(dev)
 ctx = M.RasterizeGLContext()
 
-def step():
+def step(fused):
     vis = M.visible_faces(verts_d, faces_d, cam.projmatrix, 1056, 1600, ctx)
     keep = M.occlusion_mask(cell_d, vis, F)
     e = torch.Tensor([])
-    args = (bg, scene.means3D[keep], e, scene.opacities[keep], scene.scales[keep], scene.rotations[keep], 1.0, e,
-            cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, 1056, 1600, scene.shs[keep], 3, cam.campos, False, False)
-    out = _C.rasterize_gaussians(*args)
+    if fused:   # occlusion mask as a skip flag inside preprocess (frg_forward_ex keep_mask)
+        args = (bg, scene.means3D, e, scene.opacities, scene.scales, scene.rotations, 1.0, e,
+                cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, 1056, 1600, scene.shs, 3, cam.campos, False, False)
+        out = _C.rasterize_gaussians(*args, keep_mask=keep)
+    else:       # the reference's way: boolean compaction of five per-Gaussian tensors, then render
+        args = (bg, scene.means3D[keep], e, scene.opacities[keep], scene.scales[keep], scene.rotations[keep], 1.0, e,
+                cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, 1056, 1600, scene.shs[keep], 3, cam.campos, False, False)
+        out = _C.rasterize_gaussians(*args)
     return vis, keep, out, args
 
-vis, keep, out, args = step()
-gpix = (torch.sign(out[1] - 0.5) / out[1].numel())
-torch.cuda.synchronize()
-tm, tr, tb = [], [], []
-for _ in range(8):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    vis = M.visible_faces(verts_d, faces_d, cam.projmatrix, 1056, 1600, ctx)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    vis, keep, out, args = step()
-    torch.cuda.synchronize(); t2 = time.perf_counter()
-    R, color, radii, geom, binning, img = out
-    bargs = (args[0], args[1], radii, args[2], args[4], args[5], args[6], args[7], args[8], args[9], args[10], args[11],
-             gpix, args[14], args[15], args[16], geom, R, binning, img, False)
-    _C.rasterize_gaussians_backward(*bargs)
-    torch.cuda.synchronize(); t3 = time.perf_counter()
-    tm.append(t1 - t0); tr.append(t2 - t1); tb.append(t3 - t2)
-print(f"C4: P={P} tris={F} visible faces {vis.numel()} ({vis.numel()/F:.3f}) kept Gaussians {int(keep.sum())} R={out[0]}")
-print(f"  mesh raster + unique: {1e3*np.median(tm):.3f} ms ; cull+compact+forward: {1e3*np.median(tr):.3f} ms ; backward: {1e3*np.median(tb):.3f} ms")
+imgs = {}
+for fused in (False, True):
+    vis, keep, out, args = step(fused)
+    imgs[fused] = out[1].clone()
+    gpix = (torch.sign(out[1] - 0.5) / out[1].numel())
+    torch.cuda.synchronize()
+    tm, tr, tb = [], [], []
+    for _ in range(8):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        vis = M.visible_faces(verts_d, faces_d, cam.projmatrix, 1056, 1600, ctx)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        vis, keep, out, args = step(fused)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        R, color, radii, geom, binning, img = out
+        bargs = (args[0], args[1], radii, args[2], args[4], args[5], args[6], args[7], args[8], args[9], args[10], args[11],
+                 gpix, args[14], args[15], args[16], geom, R, binning, img, False)
+        _C.rasterize_gaussians_backward(*bargs)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        tm.append(t1 - t0); tr.append(t2 - t1); tb.append(t3 - t2)
+    print(f"C4 ({'skip flag' if fused else 'compaction'}): P={P} tris={F} visible faces {vis.numel()} ({vis.numel()/F:.3f}) "
+          f"kept Gaussians {int(keep.sum())} R={out[0]}")
+    print(f"  mesh raster + unique: {1e3*np.median(tm):.3f} ms ; raster + cull + forward: {1e3*np.median(tr):.3f} ms ; "
+          f"backward: {1e3*np.median(tb):.3f} ms")
+print("images identical:", bool(torch.equal(imgs[False], imgs[True])))
