@@ -92,3 +92,26 @@ def test_drop_in_import_name():
     import diff_gaussian_rasterization as d
     assert d.GaussianRasterizer is GaussianRasterizer
     assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(d._C))
+
+
+def test_extended_entry_points_validate_arguments_without_a_gpu():
+    """Argument checks of the additive entry points run before any HIP call."""
+    import ctypes as C
+    L = _lib.lib()
+    assert C.sizeof(_lib.ForwardArgs) % 8 == 0
+    a = _lib.ForwardArgs()
+    a.struct_size = 8                                     # a caller built against another header
+    assert L.frg_forward_ex(C.byref(a)) == -1 and "struct_size" in _lib.last_error()
+    assert L.frg_forward_ex(None) == -1
+    n = C.c_int(-7)
+    assert L.frg_forward_finish(None, 0, C.byref(n)) == -1 and "pending" in _lib.last_error()
+    # deferred forward needs a positive capacity
+    args = [_lib.ALLOC_FN(lambda u, b: 0)] * 3 + [None, 4, 0, 0, None, 8, 8] + [None] * 4 + [None, 1.0, None, None] + \
+           [None] * 3 + [0.5, 0.5, 0, None, None, 0, None]
+    assert L.frg_forward_deferred(*args) == -1 and "instance_capacity" in _lib.last_error()
+    # SH rebuild: degree / coefficient-count checks
+    assert L.frg_sh_grad_from_views(4, 4, 16, 1, None, None, 0, None, 0, None, None) == -1
+    assert L.frg_sh_grad_from_views(4, 3, 9, 1, None, None, 0, None, 0, None, None) == -1 and "coefficients" in _lib.last_error()
+    assert L.frg_sh_grad_from_views(0, 3, 16, 0, None, None, 0, None, 0, None, None) == 0      # nothing to do
+    assert L.frg_sh_color_grad(0, None, None, None, None, None) == 0
+    assert L.frg_sh_color_grad(4, None, None, None, None, None) == -1
