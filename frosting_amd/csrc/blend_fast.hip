@@ -10,7 +10,7 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
     const int T = vp.gx * vp.gy;
     hipLaunchKernelGGL((blend_fwd_kernel<FRG_EXACT>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H,
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,
-                       out_color);
+                       out_color, img.tile_work);
     return hipGetLastError();
 }
 
@@ -18,9 +18,10 @@ hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const
                                 const float* bg, const float* dL_dpix, float* slots, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, xcd_grid_blocks(T), img.tile_work, img.bwd_order);
     hipLaunchKernelGGL((blend_bwd_kernel<FRG_EXACT>), dim3(xcd_grid_blocks(T)), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H,
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,
-                       img.n_contrib, dL_dpix, slots, img.cutoff);
+                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order);
     return hipGetLastError();
 }
 }  // namespace frg

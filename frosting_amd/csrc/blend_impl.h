@@ -78,7 +78,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 float* __restrict__ out_color)
+                 float* __restrict__ out_color, uint32_t* __restrict__ tile_work)
 {
     using M = BlendMath<EXACT>;
     const int tile = xcd_tile_of_block(blockIdx.x, T);
@@ -153,6 +153,43 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         out_color[plane + pid] = C1 + Tr * bg[1];
         out_color[2 * plane + pid] = C2 + Tr * bg[2];
     }
+    // how deep this tile's list was walked: the backward blend's work per tile, used to
+    // dispatch its long tiles first (bwd_order_kernel)
+    uint32_t deepest = inside ? last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, d, 64));
+    if (lane == 0 && deepest) atomicMax(&tile_work[tile], deepest);
+}
+
+// Workgroup -> tile map of the backward blend.  One wave per tile and 6.6 k tiles of very unequal
+// depth (324..1077 processed entries at C3) on 5 k wave slots: in index order the last, long tiles
+// run alone (makespan ~1.9x the balanced one).  Tiles are bucketed by processed depth (32 entries per
+// bucket, deepest first) inside their XCD band -- neighbouring tiles still share an L2 -- and dealt
+// to workgroups band-major, so workgroup b (XCD b % 8) takes the (b / 8)-th deepest tile of its band.
+static __global__ void __launch_bounds__(1024)
+bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t base[FRG_NUM_XCD * 64], cur[FRG_NUM_XCD * 64];
+    const int tid = threadIdx.x;
+    if (tid < FRG_NUM_XCD * 64) { base[tid] = 0; cur[tid] = 0; }
+    for (int b = tid; b < nblocks; b += 1024) order[b] = 0xFFFFFFFFu;   // padding workgroups
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t k = 63u - min(63u, tile_work[t] >> 5);
+        atomicAdd(&base[xcd_of_tile(t, T) * 64 + k], 1u);
+    }
+    __syncthreads();
+    if (tid < FRG_NUM_XCD) {
+        uint32_t run = 0;
+        for (int k = 0; k < 64; k++) { const uint32_t c = base[tid * 64 + k]; base[tid * 64 + k] = run; run += c; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const int x = xcd_of_tile(t, T);
+        const uint32_t k = 63u - min(63u, tile_work[t] >> 5);
+        const uint32_t pos = base[x * 64 + k] + atomicAdd(&cur[x * 64 + k], 1u);
+        order[pos * FRG_NUM_XCD + x] = (uint32_t)t;
+    }
 }
 
 // 4-bit version for the tile-per-wave backward: bit q <=> quadrant q may be touched
@@ -209,10 +246,10 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff)
+                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order)
 {
     using M = BlendMath<EXACT>;
-    const int tile = xcd_tile_of_block(blockIdx.x, T);
+    const int tile = order ? (int)order[blockIdx.x] : xcd_tile_of_block(blockIdx.x, T);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;

@@ -81,6 +81,8 @@ struct ImageState {
     uint2* ranges;           // per tile [start,end) into point_list; (0,0) when empty
     uint32_t* tile_count;    // zeroed every forward; counted by preprocess
     uint32_t* tile_fill;     // zeroed every forward; scatter cursor
+    uint32_t* tile_work;     // zeroed every forward; list entries the forward blend walked (max over the tile's pixels)
+    uint32_t* bwd_order;     // [xcd_grid_blocks(T)] workgroup -> tile map of the backward blend (longest tiles first)
     Counters* counters;      // zeroed every forward
     uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
     uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts -> scatter bases
@@ -102,8 +104,10 @@ struct ImageState {
         s.zero_begin = o;
         s.tile_count = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
         s.tile_fill = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
+        s.tile_work = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
+        s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
         s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
         s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;
         s.bin_matrix = nullptr; s.seg_sums = nullptr;
@@ -170,6 +174,13 @@ __device__ __forceinline__ int xcd_tile_of_block(int b, int T)
     const int mine = per + (xcd < rem ? 1 : 0);
     if (k < mine) return start + k;
     return -1;  // padding block of the rounded-up grid
+}
+// inverse of xcd_tile_of_block: the XCD whose band holds tile t
+__device__ __forceinline__ int xcd_of_tile(int t, int T)
+{
+    const int per = T / FRG_NUM_XCD, rem = T % FRG_NUM_XCD;
+    const int cut = rem * (per + 1);
+    return t < cut ? t / (per + 1) : rem + (t - cut) / (per > 0 ? per : 1);
 }
 __host__ inline int xcd_grid_blocks(int T) { return ((T + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD; }
 
