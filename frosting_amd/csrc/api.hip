@@ -437,7 +437,7 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
     if (!means3D || !radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background ||
         !viewmatrix || !projmatrix || !campos)
         return fail(FRG_EINVAL, "null required pointer");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+    if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
         return fail(FRG_EINVAL, "null gradient output");
     if ((scales && (!dL_dscale || !dL_drot || !rotations)))
         return fail(FRG_EINVAL, "null gradient output for a provided input");

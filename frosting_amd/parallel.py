@@ -186,7 +186,7 @@ class ViewParallelRasterizer:
         self.exchange = self.exchanges[0]
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.dev)
         # rank-local (not exchanged) backward outputs
-        self.dL_dmeans2D, self.dL_dconic, self.dL_dcolors, self.dL_dcov3D = f(P, 3), f(P, 4), f(P, 3), f(P, 6)
+        self.dL_dmeans2D, self.dL_dcolors, self.dL_dcov3D = f(P, 3), f(P, 3), f(P, 6)
         self.geom, self.binning, self.img, self.work = (_Arena(self.dev) for _ in range(4))
         self.radii = torch.empty(P, dtype=torch.int32, device=self.dev)
         self.out_color = None
@@ -263,7 +263,7 @@ class ViewParallelRasterizer:
                             _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
                             float(cam.tanfovx), float(cam.tanfovy), _p(self.radii),
                             _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
-                            _p(self.dL_dmeans2D), _p(self.dL_dconic), _p(g["opacities"]), _p(self.dL_dcolors),
+                            _p(self.dL_dmeans2D), None, _p(g["opacities"]), _p(self.dL_dcolors),
                             _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
                             _p(work), work.numel(), 0, stream)
         if rc < 0:

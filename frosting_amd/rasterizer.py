@@ -136,7 +136,7 @@ class _NativeOps:
             has_sh = sh is not None and sh.numel() != 0
             has_sr = scales is not None and scales.numel() != 0
             dL_dmeans3D, dL_dmeans2D, dL_dcolors = e(P, 3), e(P, 3), e(P, 3)
-            dL_dconic, dL_dopacity, dL_dcov3D = e(P, 2, 2), e(P, 1), e(P, 6)
+            dL_dopacity, dL_dcov3D = e(P, 1), e(P, 6)   # dL_dconic is an intermediate the reference never returns (:195)
             # rows the kernels do not write (absent input) stay zero, as in the reference's zero-allocated outputs
             dL_dsh = e(P, M, 3) if has_sh else torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
             dL_dscales = e(P, 3) if has_sr else torch.zeros((P, 3), dtype=torch.float32, device=dev)
@@ -154,7 +154,7 @@ class _NativeOps:
                                     _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
                                     float(tan_fovx), float(tan_fovy), _ptr(t["radii"]),
                                     _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(t["dpix"]),
-                                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                                    _ptr(dL_dmeans2D), None, _ptr(dL_dopacity), _ptr(dL_dcolors),
                                     _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh) if has_sh else None,
                                     _ptr(dL_dscales) if has_sr else None, _ptr(dL_drotations) if has_sr else None,
                                     _ptr(workspace), ws_bytes, int(bool(debug)), _stream_ptr(dev))

@@ -134,7 +134,8 @@ size_t frg_backward_workspace_bytes(int P, int R);
  * rasterize_points.cu:151-159).  dL_dmean2D is [P,3] (z stays 0), dL_dconic
  * [P,4] = (a, b, -, c), dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3],
  * dL_dcov3D [P,6], dL_dsh [P,M,3] (ignored when shs==NULL), dL_dscale [P,3],
- * dL_drot [P,4] (ignored when scales==NULL).  dL_dsh may be NULL with shs given: the
+ * dL_drot [P,4] (ignored when scales==NULL).  dL_dconic may be NULL: it is an intermediate that the
+ * reference's binding never hands to Python (rasterize_points.cu:195).  dL_dsh may be NULL with shs given: the
  * SH row is then not materialised (its view-direction term still reaches dL_dmean3D) and
  * the caller rebuilds it from dL_dcolor -- frg_sh_color_grad / frg_sh_grad_from_views below.  Summation order is fixed, so
  * results are bit-reproducible run to run (the reference's atomics are not). */
