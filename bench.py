@@ -100,6 +100,8 @@ def main():
                     help="N>1: 'allreduce' = one all-reduce of all 59 floats per Gaussian; 'factored' = all-reduce of the "
                          "11 non-SH floats + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
                          "every rank (frosting_amd/parallel.py)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo only for functional tests of the multi-rank path on one GPU")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange path on a single-rank RCCL group when launched without torch.distributed.run")
     ap.add_argument("--sync-exchange", action="store_true",
@@ -109,6 +111,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FRG_BENCH_ONE_GPU"):   # functional test: every rank on GPU 0
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the rasterizer has no CPU path")
     dev = torch.device("cuda", local_rank)
@@ -118,7 +122,10 @@ def main():
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 

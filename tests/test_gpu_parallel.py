@@ -157,3 +157,62 @@ def test_deferred_counters_forward_matches_blocking_forward(gpu_device):
     vpr.backward(gpix, 0)
     assert vpr.finish()
     assert torch.equal(img, img0) and torch.equal(vpr.exchange.flat, flat0)
+
+
+def _rank_worker(rank, world, port, factored, P, q):
+    """One rank of a 2-rank job on GPU 0 (gloo carries the collectives: RCCL refuses two ranks per device)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        scene, cam, bg = scenes.config_scene("mini", rank + 1, P=P)       # rank k renders view k + 1
+        vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored)
+        img, _ = vpr.forward(cam.to(dev), bg.to(dev))
+        gpix, _ = scenes.l1_target_grad(img.cpu(), 555 + rank + 1)
+        gpix = gpix.to(dev)
+        for step in range(3):                                              # pipelined protocol, two buffers
+            slot = step % 2
+            vpr.forward(cam.to(dev), bg.to(dev))
+            vpr.wait_exchange(slot)
+            vpr.backward(gpix, slot)
+            vpr.start_exchange(slot)
+        out = [vpr.wait_exchange(s).clone() for s in (0, 1)]
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out[0], out[1])
+        q.put((rank, out[0].cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("factored", [False, True])
+def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
+    import torch.multiprocessing as mp
+    world, P = 2, 5000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, factored, P, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: the same two views rendered one after the other, gradients added
+    dev = gpu_device
+    scene, _, _ = scenes.config_scene("mini", 0, P=P)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, factor_sh=True)
+    grads, _ = _per_view(vpr, "mini", [1, 2], dev, P=P)
+    want = torch.cat([(grads[0][n] + grads[1][n]).reshape(-1) for n in PARAM_ORDER]).cpu()
+    for r in range(world):
+        got = torch.from_numpy(res[r])
+        if factored:   # SH part: in-order sum, bit-exact; dense part: the all-reduce of two terms, exact as well
+            assert torch.equal(got, want)
+        else:
+            torch.testing.assert_close(got, want, rtol=0, atol=0)
+    assert (res[0] == res[1]).all()
