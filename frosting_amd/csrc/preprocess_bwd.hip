@@ -228,7 +228,9 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
         if (dL_dconic) *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
         dL_dopacity[idx] = part[8];
-        dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2];
+        // with shs given and dL_dsh == nullptr the caller wants the factor of the SH gradient instead
+        // (the clamp-masked colour gradient, stored below): see frg_backward in the header
+        if (!(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
     }
 
     // ---- 4. SH path (backward.cu:20-139) ----
@@ -249,6 +251,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
         }
+        if (!dL_dsh && valid) { dL_dcolor[3 * idx] = dRGB[0]; dL_dcolor[3 * idx + 1] = dRGB[1]; dL_dcolor[3 * idx + 2] = dRGB[2]; }
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
         if (visible) {
             wgt[0] = kSH0;

@@ -263,17 +263,23 @@ class ViewParallelRasterizer:
                             _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
                             float(cam.tanfovx), float(cam.tanfovy), _p(self.radii),
                             _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
-                            _p(self.dL_dmeans2D), None, _p(g["opacities"]), _p(self.dL_dcolors),
+                            _p(self.dL_dmeans2D), None, _p(g["opacities"]),
+                            # deferred SH rows: dL_dcolor receives the masked colour gradient = the exchange payload
+                            _p(ex.own_drgb) if defer_sh else _p(self.dL_dcolors),
                             _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
                             _p(work), work.numel(), 0, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
         if ex.factor_sh and (ex._active() if payload is None else payload):
             # this view's share of the factored SH exchange: masked colour gradient + camera centre
-            rc = L.frg_sh_color_grad(self.P, _p(self.geom.buf), _p(self.radii), _p(self.dL_dcolors), _p(ex.own_drgb), stream)
-            if rc < 0:
-                raise RuntimeError(f"frg_sh_color_grad failed ({rc}): {_lib.last_error()}")
-            ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
+            if not defer_sh:   # (with deferred SH rows the backward wrote the payload itself)
+                rc = L.frg_sh_color_grad(self.P, _p(self.geom.buf), _p(self.radii), _p(self.dL_dcolors), _p(ex.own_drgb), stream)
+                if rc < 0:
+                    raise RuntimeError(f"frg_sh_color_grad failed ({rc}): {_lib.last_error()}")
+            tag = (cam.campos.data_ptr(), cam.campos._version)
+            if getattr(ex, "_campos_tag", None) != tag:     # same camera tensor as last time: already there
+                ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
+                ex._campos_tag = tag
         return g
 
     def allreduce_grads(self, slot: int = 0):

@@ -136,8 +136,9 @@ size_t frg_backward_workspace_bytes(int P, int R);
  * dL_dcov3D [P,6], dL_dsh [P,M,3] (ignored when shs==NULL), dL_dscale [P,3],
  * dL_drot [P,4] (ignored when scales==NULL).  dL_dconic may be NULL: it is an intermediate that the
  * reference's binding never hands to Python (rasterize_points.cu:195).  dL_dsh may be NULL with shs given: the
- * SH row is then not materialised (its view-direction term still reaches dL_dmean3D) and
- * the caller rebuilds it from dL_dcolor -- frg_sh_color_grad / frg_sh_grad_from_views below.  Summation order is fixed, so
+ * SH row is then not materialised (its view-direction term still reaches dL_dmean3D) and dL_dcolor
+ * receives the clamp-masked colour gradient (backward.cu:31-34), i.e. the per-Gaussian factor dRGB of
+ * dL_dsh[i][ch] = basis_i * dRGB[ch], from which frg_sh_grad_from_views rebuilds the row.  Summation order is fixed, so
  * results are bit-reproducible run to run (the reference's atomics are not). */
 int frg_backward(int P, int D, int M, int R,
                  const float* background, int width, int height,
