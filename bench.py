@@ -93,6 +93,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
+    ap.add_argument("--tight-binning", action="store_true",
+                    help="time the whole run with frg_set_option('tight_binning', 1): instances that cannot reach alpha >= "
+                         "1/255 anywhere in their tile are dropped when the tile lists are built (outputs bit-identical, "
+                         "lists = order-preserving sub-lists of the reference's).  Without the flag the headline run keeps "
+                         "the reference's exact lists and the tight mode is timed in an extra pass (field 'tight_binning')")
     ap.add_argument("--deferred-counters", action="store_true",
                     help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
                          "which like the reference blocks on a read-back of num_rendered; measured equal at C3")
@@ -134,6 +139,7 @@ def main():
     scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
     _lib.set_option("exact_blend", 1 if args.exact else 0)
     _lib.set_option("profile", 0 if args.no_stage_timers else 1)
+    _lib.set_option("tight_binning", 1 if args.tight_binning else 0)
     vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD if dist else None,
                                  factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters)
     exchanging = dist is not None
@@ -208,6 +214,23 @@ def main():
         drain()
         torch.cuda.synchronize(dev)
         stage_avg = {k: v for k, v in _lib.stage_times().items() if v > 0}
+    tight = None
+    if world == 1 and not exchanging and not args.tight_binning:
+        # informative extra pass, after and outside the timed region: the same steps with tight binning
+        _lib.set_option("profile", 0)
+        _lib.set_option("tight_binning", 1)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt_t = time.perf_counter() - t1
+        _lib.set_option("tight_binning", 0)
+        tight = {"ms_per_step": 1e3 * dt_t / args.steps, "value": args.steps / dt_t, "unit": "views/s",
+                 "note": "option tight_binning=1 (off in the headline run): tile lists without the instances that provably "
+                         "touch no pixel of their tile; image, radii, num_rendered and gradients bit-identical"}
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -237,6 +260,7 @@ def main():
                                      ", overlapped with the next step's render (2 gradient buffers)")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"],
+                       "binning": "tight" if args.tight_binning else "reference-identical tile lists",
                        "counters": "deferred (no host synchronisation inside the step)" if args.deferred_counters
                                    else "blocking 48-byte read-back per forward"},
             "op_hbm": {"algorithmic_bytes_per_view": total_bytes,
@@ -252,6 +276,8 @@ def main():
                                "timed": "hipEvents around this kernel in every timed step"}
             out["stage_ms"] = stage_avg
             out["stage_ms_note"] = "all stages, 5 extra steps after the timed region"
+        if tight:
+            out["tight_binning"] = tight
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, P)

@@ -29,7 +29,8 @@ int fail(int code, const char* fmt, ...)
 std::atomic<int> g_exact_blend{-1};
 std::atomic<int> g_profile{0};
 std::atomic<int> g_profile_stage{-1};  // -1: every stage; k: only stage k gets events (each record costs ~3 us of stream time)
-std::atomic<int> g_global_bins{0};  // test hook: force the large-image (global-atomic) binning path
+std::atomic<int> g_global_bins{0};
+std::atomic<int> g_tight_binning{0};  // test hook: force the large-image (global-atomic) binning path
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
 // recorded on the caller's stream between the kernels of one forward / backward;
@@ -167,6 +168,7 @@ frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_
     vp.W = width; vp.H = height;
     vp.gx = (width + FRG_TILE - 1) / FRG_TILE; vp.gy = (height + FRG_TILE - 1) / FRG_TILE;
     vp.D = D; vp.M = M;
+    vp.tight = g_tight_binning.load();
     return vp;
 }
 
@@ -187,6 +189,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "profile") == 0) return g_profile.exchange(value ? 1 : 0);
     if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.exchange(value < 0 || value >= ST_COUNT ? -1 : value);
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -216,6 +219,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "profile") == 0) return g_profile.load();
     if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.load();
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
+    if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 

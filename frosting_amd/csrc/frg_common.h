@@ -148,6 +148,7 @@ struct ViewParams {
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int W, H, gx, gy;
     int D, M;   // active SH degree, coefficients per channel in memory
+    int tight;  // 1: binning keeps only (Gaussian, tile) instances that can reach alpha >= 1/255 in the tile
 };
 struct ViewMats {
     float view[16];
@@ -210,7 +211,8 @@ __device__ __forceinline__ void tile_rect(float px, float py, int max_radius, in
 // d^2 <= 512), so the cull never removes a pixel the reference would have blended.
 // Evaluated WITHOUT contraction so that the blend kernels and the per-Gaussian backward
 // (which re-derives which quadrant slots exist) agree bit for bit.
-__device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx0, int qy0)
+template <int EXTENT>
+__device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, int qy0)
 {
 #pragma clang fp contract(off)
     const float o = co.w;
@@ -219,7 +221,7 @@ __device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx
     // not a proper positive-definite conic (or not finite): no bound, keep
     if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f) || !(a < 3.0e38f) || !(c < 3.0e38f)) return true;
     const float thr = __logf(255.0f * o) + 0.02f;
-    const float xlo = (float)qx0 - x, ylo = (float)qy0 - y, xhi = xlo + 7.0f, yhi = ylo + 7.0f;
+    const float xlo = (float)qx0 - x, ylo = (float)qy0 - y, xhi = xlo + (float)EXTENT, yhi = ylo + (float)EXTENT;
     if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return true;  // centre inside: Q = 0
     const float ia = 1.0f / a, ic = 1.0f / c;
     float best = 3.0e38f;
@@ -234,5 +236,8 @@ __device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx
     }
     return !(0.5f * 0.999f * best > thr);
 }
+__device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx0, int qy0) { return rect_hit<7>(x, y, co, qx0, qy0); }
+// the same bound over a whole 16x16 tile (a superset of its four quadrants)
+__device__ __forceinline__ bool tile_hit(float x, float y, float4 co, int tx, int ty) { return rect_hit<FRG_TILE - 1>(x, y, co, tx * FRG_TILE, ty * FRG_TILE); }
 
 }  // namespace frg

@@ -61,7 +61,7 @@ __device__ __forceinline__ void wave_for_each_instance(uint32_t touched, int x0,
             const uint32_t k = s - lds_start[owner];
             const uint32_t w = (uint32_t)info.z;
             const uint32_t ry = k / w, rx = k - ry * w;
-            f(owner, (info.y + (int)ry) * gx + info.x + (int)rx, (uint32_t)info.w);
+            f(owner, (info.y + (int)ry) * gx + info.x + (int)rx, info.x + (int)rx, info.y + (int)ry, (uint32_t)info.w);
         }
     }
 }
@@ -201,6 +201,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
+    __shared__ float2 emit_xy[FRG_BIN_THREADS];   // tight binning: centre and conic/opacity of the lane's Gaussian
+    __shared__ float4 emit_co[FRG_BIN_THREADS];
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
@@ -227,8 +229,17 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
         {   // per-tile instance counts
             const int wave = threadIdx.x >> 6;
+            if (vp.tight && touched) {
+                const float4 g4 = xydr[idx];
+                emit_xy[threadIdx.x] = make_float2(g4.x, g4.y);
+                emit_co[threadIdx.x] = conic_opacity[idx];
+            }
             wave_for_each_instance(touched, rx0, ry0, rw, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
-                                   [&](int, int t, uint32_t) {
+                                   [&](int owner, int t, int tx, int ty, uint32_t) {
+                                       if (vp.tight) {
+                                           const float2 c2 = emit_xy[wave * 64 + owner];
+                                           if (!tile_hit(c2.x, c2.y, emit_co[wave * 64 + owner], tx, ty)) return;
+                                       }
                                        if (LDS_BINS) atomicAdd(&lds_bins[t], 1u);   // ds_add_u32
                                        else atomicAdd(&tile_count[t], 1u);
                                    });
@@ -461,13 +472,15 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ chunk_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ bin_matrix,
                const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs,
-               const Counters* __restrict__ counters)
+               const Counters* __restrict__ counters, const float4* __restrict__ conic_opacity, int tight)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     if (counters->overflow) return;   // wave-uniform: the binning buffer is too small for this frame
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
+    __shared__ float2 emit_xy[FRG_BIN_THREADS];
+    __shared__ float4 emit_co[FRG_BIN_THREADS];
     const int T = gx * gy;
     if (LDS_BINS) {
         const uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
@@ -487,11 +500,16 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
             const float4 g = xydr[idx];
             tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
             dbits = __float_as_uint(g.z);
+            if (tight) { emit_xy[threadIdx.x] = make_float2(g.x, g.y); emit_co[threadIdx.x] = conic_opacity[idx]; }
         }
         const int wave = threadIdx.x >> 6;
         const uint32_t idx0 = (uint32_t)(c * FRG_BIN_THREADS + wave * 64);
         wave_for_each_instance(touched, x0, y0, x1 - x0, dbits, emit_start + wave * 68, emit_info + wave * 64, gx,
-                               [&](int owner, int t, uint32_t depth_bits) {
+                               [&](int owner, int t, int tx, int ty, uint32_t depth_bits) {
+                                   if (tight) {
+                                       const float2 c2 = emit_xy[wave * 64 + owner];
+                                       if (!tile_hit(c2.x, c2.y, emit_co[wave * 64 + owner], tx, ty)) return;
+                                   }
                                    uint32_t pos;
                                    if (LDS_BINS) pos = atomicAdd(&lds_bins[t], 1u);             // ds_add_rtn_u32
                                    else pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
@@ -580,10 +598,10 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
         hipError_t e = allow_big_lds(scatter_kernel<true>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(scatter_kernel<true>, dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp.gx, vp.gy, radii, g.xydr,
-                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters);
+                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters, g.conic_opacity, vp.tight);
     } else {
         hipLaunchKernelGGL(scatter_kernel<false>, dim3(nb), dim3(FRG_BIN_THREADS), 0, s, P, vp.gx, vp.gy, radii, g.xydr,
-                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters);
+                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters, g.conic_opacity, vp.tight);
     }
     return hipGetLastError();
 }

@@ -45,6 +45,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float* __restrict__ shs, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                       const float4* __restrict__ xydr, const float4* __restrict__ rgb_clamped,
+                      const float4* __restrict__ conic_opacity, int tight,
                       const uint32_t* __restrict__ point_offsets, const uint2* __restrict__ cutoff,
                       const float* __restrict__ slots,
                       float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
@@ -85,6 +86,14 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     own_start[lane] = valid ? base - wave_base : S;
     if (lane == 0) own_start[64] = S;
     own_info[lane] = make_int4(x0, y0, x1 - x0, (int)__float_as_uint(g.z));
+    // tight binning: slots of instances that were never binned (tile_hit false) hold nothing; the
+    // owner's centre and conic sit in the (still unused) SH transpose buffer during this phase
+    float4* own_co = shbuf;                                         // [64]
+    float2* own_xy = reinterpret_cast<float2*>(shbuf + 64);         // [64]
+    if (tight) {
+        own_co[lane] = visible ? conic_opacity[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        own_xy[lane] = make_float2(g.x, g.y);
+    }
 #pragma unroll
     for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
     wave_fence();
@@ -106,10 +115,13 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             const uint32_t k = s - own_start[owner];
             const uint32_t w = (uint32_t)info.z;
             const uint32_t ry = k / w, rx = k - ry * w;
-            const uint2 cut = cutoff[(info.y + (int)ry) * vp.gx + info.x + (int)rx];
+            const int tx = info.x + (int)rx, ty = info.y + (int)ry;
+            const uint2 cut = cutoff[ty * vp.gx + tx];
             const uint32_t dbits = (uint32_t)info.w, gid = (uint32_t)(idx0 + owner);
+            bool binned = true;
+            if (tight) { const float2 c2 = own_xy[owner]; binned = tile_hit(c2.x, c2.y, own_co[owner], tx, ty); }
             // processed by the blend backward iff (depth, index) <= the tile's cutoff key
-            if (dbits < cut.x || (dbits == cut.x && gid <= cut.y)) {
+            if (binned && (dbits < cut.x || (dbits == cut.x && gid <= cut.y))) {
                 const float* sp = slots + (size_t)(wave_base + s) * FRG_SLOT_FLOATS;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
@@ -433,12 +445,12 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
     if (sh16)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,
                            in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
-                           g.rgb_clamped, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
+                           g.rgb_clamped, g.conic_opacity, vp.tight, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
                            o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
     else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,
                            in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
-                           g.rgb_clamped, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
+                           g.rgb_clamped, g.conic_opacity, vp.tight, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
                            o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
     return hipGetLastError();
 }

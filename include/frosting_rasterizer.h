@@ -160,6 +160,12 @@ int frg_backward(int P, int D, int M, int R,
  * frg_stage_times; "profile_stage": k in 0..6 restricts the events to stage k (each event
  * record costs a few microseconds of stream time), -1 (default) = every stage.  "global_bins": 1 forces the binning path used for images with
  * more than 20480 tiles (global atomics instead of LDS histograms; test hook).
+ * "tight_binning": 1 = a (Gaussian, tile) instance is only put on the tile's list if the Gaussian can
+ * reach alpha >= 1/255 somewhere in the tile (the closed-form bound the blend kernels use per 8x8
+ * quadrant, taken over the 16x16 tile); the reference lists every tile of the 3-sigma square
+ * (forward.cu:236-255), about twice as many.  num_rendered, radii, the image and all gradients are
+ * bit-identical either way; the tile lists become order-preserving sub-lists of the reference's.
+ * Default 0: lists identical to the reference's, entry for entry.
  * Returns the previous value or FRG_EINVAL for an unknown name. */
 int frg_set_option(const char* name, int value);
 int frg_get_option(const char* name);

@@ -16,6 +16,7 @@ dev = torch.device("cuda:0")
 scene, cam, bg = scenes.config_scene(cfg, 0, P=P)
 _lib.set_option("exact_blend", exact)
 _lib.set_option("profile", 1)
+_lib.set_option("tight_binning", int(os.environ.get("TIGHT", "0")))
 (R, color, radii, geom, binning, img), args = Hh.run_ours_native(scene, cam, bg, dev)
 gpix, _ = scenes.l1_target_grad(color.cpu(), 7)
 gpix = gpix.to(dev)
