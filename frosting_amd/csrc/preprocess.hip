@@ -184,7 +184,7 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool LDS_BINS, bool SH16>
+template <bool LDS_BINS, bool SH16, bool TIGHT>
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
 preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
@@ -201,8 +201,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
-    __shared__ float2 emit_xy[FRG_BIN_THREADS];   // tight binning: centre and conic/opacity of the lane's Gaussian
-    __shared__ float4 emit_co[FRG_BIN_THREADS];
+    __shared__ float2 emit_xy[TIGHT ? FRG_BIN_THREADS : 1];   // tight binning: centre and conic/opacity of the lane's Gaussian
+    __shared__ float4 emit_co[TIGHT ? FRG_BIN_THREADS : 1];
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
@@ -229,14 +229,14 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
         {   // per-tile instance counts
             const int wave = threadIdx.x >> 6;
-            if (vp.tight && touched) {
+            if (TIGHT && touched) {
                 const float4 g4 = xydr[idx];
                 emit_xy[threadIdx.x] = make_float2(g4.x, g4.y);
                 emit_co[threadIdx.x] = conic_opacity[idx];
             }
             wave_for_each_instance(touched, rx0, ry0, rw, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
                                    [&](int owner, int t, int tx, int ty, uint32_t) {
-                                       if (vp.tight) {
+                                       if (TIGHT) {
                                            const float2 c2 = emit_xy[wave * 64 + owner];
                                            if (!tile_hit(c2.x, c2.y, emit_co[wave * 64 + owner], tx, ty)) return;
                                        }
@@ -466,21 +466,21 @@ colbase_kernel(int T, int nrows, uint32_t* __restrict__ bin_matrix, const uint32
 // The order inside a tile segment is arbitrary here; the LDS sort orders by
 // (depth, index), which equals the reference's stable sort of index-ordered keys
 // (rasterizer_impl.cu:98-108, :303-308).
-template <bool LDS_BINS>
+template <bool LDS_BINS, bool TIGHT>
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
 scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float4* __restrict__ xydr,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ chunk_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ bin_matrix,
                const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs,
-               const Counters* __restrict__ counters, const float4* __restrict__ conic_opacity, int tight)
+               const Counters* __restrict__ counters, const float4* __restrict__ conic_opacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     if (counters->overflow) return;   // wave-uniform: the binning buffer is too small for this frame
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
-    __shared__ float2 emit_xy[FRG_BIN_THREADS];
-    __shared__ float4 emit_co[FRG_BIN_THREADS];
+    __shared__ float2 emit_xy[TIGHT ? FRG_BIN_THREADS : 1];
+    __shared__ float4 emit_co[TIGHT ? FRG_BIN_THREADS : 1];
     const int T = gx * gy;
     if (LDS_BINS) {
         const uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
@@ -500,13 +500,13 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
             const float4 g = xydr[idx];
             tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
             dbits = __float_as_uint(g.z);
-            if (tight) { emit_xy[threadIdx.x] = make_float2(g.x, g.y); emit_co[threadIdx.x] = conic_opacity[idx]; }
+            if (TIGHT) { emit_xy[threadIdx.x] = make_float2(g.x, g.y); emit_co[threadIdx.x] = conic_opacity[idx]; }
         }
         const int wave = threadIdx.x >> 6;
         const uint32_t idx0 = (uint32_t)(c * FRG_BIN_THREADS + wave * 64);
         wave_for_each_instance(touched, x0, y0, x1 - x0, dbits, emit_start + wave * 68, emit_info + wave * 64, gx,
                                [&](int owner, int t, int tx, int ty, uint32_t depth_bits) {
-                                   if (tight) {
+                                   if (TIGHT) {
                                        const float2 c2 = emit_xy[wave * 64 + owner];
                                        if (!tile_hit(c2.x, c2.y, emit_co[wave * 64 + owner], tx, ty)) return;
                                    }
@@ -547,16 +547,16 @@ static hipError_t allow_big_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS_BINS, bool SH16>
+template <bool LDS_BINS, bool SH16, bool TIGHT>
 static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
                                      const ImageState& img, int prefiltered, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
     const size_t lds = LDS_BINS ? (size_t)T * 4 : 0;
-    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SH16>, lds);
+    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SH16, TIGHT>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SH16>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
+    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SH16, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
@@ -568,10 +568,11 @@ hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& i
 {
     // float4-streamed SH needs the reference's usual layout: 16 coefficients per channel, 16-byte aligned
     const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0);
-    if (img.lds_bins) return sh16 ? launch_pre_variant<true, true>(P, vp, in, radii, g, img, prefiltered, s)
-                                  : launch_pre_variant<true, false>(P, vp, in, radii, g, img, prefiltered, s);
-    return sh16 ? launch_pre_variant<false, true>(P, vp, in, radii, g, img, prefiltered, s)
-                : launch_pre_variant<false, false>(P, vp, in, radii, g, img, prefiltered, s);
+#define FRG_PRE(L, S) (vp.tight ? launch_pre_variant<L, S, true>(P, vp, in, radii, g, img, prefiltered, s) \
+                                : launch_pre_variant<L, S, false>(P, vp, in, radii, g, img, prefiltered, s))
+    if (img.lds_bins) return sh16 ? FRG_PRE(true, true) : FRG_PRE(true, false);
+    return sh16 ? FRG_PRE(false, true) : FRG_PRE(false, false);
+#undef FRG_PRE
 }
 
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s)
@@ -593,16 +594,19 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
+#define FRG_SCATTER(L, TI, LDS)                                                                                          \
+    hipLaunchKernelGGL((scatter_kernel<L, TI>), dim3(nb), dim3(FRG_BIN_THREADS), LDS, s, P, vp.gx, vp.gy, radii, g.xydr,    \
+                       g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs,  \
+                       img.counters, g.conic_opacity)
     if (img.lds_bins) {
         const size_t lds = (size_t)T * 4;
-        hipError_t e = allow_big_lds(scatter_kernel<true>, lds);
+        hipError_t e = vp.tight ? allow_big_lds(scatter_kernel<true, true>, lds) : allow_big_lds(scatter_kernel<true, false>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(scatter_kernel<true>, dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp.gx, vp.gy, radii, g.xydr,
-                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters, g.conic_opacity, vp.tight);
+        if (vp.tight) FRG_SCATTER(true, true, lds); else FRG_SCATTER(true, false, lds);
     } else {
-        hipLaunchKernelGGL(scatter_kernel<false>, dim3(nb), dim3(FRG_BIN_THREADS), 0, s, P, vp.gx, vp.gy, radii, g.xydr,
-                           g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs, img.counters, g.conic_opacity, vp.tight);
+        if (vp.tight) FRG_SCATTER(false, true, 0); else FRG_SCATTER(false, false, 0);
     }
+#undef FRG_SCATTER
     return hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool SH16>
+template <bool SH16, bool TIGHT>
 __global__ void __launch_bounds__(BWD_THREADS, 4)
 preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
@@ -45,7 +45,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float* __restrict__ shs, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                       const float4* __restrict__ xydr, const float4* __restrict__ rgb_clamped,
-                      const float4* __restrict__ conic_opacity, int tight,
+                      const float4* __restrict__ conic_opacity,
                       const uint32_t* __restrict__ point_offsets, const uint2* __restrict__ cutoff,
                       const float* __restrict__ slots,
                       float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
@@ -90,7 +90,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // owner's centre and conic sit in the (still unused) SH transpose buffer during this phase
     float4* own_co = shbuf;                                         // [64]
     float2* own_xy = reinterpret_cast<float2*>(shbuf + 64);         // [64]
-    if (tight) {
+    if (TIGHT) {
         own_co[lane] = visible ? conic_opacity[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         own_xy[lane] = make_float2(g.x, g.y);
     }
@@ -119,7 +119,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             const uint2 cut = cutoff[ty * vp.gx + tx];
             const uint32_t dbits = (uint32_t)info.w, gid = (uint32_t)(idx0 + owner);
             bool binned = true;
-            if (tight) { const float2 c2 = own_xy[owner]; binned = tile_hit(c2.x, c2.y, own_co[owner], tx, ty); }
+            if (TIGHT) { const float2 c2 = own_xy[owner]; binned = tile_hit(c2.x, c2.y, own_co[owner], tx, ty); }
             // processed by the blend backward iff (depth, index) <= the tile's cutoff key
             if (binned && (dbits < cut.x || (dbits == cut.x && gid <= cut.y))) {
                 const float* sp = slots + (size_t)(wave_base + s) * FRG_SLOT_FLOATS;
@@ -442,16 +442,14 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
     const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(o.dL_dsh) % 16 == 0);
-    if (sh16)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,
-                           in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
-                           g.rgb_clamped, g.conic_opacity, vp.tight, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
-                           o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
-    else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,
-                           in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,
-                           g.rgb_clamped, g.conic_opacity, vp.tight, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic, o.dL_dopacity,
-                           o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot);
+#define FRG_PBW(S16, TI)                                                                                              \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<S16, TI>), grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,          \
+                       in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
+                       g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic,      \
+                       o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot)
+    if (sh16) { if (vp.tight) FRG_PBW(true, true); else FRG_PBW(true, false); }
+    else      { if (vp.tight) FRG_PBW(false, true); else FRG_PBW(false, false); }
+#undef FRG_PBW
     return hipGetLastError();
 }
 
