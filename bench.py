@@ -162,11 +162,15 @@ def main():
         counter[0] += 1
         vpr.forward(cam_d, bg_d)
         if exchanging and not args.sync_exchange:
-            vpr.wait_exchange(slot)          # the exchange launched two steps ago on this buffer
+            # the exchange launched two steps ago on this buffer: its collectives are waited for here, its
+            # SH rebuild runs on a side stream under the backward below
+            vpr.prefetch_exchange(slot)
         vpr.backward(gpix, slot)             # writes straight into the flat gradient buffer
         if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
             vpr.forward(cam_d, bg_d, deferred=False)
             vpr.backward(gpix, slot)
+        if exchanging and not args.sync_exchange:
+            vpr.wait_exchange(slot)          # join the rebuild before this buffer's collectives start again
         if exchanging:
             vpr.start_exchange(slot)
             if args.sync_exchange:

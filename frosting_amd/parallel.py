@@ -121,18 +121,53 @@ class GradientExchange:
     def wait(self):
         """Make the current stream (CPU backends: the caller) wait for the pending collectives;
         in the factored plan, then rebuild the summed SH gradient on the current stream."""
-        import torch.distributed as dist
+        self.join()
         if self._works:
-            for w in self._works:
-                w.wait()
-            self._works = []
-            if self.factor_sh:
-                if self.means3D is None:
-                    raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
-                self.sh_reducer(self)
-            if self.average:
-                self.flat.mul_(1.0 / dist.get_world_size(self.group))
+            self._finish_on_current_stream()
         return self.flat
+
+    def _finish_on_current_stream(self):
+        import torch.distributed as dist
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.factor_sh:
+            if self.means3D is None:
+                raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
+            self.sh_reducer(self)
+        if self.average:
+            self.flat.mul_(1.0 / dist.get_world_size(self.group))
+
+    def wait_on_side_stream(self):
+        """GPU, factored plan: the current stream waits for the pending collectives (so the dense part
+        may be overwritten by the next backward), but the SH rebuild -- an HBM-bound 0.15 ms kernel that
+        only touches the SH rows and the gathered colour gradients -- goes to a side stream ordered after
+        what the caller has enqueued so far, and overlaps what it enqueues next (the backward blend is
+        VALU bound).  join() / wait() orders the caller's stream after it: call it before the exchange of
+        this buffer is started again and before the SH rows are read."""
+        if not self._works:
+            return
+        if not self.factor_sh or self.average or self.flat.device.type != "cuda":
+            self._finish_on_current_stream()
+            return
+        if self.means3D is None:
+            raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.flat.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self._side):
+            self.sh_reducer(self)
+            self._joined = torch.cuda.Event()
+            self._joined.record(self._side)
+
+    def join(self):
+        ev = getattr(self, "_joined", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.flat.device).wait_event(ev)
+            self._joined = None
 
 
 class _Arena:
@@ -289,6 +324,12 @@ class ViewParallelRasterizer:
     def start_exchange(self, slot: int):
         """Launch the all-reduce of buffer `slot` behind its backward; returns immediately."""
         return self.exchanges[slot].start()
+
+    def prefetch_exchange(self, slot: int):
+        """Finish the pending exchange of buffer `slot` with the SH rebuild on a side stream (see
+        GradientExchange.wait_on_side_stream); the dense gradients may be overwritten right away, a
+        later wait_exchange(slot) joins the rebuild.  Call between forward() and backward(.., slot)."""
+        self.exchanges[slot].wait_on_side_stream()
 
     def wait_exchange(self, slot: int):
         """Order the current stream after the pending all-reduce of buffer `slot` (call before

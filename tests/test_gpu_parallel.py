@@ -96,6 +96,8 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
             gpix = gpix.to(dev)
             for step in range(4):                    # two buffers, exchange of step k waited at step k+2
                 slot = step % 2
+                if step % 2:
+                    vpr.prefetch_exchange(slot)      # side-stream completion, joined by wait_exchange below
                 vpr.forward(cam.to(dev), bg.to(dev))
                 vpr.wait_exchange(slot)
                 vpr.backward(gpix, slot)
@@ -176,8 +178,9 @@ def _rank_worker(rank, world, port, factored, P, q):
         for step in range(3):                                              # pipelined protocol, two buffers
             slot = step % 2
             vpr.forward(cam.to(dev), bg.to(dev))
-            vpr.wait_exchange(slot)
-            vpr.backward(gpix, slot)
+            vpr.prefetch_exchange(slot)                                    # SH rebuild on a side stream ...
+            vpr.backward(gpix, slot)                                       # ... under this backward
+            vpr.wait_exchange(slot)                                        # joined before the buffer is exchanged again
             vpr.start_exchange(slot)
         out = [vpr.wait_exchange(s).clone() for s in (0, 1)]
         torch.cuda.synchronize(dev)
