@@ -1,0 +1,85 @@
+// Fused Adam step over the flat per-Gaussian parameter layout (the step
+// right after the backward / the gradient exchange).
+//
+// Replaces torch.optim.Adam(groups, lr=0.0, eps=1e-15).step() as the reference configures it
+// (frosting_scene/frosting_optimizer.py:74-121, gaussian_splatting/scene/gaussian_model.py:149-167:
+// one parameter group per tensor, per-group learning rate, betas (0.9, 0.999), no weight decay, no
+// amsgrad).  The eager optimizer runs ~6 elementwise kernels per group; here parameters, gradients and
+// both moments live in one flat fp32 layout each (the gradient layout is the exchange buffer of
+// frosting_amd/parallel.py) and ONE launch updates all groups: 16 bytes read + 12 written per
+// element, the HBM floor of the operation.
+//
+// Arithmetic follows torch/optim/adam.py::_single_tensor_adam (non-capturable path):
+//   m <- lerp(m, g, 1 - beta1);  v <- v * beta2 + (1 - beta2) * g * g
+//   p <- p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+// with the bias corrections evaluated in double on the host, like the Python floats there.
+#include "../../include/frosting_rasterizer.h"
+#include "kernels.h"
+
+namespace frg {
+
+__device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, float step_size, float w1,
+                                          float beta2, float omb2, float inv_bc2_sqrt, float eps)
+{
+    // Tensor.lerp_(end, weight): weight < 0.5 ? self + weight * (end - self) : end - (end - self) * (1 - weight)
+    const float d = g - m;
+    m = w1 < 0.5f ? m + w1 * d : g - d * (1.0f - w1);
+    v = v * beta2 + omb2 * g * g;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+    return p;
+}
+
+__global__ void __launch_bounds__(256)
+adam_step_kernel(long long n, float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ exp_avg,
+                 float* __restrict__ exp_avg_sq, AdamSegments seg, float w1, float beta2, float omb2,
+                 float inv_bc2_sqrt, float eps, float grad_scale)
+{
+    // 4 consecutive elements per thread (one 16-byte access per array); n4 = full groups of four
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long base = i4 * 4;
+    if (base >= n) return;
+    auto step_of = [&](long long i) {
+        float s = seg.step_size[0];
+#pragma unroll
+        for (int k = 1; k < FRG_ADAM_MAX_SEGMENTS; k++)
+            if (k < seg.count && i >= seg.end[k - 1]) s = seg.step_size[k];
+        return s;
+    };
+    if (base + 4 <= n) {
+        float4 p = *reinterpret_cast<const float4*>(params + base);
+        float4 g = *reinterpret_cast<const float4*>(grads + base);
+        float4 m = *reinterpret_cast<const float4*>(exp_avg + base);
+        float4 v = *reinterpret_cast<const float4*>(exp_avg_sq + base);
+        g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
+        // a group of four may straddle a segment boundary: per-element step size
+        const float s0 = step_of(base), s3 = step_of(base + 3);
+        const float s1 = s0 == s3 ? s0 : step_of(base + 1), s2 = s0 == s3 ? s0 : step_of(base + 2);
+        adam_one(p.x, g.x, m.x, v.x, s0, w1, beta2, omb2, inv_bc2_sqrt, eps);
+        adam_one(p.y, g.y, m.y, v.y, s1, w1, beta2, omb2, inv_bc2_sqrt, eps);
+        adam_one(p.z, g.z, m.z, v.z, s2, w1, beta2, omb2, inv_bc2_sqrt, eps);
+        adam_one(p.w, g.w, m.w, v.w, s3, w1, beta2, omb2, inv_bc2_sqrt, eps);
+        *reinterpret_cast<float4*>(params + base) = p;
+        *reinterpret_cast<float4*>(exp_avg + base) = m;
+        *reinterpret_cast<float4*>(exp_avg_sq + base) = v;
+    } else {
+        for (long long i = base; i < n; i++) {
+            float p = params[i], m = exp_avg[i], v = exp_avg_sq[i];
+            adam_one(p, grads[i] * grad_scale, m, v, step_of(i), w1, beta2, omb2, inv_bc2_sqrt, eps);
+            params[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+        }
+    }
+}
+
+hipError_t launch_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                            const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,
+                            float grad_scale, hipStream_t s)
+{
+    const long long groups = (n + 3) / 4;
+    const long long blocks = (groups + 255) / 256;
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n, params, grads, exp_avg, exp_avg_sq, seg,
+                       w1, beta2, omb2, inv_bc2_sqrt, eps, grad_scale);
+    return hipGetLastError();
+}
+
+}  // namespace frg

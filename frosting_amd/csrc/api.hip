@@ -7,6 +7,7 @@
 #include "kernels.h"
 
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -490,6 +491,39 @@ int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
     if (!means3D || !dL_dsh || (n_views > 0 && (!campos || !drgb))) return fail(FRG_EINVAL, "null pointer");
     FRG_HIP(frg::launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, drgb, view_stride, dL_dsh,
                                            (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  const long long* segment_ends, const float* segment_lrs, int n_segments,
+                  double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream)
+{
+    if (n < 0 || step < 1) return fail(FRG_EINVAL, "bad sizes n=%lld step=%d", n, step);
+    if (n_segments < 1 || n_segments > FRG_ADAM_MAX_SEGMENTS || !segment_ends || !segment_lrs)
+        return fail(FRG_EINVAL, "1..%d segments expected, got %d", FRG_ADAM_MAX_SEGMENTS, n_segments);
+    for (int k = 1; k < n_segments; k++)
+        if (segment_ends[k] < segment_ends[k - 1]) return fail(FRG_EINVAL, "segment ends must not decrease");
+    if (segment_ends[0] < 0 || segment_ends[n_segments - 1] != n) return fail(FRG_EINVAL, "the last segment must end at n");
+    if (n == 0) return FRG_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(FRG_EINVAL, "null pointer");
+    if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 != 0)
+        return fail(FRG_EINVAL, "the four arrays must be 16-byte aligned");
+    if ((n + 3) / 4 / 256 + 1 > 0x7fffffffLL) return fail(FRG_EINVAL, "n too large for one launch");
+    // Python-float arithmetic of torch/optim/adam.py: doubles, rounded to float where a tensor op takes them
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    frg::AdamSegments seg;
+    seg.count = n_segments;
+    for (int k = 0; k < FRG_ADAM_MAX_SEGMENTS; k++) {
+        seg.end[k] = k < n_segments ? segment_ends[k] : n;
+        seg.step_size[k] = k < n_segments ? (float)((double)segment_lrs[k] / bc1) : 0.0f;
+    }
+    const float w1 = (float)(1.0 - beta1);      // betas arrive as doubles: 1 - beta is formed before rounding to float,
+    const float omb2 = (float)(1.0 - beta2);    // as the Python floats of torch/optim/adam.py are
+    const float inv_bc2_sqrt = 1.0f / (float)std::sqrt(bc2);   // ATen divides by a scalar as a multiplication by its float reciprocal
+    FRG_HIP(frg::launch_adam_step(n, params, grads, exp_avg, exp_avg_sq, seg, w1, (float)beta2, omb2, inv_bc2_sqrt, (float)eps, grad_scale,
+                                  (hipStream_t)hip_stream));
     return FRG_OK;
 }
 

@@ -46,4 +46,17 @@ hipError_t launch_sh_grad_from_views(int P, int D, int M, int n_views, const flo
                                      long long campos_stride, const float* drgb, long long view_stride, float* dL_dsh,
                                      hipStream_t s);
 
+// fused Adam over the flat parameter layout (adam.hip)
+#ifndef FRG_ADAM_MAX_SEGMENTS
+#define FRG_ADAM_MAX_SEGMENTS 8
+#endif
+struct AdamSegments {
+    long long end[FRG_ADAM_MAX_SEGMENTS];    // exclusive end of segment k (begin = end of k-1), in elements
+    float step_size[FRG_ADAM_MAX_SEGMENTS];  // lr_k / (1 - beta1^t)
+    int count;
+};
+hipError_t launch_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                            const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,
+                            float grad_scale, hipStream_t s);
+
 }  // namespace frg

@@ -227,6 +227,21 @@ int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
                            const float* campos, long long campos_stride,
                            const float* drgb, long long view_stride, float* dL_dsh, void* hip_stream);
 
+/* ---- fused Adam over the flat per-Gaussian parameter layout ---------------------------
+ * SURVEY.md 8(f) rank 1, the step right after the backward / the gradient exchange.  Replaces
+ * torch.optim.Adam(groups, lr=0.0, eps=1e-15).step() as the reference sets it up
+ * (frosting_scene/frosting_optimizer.py:74-121, gaussian_splatting/scene/gaussian_model.py:149-167):
+ * one parameter group per tensor with its own learning rate, betas (0.9, 0.999), no weight decay,
+ * no amsgrad.  params / grads / exp_avg / exp_avg_sq are flat fp32 arrays of n elements with the
+ * same layout (16-byte aligned); segment k covers [segment_ends[k-1], segment_ends[k]) and uses
+ * segment_lrs[k]; the last segment must end at n.  `step` is the 1-based step count of the bias
+ * corrections, grad_scale multiplies the gradient first (1/world for a mean over views).  One
+ * launch, 28 bytes of HBM traffic per element; arithmetic as torch's _single_tensor_adam. */
+#define FRG_ADAM_MAX_SEGMENTS 8
+int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  const long long* segment_ends, const float* segment_lrs, int n_segments,
+                  double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,3 +115,16 @@ def test_extended_entry_points_validate_arguments_without_a_gpu():
     assert L.frg_sh_grad_from_views(0, 3, 16, 0, None, None, 0, None, 0, None, None) == 0      # nothing to do
     assert L.frg_sh_color_grad(0, None, None, None, None, None) == 0
     assert L.frg_sh_color_grad(4, None, None, None, None, None) == -1
+
+
+def test_adam_entry_point_validates_arguments_without_a_gpu():
+    import ctypes as C
+    L = _lib.lib()
+    ends, lrs = (C.c_longlong * 2)(4, 8), (C.c_float * 2)(0.1, 0.2)
+    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, 2, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1   # null arrays
+    assert L.frg_adam_step(9, None, None, None, None, ends, lrs, 2, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1 \
+        and "end at n" in _lib.last_error()
+    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, 9, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1
+    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, 2, 0.9, 0.999, 1e-15, 0, 1.0, None) == -1   # step is 1-based
+    ends0 = (C.c_longlong * 1)(0)
+    assert L.frg_adam_step(0, None, None, None, None, ends0, lrs, 1, 0.9, 0.999, 1e-15, 1, 1.0, None) == 0    # nothing to do
