@@ -527,4 +527,24 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
     return FRG_OK;
 }
 
+size_t frg_photometric_workspace_bytes(int channels, int width, int height)
+{
+    if (channels <= 0 || width <= 0 || height <= 0) return 0;
+    return frg::photometric_workspace_bytes(channels, width, height);
+}
+
+int frg_photometric_loss(int channels, int width, int height, const float* image, const float* target,
+                         const float* window11, float lambda_dssim, float* loss, float* dL_dimage,
+                         char* workspace, size_t workspace_bytes, void* hip_stream)
+{
+    if (channels <= 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes C=%d W=%d H=%d", channels, width, height);
+    if (!image || !target || !window11 || !loss) return fail(FRG_EINVAL, "null pointer");
+    if (!workspace || workspace_bytes < frg_photometric_workspace_bytes(channels, width, height))
+        return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_photometric_workspace_bytes(channels, width, height));
+    if ((long long)channels * ((width + 15) / 16) * ((height + 15) / 16) > 0x7fffffffLL) return fail(FRG_EINVAL, "image too large");
+    FRG_HIP(frg::launch_photometric(channels, width, height, image, target, window11, lambda_dssim, loss, dL_dimage, workspace,
+                                    (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
 }  // extern "C"

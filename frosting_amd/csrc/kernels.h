@@ -59,4 +59,9 @@ hipError_t launch_adam_step(long long n, float* params, const float* grads, floa
                             const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,
                             float grad_scale, hipStream_t s);
 
+// fused photometric loss (photometric.hip)
+size_t photometric_workspace_bytes(int C, int W, int H);
+hipError_t launch_photometric(int C, int W, int H, const float* pred, const float* gt, const float* window11, float lambda,
+                              float* loss, float* dL_dpred, char* workspace, hipStream_t s);
+
 }  // namespace frg

@@ -242,6 +242,20 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
                   const long long* segment_ends, const float* segment_lrs, int n_segments,
                   double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream);
 
+/* ---- fused photometric loss (forward + backward) ----------------------------------------
+ * SURVEY.md 8(f) rank 2, the step right before the rasterizer's backward.  Replaces
+ *     (1 - lambda) * l1_loss(image, target) + lambda * (1 - ssim(image, target))
+ * of frosting_utils/loss_utils.py:17-62 as frosting_trainers/refine.py:407-409 uses it (lambda = 0.2),
+ * and its autograd backward: image, target [C,H,W] planar float32; window11 = the 11 taps of the
+ * reference's normalised 1-D Gaussian window (loss_utils.py:23-25; HOST memory, the 2-D window there is
+ * its outer product); loss (device, 1 float) and dL_dimage [C,H,W] = d loss / d image are written
+ * (dL_dimage may be NULL for the value only).  Zero padding like conv2d(padding=5); the scalar is
+ * reduced in a fixed order (bit-reproducible).  workspace: frg_photometric_workspace_bytes. */
+size_t frg_photometric_workspace_bytes(int channels, int width, int height);
+int frg_photometric_loss(int channels, int width, int height, const float* image, const float* target,
+                         const float* window11, float lambda_dssim, float* loss, float* dL_dimage,
+                         char* workspace, size_t workspace_bytes, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,27 @@ def render(means3D, scales, rotations, opacities, shs, cam, bg, sh_degree):
         img = img + col[i][:, None, None] * w[None]
         Tacc = torch.where(use, test_T, Tacc)
     return img + Tacc[None] * bg.to(dt)[:, None, None]
+
+
+# ---- photometric loss restatement (frosting_utils/loss_utils.py:17-62, refine.py:407-409) ---------
+def photometric_loss_ref(pred, gt, lambda_dssim=0.2, window_size=11, sigma=1.5):
+    """(1 - l) * l1_loss + l * (1 - ssim), every step as the reference writes it (grouped conv2d with
+    the 2-D outer-product window, padding = window_size // 2).  pred, gt: [C,H,W]."""
+    import torch.nn.functional as F
+    from math import exp
+    g1 = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g1 = (g1 / g1.sum()).unsqueeze(1)
+    C = pred.shape[-3]
+    window = g1.mm(g1.t()).float().unsqueeze(0).unsqueeze(0).expand(C, 1, window_size, window_size).contiguous()
+    window = window.to(device=pred.device, dtype=pred.dtype)
+    a, b = pred.unsqueeze(0), gt.unsqueeze(0)
+    pad = window_size // 2
+    mu1 = F.conv2d(a, window, padding=pad, groups=C)
+    mu2 = F.conv2d(b, window, padding=pad, groups=C)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(a * a, window, padding=pad, groups=C) - mu1_sq
+    sigma2_sq = F.conv2d(b * b, window, padding=pad, groups=C) - mu2_sq
+    sigma12 = F.conv2d(a * b, window, padding=pad, groups=C) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return (1.0 - lambda_dssim) * torch.abs(pred - gt).mean() + lambda_dssim * (1.0 - ssim_map.mean())
