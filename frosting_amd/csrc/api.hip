@@ -107,7 +107,8 @@ struct PendingCounters {
     hipEvent_t ev = nullptr;           // counters have landed in `host`
     hipEvent_t scanned = nullptr;      // scan finished on the caller's stream
     hipStream_t copy_stream = nullptr; // carries the 48-byte read-back off the caller's stream
-    const void* key = nullptr;      // image buffer of the forward
+    const void* key = nullptr;      // image buffer of the forward; cleared by frg_forward_finish
+    const void* last_key = nullptr; // ... kept: the next forward on the same buffer orders itself after the read-back
     int device = -1;
 };
 constexpr int kPendingSlots = 8;
@@ -116,12 +117,13 @@ struct PendingRing {
     int next = 0;
     uint32_t last_class_count[FRG_SORT_CLASSES] = {0, 0, 0, 0, 0};
     bool have_hint = false;
-    PendingCounters* acquire(const void* key)
+    PendingCounters* acquire(const void* key, bool* reused)
     {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) return nullptr;
         PendingCounters* p = nullptr;
-        for (auto& c : slot) if (c.key == key) p = &c;          // the same image buffer is being reused
+        for (auto& c : slot) if (c.last_key == key && c.ev && c.device == dev) p = &c;   // the same image buffer again
+        *reused = p != nullptr;
         if (!p) { p = &slot[next]; next = (next + 1) % kPendingSlots; }
         if (!p->host && hipHostMalloc(reinterpret_cast<void**>(&p->host), sizeof(frg::Counters), hipHostMallocDefault) != hipSuccess) return nullptr;
         if (p->ev && p->device != dev) {
@@ -133,6 +135,7 @@ struct PendingRing {
         if (!p->copy_stream && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         p->device = dev;
         p->key = key;
+        p->last_key = key;
         return p;
     }
     PendingCounters* find(const void* key)
@@ -301,16 +304,20 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
     const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height, g_global_bins.load() != 0);
 
+    PendingCounters* pend = nullptr;
+    if (capacity > 0) {
+        bool reused = false;
+        pend = g_pending.acquire(img_chunk, &reused);
+        if (!pend) return fail(FRG_EHIP, "pinned counter slot / event creation failed");
+        // the previous deferred forward on this image buffer reads its counters back on a side stream:
+        // that copy must have happened before the counters are cleared again
+        if (reused) FRG_HIP(hipStreamWaitEvent(stream, pend->ev, 0));
+    }
     FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
     in.keep_mask = keep_mask;
     { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess"); }
-    PendingCounters* pend = nullptr;
-    if (capacity > 0) {
-        pend = g_pending.acquire(img_chunk);
-        if (!pend) return fail(FRG_EHIP, "pinned counter slot / event creation failed");
-    }
     { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, (uint32_t)capacity, stream), "scan"); }
 
     int R = capacity;
