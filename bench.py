@@ -98,6 +98,9 @@ def main():
                          "1/255 anywhere in their tile are dropped when the tile lists are built (outputs bit-identical, "
                          "lists = order-preserving sub-lists of the reference's).  Without the flag the headline run keeps "
                          "the reference's exact lists and the tight mode is timed in an extra pass (field 'tight_binning')")
+    ap.add_argument("--no-tight-pass", action="store_true",
+                    help="skip the informative extra pass that times tight binning after the timed region (used under "
+                         "rocprofv3 so that per-kernel averages are not a mix of the two modes)")
     ap.add_argument("--deferred-counters", action="store_true",
                     help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
                          "which like the reference blocks on a read-back of num_rendered; measured equal at C3")
@@ -219,7 +222,7 @@ def main():
         torch.cuda.synchronize(dev)
         stage_avg = {k: v for k, v in _lib.stage_times().items() if v > 0}
     tight = None
-    if world == 1 and not exchanging and not args.tight_binning:
+    if world == 1 and not exchanging and not args.tight_binning and not args.no_tight_pass:
         # informative extra pass, after and outside the timed region: the same steps with tight binning
         _lib.set_option("profile", 0)
         _lib.set_option("tight_binning", 1)
