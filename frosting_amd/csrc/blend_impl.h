@@ -216,7 +216,7 @@ __device__ __forceinline__ void lane_pixel(int lane, int q, int tx, int ty, int&
 }
 
 // ---------------------------------------------------------------------------
-// wave64 sum with a fixed DPP tree; the total lands in lane 63.
+// one step of a fixed DPP reduction tree (v + the lane selected by CTRL)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_step(float v)
 {
@@ -232,17 +232,6 @@ __device__ __forceinline__ float fold_two(float a, float b)
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v = dpp_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v = dpp_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v = dpp_step<0x141, 0xf>(v);  // row_half_mirror
-    v = dpp_step<0x140, 0xf>(v);  // row_mirror         -> every lane holds its row's sum
-    v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-    v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the total
-    return v;
 }
 
 template <bool EXACT>
