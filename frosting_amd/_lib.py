@@ -95,7 +95,8 @@ def lib():
     L.frg_photometric_loss.restype = i
     L.frg_photometric_loss.argtypes = [i, i, i, vp, vp, C.POINTER(C.c_float), f, vp, vp, vp, sz, vp]
     L.frg_adam_step.restype = i
-    L.frg_adam_step.argtypes = [C.c_longlong, vp, vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_float), i,
+    L.frg_adam_step.argtypes = [C.c_longlong, vp, vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_float),
+                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), i,
                                 C.c_double, C.c_double, C.c_double, i, f, vp]
     L.frg_forward_ex.restype = i
     L.frg_forward_ex.argtypes = [C.POINTER(ForwardArgs)]

@@ -39,13 +39,21 @@ adam_step_kernel(long long n, float* __restrict__ params, const float* __restric
     const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long base = i4 * 4;
     if (base >= n) return;
-    auto step_of = [&](long long i) {
-        float s = seg.step_size[0];
+    // segment of element i, and -- where the segment has a periodic head -- i's phase in the period
+    auto seg_of = [&](long long i) {
+        int k = 0;
 #pragma unroll
-        for (int k = 1; k < FRG_ADAM_MAX_SEGMENTS; k++)
-            if (k < seg.count && i >= seg.end[k - 1]) s = seg.step_size[k];
-        return s;
+        for (int j = 1; j < FRG_ADAM_MAX_SEGMENTS; j++)
+            if (j < seg.count && i >= seg.end[j - 1]) k = j;
+        return k;
     };
+    auto phase_of = [&](long long i, int k) -> int {
+        if (seg.period[k] <= 0) return 0;
+        const unsigned long long off = (unsigned long long)(i - (k ? seg.end[k - 1] : 0));
+        return off < 0x100000000ull ? (int)((uint32_t)off % (uint32_t)seg.period[k]) : (int)(off % (unsigned long long)seg.period[k]);
+    };
+    auto step_at = [&](int k, int phase) { return (seg.period[k] > 0 && phase < seg.head[k]) ? seg.head_step_size[k] : seg.step_size[k]; };
+    auto step_of = [&](long long i) { const int k = seg_of(i); return step_at(k, phase_of(i, k)); };
     if (base + 4 <= n) {
         float4 p = *reinterpret_cast<const float4*>(params + base);
         float4 g = *reinterpret_cast<const float4*>(grads + base);
@@ -53,8 +61,20 @@ adam_step_kernel(long long n, float* __restrict__ params, const float* __restric
         float4 v = *reinterpret_cast<const float4*>(exp_avg_sq + base);
         g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
         // a group of four may straddle a segment boundary: per-element step size
-        const float s0 = step_of(base), s3 = step_of(base + 3);
-        const float s1 = s0 == s3 ? s0 : step_of(base + 1), s2 = s0 == s3 ? s0 : step_of(base + 2);
+        // a group of four may straddle a segment boundary or a period: one segment search and one
+        // modulo in the common case, the phase then just counts up
+        const int k0 = seg_of(base), k3 = seg_of(base + 3);
+        float s0, s1, s2, s3;
+        if (k0 == k3) {
+            int ph = phase_of(base, k0);
+            const int per = seg.period[k0];
+            s0 = step_at(k0, ph); ph = (per > 0 && ph + 1 == per) ? 0 : ph + 1;
+            s1 = step_at(k0, ph); ph = (per > 0 && ph + 1 == per) ? 0 : ph + 1;
+            s2 = step_at(k0, ph); ph = (per > 0 && ph + 1 == per) ? 0 : ph + 1;
+            s3 = step_at(k0, ph);
+        } else {
+            s0 = step_of(base); s1 = step_of(base + 1); s2 = step_of(base + 2); s3 = step_of(base + 3);
+        }
         adam_one(p.x, g.x, m.x, v.x, s0, w1, beta2, omb2, inv_bc2_sqrt, eps);
         adam_one(p.y, g.y, m.y, v.y, s1, w1, beta2, omb2, inv_bc2_sqrt, eps);
         adam_one(p.z, g.z, m.z, v.z, s2, w1, beta2, omb2, inv_bc2_sqrt, eps);

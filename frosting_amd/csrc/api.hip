@@ -502,7 +502,8 @@ int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
 }
 
 int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                  const long long* segment_ends, const float* segment_lrs, int n_segments,
+                  const long long* segment_ends, const float* segment_lrs, const int* segment_period,
+                  const int* segment_head, const float* segment_head_lrs, int n_segments,
                   double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream)
 {
     if (n < 0 || step < 1) return fail(FRG_EINVAL, "bad sizes n=%lld step=%d", n, step);
@@ -525,6 +526,12 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
     for (int k = 0; k < FRG_ADAM_MAX_SEGMENTS; k++) {
         seg.end[k] = k < n_segments ? segment_ends[k] : n;
         seg.step_size[k] = k < n_segments ? (float)((double)segment_lrs[k] / bc1) : 0.0f;
+        const bool sub = k < n_segments && segment_period && segment_head && segment_head_lrs && segment_period[k] > 0;
+        if (sub && (segment_head[k] < 0 || segment_head[k] > segment_period[k]))
+            return fail(FRG_EINVAL, "segment %d: head %d outside its period %d", k, segment_head[k], segment_period[k]);
+        seg.period[k] = sub ? segment_period[k] : 0;
+        seg.head[k] = sub ? segment_head[k] : 0;
+        seg.head_step_size[k] = sub ? (float)((double)segment_head_lrs[k] / bc1) : 0.0f;
     }
     const float w1 = (float)(1.0 - beta1);      // betas arrive as doubles: 1 - beta is formed before rounding to float,
     const float omb2 = (float)(1.0 - beta2);    // as the Python floats of torch/optim/adam.py are

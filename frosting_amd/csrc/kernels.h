@@ -53,6 +53,11 @@ hipError_t launch_sh_grad_from_views(int P, int D, int M, int n_views, const flo
 struct AdamSegments {
     long long end[FRG_ADAM_MAX_SEGMENTS];    // exclusive end of segment k (begin = end of k-1), in elements
     float step_size[FRG_ADAM_MAX_SEGMENTS];  // lr_k / (1 - beta1^t)
+    // optional sub-structure of a segment: elements whose (offset in segment) % period < head use
+    // head_step_size instead (one [P,16,3] SH tensor optimised as the reference's two groups,
+    // features_dc and features_rest, without ever concatenating them); period 0 = none
+    int period[FRG_ADAM_MAX_SEGMENTS], head[FRG_ADAM_MAX_SEGMENTS];
+    float head_step_size[FRG_ADAM_MAX_SEGMENTS];
     int count;
 };
 hipError_t launch_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

@@ -24,7 +24,9 @@ class FlatAdam:
     update rule, defaults (betas 0.9/0.999) and eps handling as ``torch.optim.Adam`` without weight
     decay / amsgrad."""
 
-    def __init__(self, shapes: dict, lrs: dict, device, betas=(0.9, 0.999), eps: float = 1e-15):
+    def __init__(self, shapes: dict, lrs: dict, device, betas=(0.9, 0.999), eps: float = 1e-15, sh_dc_lr=None):
+        """sh_dc_lr: learning rate of the DC coefficient of "shs" ([P,K,3]); lrs["shs"] then applies to the
+        other K-1 coefficients -- the reference's features_dc / features_rest groups on one tensor."""
         self.device = torch.device(device)
         names = [k for k in PARAM_ORDER if k in shapes] + [k for k in shapes if k not in PARAM_ORDER]
         if not 1 <= len(names) <= 8:
@@ -45,6 +47,14 @@ class FlatAdam:
         self.lrs = {k: float(lrs[k]) for k in names}
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.steps = 0
+        self.sh_dc_lr = None if sh_dc_lr is None else float(sh_dc_lr)
+        n = len(names)
+        self._period, self._head = (C.c_int * n)(*([0] * n)), (C.c_int * n)(*([0] * n))
+        if self.sh_dc_lr is not None:
+            if "shs" not in self.shapes or len(self.shapes["shs"]) != 3:
+                raise ValueError('sh_dc_lr needs a "shs" group of shape [P,K,3]')
+            k = names.index("shs")
+            self._period[k], self._head[k] = int(self.shapes["shs"][1] * self.shapes["shs"][2]), int(self.shapes["shs"][2])
 
     def set_lr(self, name: str, lr: float):
         """Per-group learning-rate schedule hook (reference: update_learning_rate)."""
@@ -60,10 +70,13 @@ class FlatAdam:
             raise RuntimeError(f"expected a contiguous float32 gradient buffer of {self.numel} elements on {self.flat.device}")
         self.steps += 1
         lrs = (C.c_float * len(self.names))(*[self.lrs[k] for k in self.names])
+        head_lrs = (C.c_float * len(self.names))(*[(self.sh_dc_lr if (k == "shs" and self.sh_dc_lr is not None) else 0.0)
+                                                    for k in self.names])
         stream = C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
         rc = _lib.lib().frg_adam_step(self.numel, C.c_void_p(self.flat.data_ptr()), C.c_void_p(g.data_ptr()),
                                       C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
-                                      self._ends, lrs, len(self.names), self.betas[0], self.betas[1], self.eps,
+                                      self._ends, lrs, self._period, self._head, head_lrs, len(self.names),
+                                      self.betas[0], self.betas[1], self.eps,
                                       self.steps, float(grad_scale), stream)
         if rc < 0:
             raise RuntimeError(f"frg_adam_step failed ({rc}): {_lib.last_error()}")

@@ -234,12 +234,17 @@ int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
  * one parameter group per tensor with its own learning rate, betas (0.9, 0.999), no weight decay,
  * no amsgrad.  params / grads / exp_avg / exp_avg_sq are flat fp32 arrays of n elements with the
  * same layout (16-byte aligned); segment k covers [segment_ends[k-1], segment_ends[k]) and uses
- * segment_lrs[k]; the last segment must end at n.  `step` is the 1-based step count of the bias
+ * segment_lrs[k]; the last segment must end at n.  Optionally (all three arrays non-NULL, period > 0)
+ * a segment has a periodic head: elements whose offset in the segment modulo segment_period[k] is below
+ * segment_head[k] use segment_head_lrs[k] -- one [P,16,3] SH tensor is then stepped as the reference's two
+ * groups features_dc (lr) and features_rest (lr/20) without the torch.cat of every iteration
+ * (gaussian_model.py:get_features, frosting_model.py:sh_coordinates).  `step` is the 1-based step count of the bias
  * corrections, grad_scale multiplies the gradient first (1/world for a mean over views).  One
  * launch, 28 bytes of HBM traffic per element; arithmetic as torch's _single_tensor_adam. */
 #define FRG_ADAM_MAX_SEGMENTS 8
 int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                  const long long* segment_ends, const float* segment_lrs, int n_segments,
+                  const long long* segment_ends, const float* segment_lrs, const int* segment_period,
+                  const int* segment_head, const float* segment_head_lrs, int n_segments,
                   double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream);
 
 /* ---- fused photometric loss (forward + backward) ----------------------------------------

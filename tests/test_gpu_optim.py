@@ -60,3 +60,30 @@ def test_flat_adam_grad_scale_and_errors(gpu_device):
         a.step(g[:-1])
     with pytest.raises(RuntimeError, match="GPU only"):
         a.step(g.cpu())
+
+
+def test_flat_adam_dc_and_rest_groups_on_one_sh_tensor(gpu_device):
+    """sh_dc_lr: one [P,16,3] SH tensor stepped like the reference's two groups (features_dc at lr,
+    features_rest at lr / 20) -- no torch.cat, no gradient split."""
+    dev = gpu_device
+    P, K = 333, 16
+    shapes = dict(means3D=(P, 3), shs=(P, K, 3))
+    g = torch.Generator().manual_seed(3)
+    sh0, m0 = torch.randn(P, K, 3, generator=g), torch.randn(P, 3, generator=g)
+    ours = FlatAdam(shapes, dict(means3D=1e-3, shs=2.5e-3 / 20.0), dev, sh_dc_lr=2.5e-3)
+    ours.params["means3D"].copy_(m0); ours.params["shs"].copy_(sh0)
+    dc = torch.nn.Parameter(sh0[:, :1].clone().to(dev)); rest = torch.nn.Parameter(sh0[:, 1:].clone().to(dev))
+    xyz = torch.nn.Parameter(m0.clone().to(dev))
+    ref = torch.optim.Adam([{"params": [xyz], "lr": 1e-3}, {"params": [dc], "lr": 2.5e-3},
+                            {"params": [rest], "lr": 2.5e-3 / 20.0}], lr=0.0, eps=1e-15)
+    for _ in range(6):
+        gs, gm = torch.randn(P, K, 3, generator=g) * 1e-2, torch.randn(P, 3, generator=g) * 1e-2
+        ours.step(torch.cat([gm.reshape(-1), gs.reshape(-1)]).to(dev))
+        xyz.grad, dc.grad, rest.grad = gm.to(dev), gs[:, :1].contiguous().to(dev), gs[:, 1:].contiguous().to(dev)
+        ref.step()
+    want = torch.cat([dc.detach(), rest.detach()], dim=1)
+    torch.testing.assert_close(ours.params["shs"], want, rtol=2e-6, atol=4e-7 * float(want.abs().max()))
+    torch.testing.assert_close(ours.params["means3D"], xyz.detach(), rtol=2e-6, atol=4e-7 * float(xyz.detach().abs().max()))
+    # the two learning rates really differ: DC moved ~20x further than the rest
+    moved = (ours.params["shs"].cpu() - sh0).abs()
+    assert float(moved[:, 0].mean()) > 10 * float(moved[:, 1:].mean())

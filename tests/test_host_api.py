@@ -121,10 +121,10 @@ def test_adam_entry_point_validates_arguments_without_a_gpu():
     import ctypes as C
     L = _lib.lib()
     ends, lrs = (C.c_longlong * 2)(4, 8), (C.c_float * 2)(0.1, 0.2)
-    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, 2, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1   # null arrays
-    assert L.frg_adam_step(9, None, None, None, None, ends, lrs, 2, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1 \
+    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, None, None, None, 2, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1   # null arrays
+    assert L.frg_adam_step(9, None, None, None, None, ends, lrs, None, None, None, 2, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1 \
         and "end at n" in _lib.last_error()
-    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, 9, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1
-    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, 2, 0.9, 0.999, 1e-15, 0, 1.0, None) == -1   # step is 1-based
+    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, None, None, None, 9, 0.9, 0.999, 1e-15, 1, 1.0, None) == -1
+    assert L.frg_adam_step(8, None, None, None, None, ends, lrs, None, None, None, 2, 0.9, 0.999, 1e-15, 0, 1.0, None) == -1   # step is 1-based
     ends0 = (C.c_longlong * 1)(0)
-    assert L.frg_adam_step(0, None, None, None, None, ends0, lrs, 1, 0.9, 0.999, 1e-15, 1, 1.0, None) == 0    # nothing to do
+    assert L.frg_adam_step(0, None, None, None, None, ends0, lrs, None, None, None, 1, 0.9, 0.999, 1e-15, 1, 1.0, None) == 0    # nothing to do

@@ -29,6 +29,10 @@ def timeit(fn, n=20):
 
 t = timeit(lambda: opt.step(g))
 print(f"FlatAdam (frg_adam_step): {1e3*t:.3f} ms/step, {28*opt.numel/t/1e9:.0f} GB/s of 28 B/element ({opt.numel/1e6:.0f} M elements)")
+opt2 = FlatAdam(shapes, dict(lrs, shs=lrs["shs"] / 20.0), dev, sh_dc_lr=lrs["shs"])
+opt2.flat.normal_()
+t = timeit(lambda: opt2.step(g))
+print(f"FlatAdam with the features_dc / features_rest split on the SH tensor: {1e3*t:.3f} ms/step, {28*opt2.numel/t/1e9:.0f} GB/s")
 for name, kw in (("torch Adam single-tensor", dict(foreach=False)), ("torch Adam foreach", dict(foreach=True)),
                  ("torch Adam fused", dict(fused=True))):
     try:

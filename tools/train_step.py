@@ -17,7 +17,7 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else None
 scene, cam, bg = scenes.config_scene("c3", 0, P=P)
 shapes = {k: tuple(getattr(scene, k).shape) for k in PARAM_ORDER}
 lrs = dict(means3D=1.6e-6, scales=5e-5, rotations=1e-5, opacities=5e-4, shs=2.5e-5)   # small: raw (activated) parameters
-opt = FlatAdam(shapes, lrs, dev)
+opt = FlatAdam(shapes, dict(lrs, shs=lrs["shs"] / 20.0), dev, sh_dc_lr=lrs["shs"])   # features_dc / features_rest rates on one tensor
 for k in PARAM_ORDER:
     opt.params[k].copy_(getattr(scene, k))
 live = scenes.Scene(opt.params["means3D"], opt.params["scales"], opt.params["rotations"], opt.params["opacities"],
