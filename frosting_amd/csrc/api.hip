@@ -561,4 +561,24 @@ int frg_photometric_loss(int channels, int width, int height, const float* image
     return FRG_OK;
 }
 
+int frg_activate(int P, const float* raw_opacity, const float* raw_scale, const float* raw_rot,
+                 float* opacity, float* scale, float* rot, void* hip_stream)
+{
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!raw_opacity || !raw_scale || !raw_rot || !opacity || !scale || !rot) return fail(FRG_EINVAL, "null pointer");
+    FRG_HIP(frg::launch_activate(P, raw_opacity, raw_scale, raw_rot, opacity, scale, rot, (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_activate_backward(int P, const float* opacity, const float* scale, const float* raw_rot,
+                          float* g_opacity, float* g_scale, float* g_rot, void* hip_stream)
+{
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!opacity || !scale || !raw_rot || !g_opacity || !g_scale || !g_rot) return fail(FRG_EINVAL, "null pointer");
+    FRG_HIP(frg::launch_activate_bwd(P, opacity, scale, raw_rot, g_opacity, g_scale, g_rot, (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
 }  // extern "C"

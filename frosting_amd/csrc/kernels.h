@@ -64,6 +64,12 @@ hipError_t launch_adam_step(long long n, float* params, const float* grads, floa
                             const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,
                             float grad_scale, hipStream_t s);
 
+// parameter activations (activations.hip)
+hipError_t launch_activate(int P, const float* raw_opacity, const float* raw_scale, const float* raw_rot, float* opacity,
+                           float* scale, float* rot, hipStream_t s);
+hipError_t launch_activate_bwd(int P, const float* opacity, const float* scale, const float* raw_rot, float* g_opacity,
+                               float* g_scale, float* g_rot, hipStream_t s);
+
 // fused photometric loss (photometric.hip)
 size_t photometric_workspace_bytes(int C, int W, int H);
 hipError_t launch_photometric(int C, int W, int H, const float* pred, const float* gt, const float* window11, float lambda,

@@ -247,6 +247,17 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
                   const int* segment_head, const float* segment_head_lrs, int n_segments,
                   double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream);
 
+/* ---- parameter activations -----------------------------------------------------------------
+ * Part of SURVEY.md 8(f) rank 3.  opacity = sigmoid(raw), scale = exp(raw), rotation = F.normalize(raw)
+ * (gaussian_splatting/scene/gaussian_model.py:32-40,96-115; frosting_scene/frosting_model.py:32,726,797-798)
+ * in one launch; frg_activate_backward turns, IN PLACE, the rasterizer's gradients w.r.t. the activated
+ * values (g_opacity [P], g_scale [P,3], g_rot [P,4]) into gradients w.r.t. the raw parameters, so the flat
+ * gradient buffer can go straight into frg_adam_step. */
+int frg_activate(int P, const float* raw_opacity, const float* raw_scale, const float* raw_rot,
+                 float* opacity, float* scale, float* rot, void* hip_stream);
+int frg_activate_backward(int P, const float* opacity, const float* scale, const float* raw_rot,
+                          float* g_opacity, float* g_scale, float* g_rot, void* hip_stream);
+
 /* ---- fused photometric loss (forward + backward) ----------------------------------------
  * SURVEY.md 8(f) rank 2, the step right before the rasterizer's backward.  Replaces
  *     (1 - lambda) * l1_loss(image, target) + lambda * (1 - ssim(image, target))
