@@ -581,4 +581,18 @@ int frg_activate_backward(int P, const float* opacity, const float* scale, const
     return FRG_OK;
 }
 
+size_t frg_knn_workspace_bytes(int P) { return P > 0 ? frg::knn_workspace_bytes(P) : 0; }
+
+int frg_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* workspace, size_t workspace_bytes, void* hip_stream)
+{
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!points || !mean_dist2) return fail(FRG_EINVAL, "null pointer");
+    if (!workspace || workspace_bytes < frg_knn_workspace_bytes(P))
+        return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_knn_workspace_bytes(P));
+    if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return fail(FRG_EINVAL, "workspace must be 256-byte aligned");
+    FRG_HIP(frg::launch_knn(P, points, mean_dist2, workspace, (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
 }  // extern "C"

@@ -70,6 +70,10 @@ hipError_t launch_activate(int P, const float* raw_opacity, const float* raw_sca
 hipError_t launch_activate_bwd(int P, const float* opacity, const float* scale, const float* raw_rot, float* g_opacity,
                                float* g_scale, float* g_rot, hipStream_t s);
 
+// 3-nearest-neighbour mean squared distance (knn.hip)
+size_t knn_workspace_bytes(int P);
+hipError_t launch_knn(int P, const float* pts, float* out, char* workspace, hipStream_t s);
+
 // fused photometric loss (photometric.hip)
 size_t photometric_workspace_bytes(int C, int W, int H);
 hipError_t launch_photometric(int C, int W, int H, const float* pred, const float* gt, const float* window11, float lambda,

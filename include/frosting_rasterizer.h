@@ -247,6 +247,15 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
                   const int* segment_head, const float* segment_head_lrs, int n_segments,
                   double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream);
 
+/* ---- nearest-neighbour distances (scale initialisation) --------------------------------------
+ * SURVEY.md 8(f) rank 4.  Replaces simple-knn's distCUDA2 (gaussian_splatting/submodules/simple-knn/
+ * simple_knn.cu:64-222, spatial.cu:15-26; callers gaussian_model.py:134, frosting_model.py:530):
+ * mean_dist2[i] = mean of the three smallest squared distances from points[i] ([P,3] float32) to the
+ * other points, (b0 + b1 + b2) / 3 with b ascending -- exact search, the reference's values. */
+size_t frg_knn_workspace_bytes(int P);
+int frg_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* workspace, size_t workspace_bytes,
+                       void* hip_stream);
+
 /* ---- parameter activations -----------------------------------------------------------------
  * Part of SURVEY.md 8(f) rank 3.  opacity = sigmoid(raw), scale = exp(raw), rotation = F.normalize(raw)
  * (gaussian_splatting/scene/gaussian_model.py:32-40,96-115; frosting_scene/frosting_model.py:32,726,797-798)
