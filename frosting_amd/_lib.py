@@ -94,6 +94,10 @@ def lib():
     L.frg_knn_workspace_bytes.argtypes = [i]
     L.frg_knn_mean_dist2.restype = i
     L.frg_knn_mean_dist2.argtypes = [i, vp, vp, vp, sz, vp]
+    L.frg_shell_points.restype = i
+    L.frg_shell_points.argtypes = [i, vp, vp, vp, vp, vp]
+    L.frg_shell_points_backward.restype = i
+    L.frg_shell_points_backward.argtypes = [i, vp, vp, vp, vp, vp, vp]
     L.frg_activate.restype = i
     L.frg_activate.argtypes = [i, vp, vp, vp, vp, vp, vp, vp]
     L.frg_activate_backward.restype = i
@@ -163,5 +167,5 @@ EXPORTED_SYMBOLS = [
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_sh_color_grad", "frg_sh_grad_from_views",
     "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",
-    "frg_knn_workspace_bytes", "frg_knn_mean_dist2",
+    "frg_knn_workspace_bytes", "frg_knn_mean_dist2", "frg_shell_points", "frg_shell_points_backward",
 ]

@@ -68,3 +68,39 @@ class _Activations(torch.autograd.Function):
 def gaussian_activations(raw_opacity, raw_scale, raw_rot):
     """Differentiable (opacity, scale, rotation) = (sigmoid, exp, normalize)(raw)."""
     return _Activations.apply(raw_opacity, raw_scale, raw_rot)
+
+
+# ---- Frosting's shell parameterisation of the centres (frosting_model.py:713-724) -------------------
+class _ShellPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bary_logits, cell_verts, point_cell_indices):
+        lg, cv, ci = bary_logits.contiguous(), cell_verts.contiguous(), point_cell_indices.contiguous()
+        P = lg.shape[0]
+        dev = _check(P, lg)
+        if lg.shape[1:] != (6,) or cv.dtype != torch.float32 or cv.device != dev or cv.reshape(-1).numel() % 18 or \
+                ci.dtype != torch.int64 or ci.device != dev or ci.shape != (P,):
+            raise RuntimeError("expected bary_logits [P,6] float32, cell_verts [F,6,3] (or [F,2,3,3]) float32, "
+                               "point_cell_indices [P] int64 on one GPU")
+        pts = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        rc = _lib.lib().frg_shell_points(P, _ptr(lg), _ptr(cv), _ptr(ci), _ptr(pts),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"frg_shell_points failed ({rc}): {_lib.last_error()}")
+        ctx.save_for_backward(lg, cv, ci)
+        return pts
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, cv, ci = ctx.saved_tensors
+        out = torch.empty_like(lg)
+        rc = _lib.lib().frg_shell_points_backward(lg.shape[0], _ptr(lg), _ptr(cv), _ptr(ci), _ptr(g.contiguous()), _ptr(out),
+                                                  C.c_void_p(torch.cuda.current_stream(lg.device).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"frg_shell_points_backward failed ({rc}): {_lib.last_error()}")
+        return out, None, None
+
+
+def shell_points(bary_logits, cell_verts, point_cell_indices):
+    """``(softmax(_bary_coords)[..., None] * shell_cells_verts[_point_cell_indices].reshape(-1, 6, 3)).sum(-2)``,
+    differentiable w.r.t. the logits (cell vertices are constants: the reference's learn_shell = False)."""
+    return _ShellPoints.apply(bary_logits, cell_verts, point_cell_indices)

@@ -595,4 +595,25 @@ int frg_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* work
     return FRG_OK;
 }
 
+int frg_shell_points(int P, const float* bary_logits, const float* cell_verts, const long long* point_cell_indices,
+                     float* points, void* hip_stream)
+{
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!bary_logits || !cell_verts || !point_cell_indices || !points) return fail(FRG_EINVAL, "null pointer");
+    FRG_HIP(frg::launch_shell_points(P, bary_logits, cell_verts, point_cell_indices, points, (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_shell_points_backward(int P, const float* bary_logits, const float* cell_verts, const long long* point_cell_indices,
+                              const float* dL_dpoints, float* dL_dlogits, void* hip_stream)
+{
+    if (P < 0) return fail(FRG_EINVAL, "P < 0");
+    if (P == 0) return FRG_OK;
+    if (!bary_logits || !cell_verts || !point_cell_indices || !dL_dpoints || !dL_dlogits) return fail(FRG_EINVAL, "null pointer");
+    FRG_HIP(frg::launch_shell_points_bwd(P, bary_logits, cell_verts, point_cell_indices, dL_dpoints, dL_dlogits,
+                                         (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
 }  // extern "C"

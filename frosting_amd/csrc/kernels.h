@@ -64,6 +64,12 @@ hipError_t launch_adam_step(long long n, float* params, const float* grads, floa
                             const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,
                             float grad_scale, hipStream_t s);
 
+// Frosting shell parameterisation of the centres (shell.hip)
+hipError_t launch_shell_points(int P, const float* logits, const float* cell_verts, const long long* cell, float* points,
+                               hipStream_t s);
+hipError_t launch_shell_points_bwd(int P, const float* logits, const float* cell_verts, const long long* cell,
+                                   const float* dL_dpoints, float* dL_dlogits, hipStream_t s);
+
 // parameter activations (activations.hip)
 hipError_t launch_activate(int P, const float* raw_opacity, const float* raw_scale, const float* raw_rot, float* opacity,
                            float* scale, float* rot, hipStream_t s);

@@ -256,6 +256,16 @@ size_t frg_knn_workspace_bytes(int P);
 int frg_knn_mean_dist2(int P, const float* points, float* mean_dist2, char* workspace, size_t workspace_bytes,
                        void* hip_stream);
 
+/* ---- Frosting shell parameterisation of the centres -------------------------------------------
+ * The rest of SURVEY.md 8(f) rank 3.  points = sum_k softmax(bary_logits)[k] * cell_verts[cell][k]
+ * (frosting_scene/frosting_model.py:713-724; cell_verts [F,6,3] = shell_cells_verts.reshape(-1, 6, 3),
+ * the inner then the outer triangle of each prismatic cell, constants when learn_shell = False;
+ * point_cell_indices [P] int64 as the reference stores them) and its backward w.r.t. the logits. */
+int frg_shell_points(int P, const float* bary_logits, const float* cell_verts, const long long* point_cell_indices,
+                     float* points, void* hip_stream);
+int frg_shell_points_backward(int P, const float* bary_logits, const float* cell_verts, const long long* point_cell_indices,
+                              const float* dL_dpoints, float* dL_dlogits, void* hip_stream);
+
 /* ---- parameter activations -----------------------------------------------------------------
  * Part of SURVEY.md 8(f) rank 3.  opacity = sigmoid(raw), scale = exp(raw), rotation = F.normalize(raw)
  * (gaussian_splatting/scene/gaussian_model.py:32-40,96-115; frosting_scene/frosting_model.py:32,726,797-798)

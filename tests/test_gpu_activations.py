@@ -44,3 +44,25 @@ def test_in_place_backward_on_a_flat_gradient_buffer(gpu_device):
     assert float((gr * r).sum(dim=1).abs().max()) < 1e-5    # the normalisation's backward is orthogonal to the unit quaternion
     with pytest.raises(RuntimeError, match="GPU only"):
         activate(ro.cpu(), rs.cpu(), rr.cpu())
+
+
+def test_shell_points_match_the_reference_formula(gpu_device):
+    """frosting_model.py:713-724 in torch (softmax, gather, weighted sum) against the fused kernels."""
+    from frosting_amd.activations import shell_points
+    dev = gpu_device
+    g = torch.Generator().manual_seed(2)
+    F, P = 500, 7001
+    cells = torch.randn(F, 2, 3, 3, generator=g).to(dev)                       # shell_cells_verts
+    idx = torch.randint(0, F, (P,), generator=g).to(dev)
+    lg0 = (3 * torch.randn(P, 6, generator=g)).to(dev)
+    a = lg0.clone().requires_grad_(True)
+    b = lg0.clone().requires_grad_(True)
+    ours = shell_points(a, cells, idx)
+    ref = (torch.softmax(b, dim=-1)[..., None] * cells[idx].reshape(-1, 6, 3)).sum(dim=-2)
+    torch.testing.assert_close(ours, ref.detach(), rtol=2e-6, atol=2e-6)
+    w = torch.randn(P, 3, generator=g).to(dev)
+    (ours * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=2e-6)
+    with pytest.raises(RuntimeError, match="int64"):
+        shell_points(a, cells, idx.int())
