@@ -85,6 +85,24 @@ def visible_faces(verts, faces, full_proj_transform, height, width, glctx=None):
     return ids[ids >= 0].long()
 
 
+def visible_face_mask(verts, faces, full_proj_transform, height, width, glctx=None):
+    """bool [F]: the face is the nearest surface in at least one pixel.  Same set as visible_faces(),
+    without the sort inside torch.unique: one index_put of the rasterizer's id plane (the per-frame
+    path of frosting_model.py:1524-1539 only needs the mask, :1564-1566)."""
+    rast, _ = rasterize(glctx, clip_space_vertices(verts, full_proj_transform), faces, [height, width])
+    mask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool, device=faces.device)
+    mask[rast[..., 3].reshape(-1).long()] = True          # id + 1, 0 = empty
+    return mask[1:]
+
+
+def occlusion_mask_from_face_mask(point_cell_indices, face_mask, n_background=0):
+    """occlusion_mask() for a precomputed boolean face mask."""
+    keep = face_mask[point_cell_indices]
+    if n_background:
+        keep = torch.cat([keep, torch.ones(n_background, dtype=torch.bool, device=keep.device)])
+    return keep
+
+
 def occlusion_mask(point_cell_indices, face_idx_to_render, n_faces, n_background=0):
     """Per-Gaussian keep mask of the Frosting occlusion culling (frosting_model.py:1564-1586):
     a shell Gaussian survives iff the base face of its cell is visible; background Gaussians

@@ -89,6 +89,10 @@ def test_occlusion_culling_mask_c4_shape(gpu_device):
     cell = torch.randint(0, F, (P,), generator=g).to(dev)
     keep = M.occlusion_mask(cell, vis, F, n_background=100)
     assert keep.shape[0] == P + 100 and keep[-100:].all()
+    # the boolean-mask route (no torch.unique) selects the same faces and Gaussians
+    fm = M.visible_face_mask(verts.to(dev), faces.to(dev), cam.projmatrix.to(dev), cam.image_height, cam.image_width)
+    assert torch.equal(torch.nonzero(fm).flatten(), vis.sort().values)
+    assert torch.equal(M.occlusion_mask_from_face_mask(cell, fm, n_background=100), keep)
     assert abs(keep[:P].float().mean().item() - frac) < 0.02
 
 

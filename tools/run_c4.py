@@ -37,10 +37,15 @@ verts_d, faces_d, cell_d = verts.to(dev), faces.to(dev), cell.to(dev)
 ctx = M.RasterizeGLContext()
 
 def step(fused):
-    vis = M.visible_faces(verts_d, faces_d, cam.projmatrix, 1056, 1600, ctx)
-    keep = M.occlusion_mask(cell_d, vis, F)
     e = torch.Tensor([])
-    if fused:   # occlusion mask as a skip flag inside preprocess (frg_forward_ex keep_mask)
+    if fused:   # face mask by one index_put (no unique), occlusion mask as a skip flag inside preprocess
+        fm = M.visible_face_mask(verts_d, faces_d, cam.projmatrix, 1056, 1600, ctx)
+        keep = M.occlusion_mask_from_face_mask(cell_d, fm)
+        vis = fm
+    else:
+        vis = M.visible_faces(verts_d, faces_d, cam.projmatrix, 1056, 1600, ctx)
+        keep = M.occlusion_mask(cell_d, vis, F)
+    if fused:
         args = (bg, scene.means3D, e, scene.opacities, scene.scales, scene.rotations, 1.0, e,
                 cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, 1056, 1600, scene.shs, 3, cam.campos, False, False)
         out = _C.rasterize_gaussians(*args, keep_mask=keep)
@@ -69,7 +74,8 @@ for fused in (False, True):
         _C.rasterize_gaussians_backward(*bargs)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         tm.append(t1 - t0); tr.append(t2 - t1); tb.append(t3 - t2)
-    print(f"C4 ({'skip flag' if fused else 'compaction'}): P={P} tris={F} visible faces {vis.numel()} ({vis.numel()/F:.3f}) "
+    nvis = int(vis.sum()) if vis.dtype == torch.bool else vis.numel()
+    print(f"C4 ({'face mask + skip flag' if fused else 'unique + compaction'}): P={P} tris={F} visible faces {nvis} ({nvis/F:.3f}) "
           f"kept Gaussians {int(keep.sum())} R={out[0]}")
     print(f"  mesh raster + unique: {1e3*np.median(tm):.3f} ms ; raster + cull + forward: {1e3*np.median(tr):.3f} ms ; "
           f"backward: {1e3*np.median(tb):.3f} ms")
