@@ -338,14 +338,16 @@ def test_large_image_binning_path(gpu_device):
         _lib.set_option("global_bins", 0)
 
 
-@pytest.mark.parametrize("cfg,P,exact", [("mini", 3000, 1), ("mini", 3000, 0), ("c2", 60000, 0)])
-def test_tight_binning_is_invisible_in_every_output(gpu_device, cfg, P, exact):
+@pytest.mark.parametrize("cfg,P,exact,global_bins", [("mini", 3000, 1, 0), ("mini", 3000, 0, 0), ("c2", 60000, 0, 0),
+                                                      ("mini", 2500, 0, 1)])
+def test_tight_binning_is_invisible_in_every_output(gpu_device, cfg, P, exact, global_bins):
     """Option "tight_binning": (Gaussian, tile) instances that provably cannot reach alpha >= 1/255
     anywhere in the tile are dropped when the lists are built instead of when they are walked.
     num_rendered, radii, the image and every gradient stay bit-identical; the tile lists become
     order-preserving sub-lists of the reference's."""
     scene, cam, bg = scenes.config_scene(cfg, 3, P=P)
     _lib.set_option("exact_blend", exact)
+    _lib.set_option("global_bins", global_bins)          # also the large-image (global-atomic) binning path
     out_a, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
     st_a = State(scene.P, cam.image_width, cam.image_height, out_a[0], out_a[3], out_a[4], out_a[5])
     ranges_a, pl_a = st_a.ranges.cpu().numpy().copy(), st_a.point_list.cpu().numpy().copy()
@@ -375,6 +377,7 @@ def test_tight_binning_is_invisible_in_every_output(gpu_device, cfg, P, exact):
     finally:
         _lib.set_option("tight_binning", 0)
         _lib.set_option("exact_blend", 0)
+        _lib.set_option("global_bins", 0)
 
 
 @pytest.mark.parametrize("P,spread,planes", [(500, 0.5, 0), (3000, 0.3, 0), (9000, 0.15, 0), (30000, 0.08, 0),
