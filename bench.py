@@ -250,6 +250,11 @@ def main():
         R = int(vpr.true_num_rendered)
         N = cam.image_width * cam.image_height
         T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
+        from frosting_amd.introspect import State      # report-only: per-tile list statistics
+        if not args.tight_binning and tight is not None:
+            vpr.forward(cam_d, bg_d, deferred=False)   # the extra pass left tight lists in the buffers
+        rng = State(P, cam.image_width, cam.image_height, R, vpr.geom.buf, vpr.binning.buf, vpr.img.buf).ranges
+        tile_len = (rng[:, 1] - rng[:, 0]).float()
         B = stage_bytes(P, V, R, N, T)
         total_bytes = 312 * P + 614 * V + 160 * R + 40 * N + 8 * T
         out = {
@@ -258,7 +263,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, "
                                    f"forward+backward, 1 view per GPU per step", "P": P, "visible": V,
-                       "num_rendered": R, "tiles": T, "parallelism": f"view-parallel x{world}",
+                       "num_rendered": R, "instances_per_visible": R / max(V, 1), "tiles": T,
+                       "tile_list_mean": float(tile_len.mean()), "tile_list_max": int(tile_len.max()),
+                       "parallelism": f"view-parallel x{world}",
                        "exchange": ("none" if not exchanging else
                                     ("all-reduce of 59 floats/Gaussian" if args.exchange == "allreduce" else
                                      "factored: all-reduce of 11 floats/Gaussian + all-gather of dRGB (3 floats), "
