@@ -30,8 +30,11 @@ int fail(int code, const char* fmt, ...)
 std::atomic<int> g_exact_blend{-1};
 std::atomic<int> g_profile{0};
 std::atomic<int> g_profile_stage{-1};  // -1: every stage; k: only stage k gets events (each record costs ~3 us of stream time)
-std::atomic<int> g_global_bins{0};
-std::atomic<int> g_tight_binning{0};  // test hook: force the large-image (global-atomic) binning path
+// Options below shape the FORWARD only.  What a backward needs to know about the forward that filled its
+// buffers travels with those buffers: the carve of every field the backward reads depends on (P, W, H, R)
+// alone, and the binning mode is stamped into the image chunk's counters (Counters::tight_binning).
+std::atomic<int> g_global_bins{0};    // test hook: force the large-image (global-atomic) binning path
+std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
 // recorded on the caller's stream between the kernels of one forward / backward;
@@ -44,38 +47,46 @@ struct StageTimers {
     hipEvent_t ev[ST_COUNT][ST_SLOTS][2];
     unsigned launches[ST_COUNT];
     bool init = false;
-    int device = -1;
     bool ensure()
     {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (init && dev == device) return true;
-        if (init)
-            for (int i = 0; i < ST_COUNT; i++)
-                for (int k = 0; k < ST_SLOTS; k++) { (void)hipEventDestroy(ev[i][k][0]); (void)hipEventDestroy(ev[i][k][1]); }
+        if (init) return true;
         for (int i = 0; i < ST_COUNT; i++) {
-            for (int k = 0; k < ST_SLOTS; k++) { (void)hipEventCreate(&ev[i][k][0]); (void)hipEventCreate(&ev[i][k][1]); }
+            for (int k = 0; k < ST_SLOTS; k++) {
+                if (hipEventCreate(&ev[i][k][0]) != hipSuccess || hipEventCreate(&ev[i][k][1]) != hipSuccess) return false;
+            }
             launches[i] = 0;
         }
         init = true;
-        device = dev;
         return true;
     }
 };
-thread_local StageTimers g_timers;
+// One timer set per DEVICE, shared by every host thread (torch runs autograd backward on its engine
+// thread: thread-local timers would never show the backward stages to the thread that asks for them).
+constexpr int kMaxDevices = 16;
+std::mutex g_timers_mu;
+StageTimers g_timers[kMaxDevices];
 
 struct StageScope {
-    int id; hipStream_t s; bool on; int slot;
-    StageScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile.load() != 0), slot(0)
+    int id; hipStream_t s; bool on; int slot; int dev;
+    StageScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile.load() != 0), slot(0), dev(-1)
     {
         const int only = g_profile_stage.load();
         if (only >= 0 && only != id) on = false;
-        if (on && !g_timers.ensure()) on = false;
-        if (on) { slot = (int)(g_timers.launches[id] % ST_SLOTS); (void)hipEventRecord(g_timers.ev[id][slot][0], s); }
+        if (!on) return;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { on = false; return; }
+        std::lock_guard<std::mutex> lk(g_timers_mu);
+        StageTimers& t = g_timers[dev];
+        if (!t.ensure()) { on = false; return; }
+        slot = (int)(t.launches[id] % ST_SLOTS);
+        (void)hipEventRecord(t.ev[id][slot][0], s);
     }
     ~StageScope()
     {
-        if (on) { (void)hipEventRecord(g_timers.ev[id][slot][1], s); g_timers.launches[id]++; }
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_timers_mu);
+        StageTimers& t = g_timers[dev];
+        (void)hipEventRecord(t.ev[id][slot][1], s);
+        t.launches[id]++;
     }
 };
 
@@ -201,18 +212,22 @@ int frg_stage_times(float* ms, int n)
 {
     if (!ms || n < ST_COUNT) return fail(FRG_EINVAL, "need room for %d stages", (int)ST_COUNT);
     for (int i = 0; i < n; i++) ms[i] = -1.0f;
-    if (!g_timers.init) return ST_COUNT;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return ST_COUNT;
+    std::lock_guard<std::mutex> lk(g_timers_mu);
+    StageTimers& tm = g_timers[dev];
+    if (!tm.init) return ST_COUNT;
     for (int i = 0; i < ST_COUNT; i++) {
-        const unsigned cnt = g_timers.launches[i] < (unsigned)ST_SLOTS ? g_timers.launches[i] : (unsigned)ST_SLOTS;
+        const unsigned cnt = tm.launches[i] < (unsigned)ST_SLOTS ? tm.launches[i] : (unsigned)ST_SLOTS;
         double sum = 0.0;
         unsigned good = 0;
         for (unsigned k = 0; k < cnt; k++) {
-            if (hipEventSynchronize(g_timers.ev[i][k][1]) != hipSuccess) continue;
+            if (hipEventSynchronize(tm.ev[i][k][1]) != hipSuccess) continue;
             float t = -1.0f;
-            if (hipEventElapsedTime(&t, g_timers.ev[i][k][0], g_timers.ev[i][k][1]) == hipSuccess) { sum += t; good++; }
+            if (hipEventElapsedTime(&t, tm.ev[i][k][0], tm.ev[i][k][1]) == hipSuccess) { sum += t; good++; }
         }
         if (good) ms[i] = (float)(sum / good);
-        g_timers.launches[i] = 0;
+        tm.launches[i] = 0;
     }
     return ST_COUNT;
 }
@@ -285,7 +300,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         FRG_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), stream));
         return 0;
     }
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background || !radii)
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background)
         return fail(FRG_EINVAL, "null required pointer");
     if ((shs == nullptr) == (colors_precomp == nullptr))
         return fail(FRG_EINVAL, "provide exactly one of shs / colors_precomp");
@@ -303,6 +318,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (!geom_chunk || !img_chunk) return fail(FRG_EALLOC, "allocation callback returned null");
     const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
     const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height, g_global_bins.load() != 0);
+    if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:228-231
 
     PendingCounters* pend = nullptr;
     if (capacity > 0) {
@@ -446,7 +462,7 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
     hipStream_t stream = (hipStream_t)hip_stream;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
     if (P == 0) return FRG_OK;
-    if (!means3D || !radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background ||
+    if (!means3D || !geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background ||
         !viewmatrix || !projmatrix || !campos)
         return fail(FRG_EINVAL, "null required pointer");
     if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
@@ -457,11 +473,17 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
         return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_backward_workspace_bytes(P, R));
     (void)colors_precomp;  // forward copied precomputed colours into the geometry state
 
-    const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+    // Nothing here depends on the process-wide binning options: every field of the three chunks that the
+    // backward reads is carved from (P, W, H, R) alone (the option-dependent matrices of the binning stage
+    // come last in the image chunk), and the kernels take the forward's binning mode from the counters it
+    // stamped.  "exact_blend" only selects the arithmetic of this backward's own blend pass.
+    frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+    vp.tight = 0;
     const frg::GeomState g = frg::GeomState::carve(geom_buffer, P);
-    const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, g_global_bins.load() != 0);
+    const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, false);
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
+    if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
     {
         StageScope sc_(ST_BLEND_BWD, stream);

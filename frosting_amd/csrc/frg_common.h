@@ -32,6 +32,7 @@ struct GeomState {
     uint32_t* tiles_touched;
     uint32_t* point_offsets; // inclusive scan of tiles_touched (rasterizer_impl.cu:277)
     uint32_t* block_sums;    // per-256-Gaussian block totals -> exclusive prefix
+    int* internal_radii;     // used when the caller passes radii == NULL (rasterizer_impl.cu:228-231)
     size_t bytes;
     __host__ static GeomState carve(char* base, int P)
     {
@@ -44,6 +45,7 @@ struct GeomState {
         s.tiles_touched = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
         s.point_offsets = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
         s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);  // per chunk
+        s.internal_radii = (int*)(base + o); o = align_up(o + Pp * 4, 256);
         s.bytes = o;
         return s;
     }
@@ -57,7 +59,10 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
     uint32_t filtered;       // prefiltered assertion (auxiliary.h:154-162)
     uint32_t overflow;       // deferred-counters forward: num_rendered exceeded the caller's capacity
     uint32_t class_count[FRG_SORT_CLASSES];  // number of tiles per sort size class
-    uint32_t pad2[3];
+    // modes of the forward that filled this image chunk, stamped by scan_kernel: the backward follows
+    // THESE, not the process-wide options at the time it is called
+    uint32_t tight_binning;
+    uint32_t pad2[2];
 };
 __host__ __device__ inline int sort_class_of(uint32_t n)
 {

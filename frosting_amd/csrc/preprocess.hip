@@ -356,7 +356,7 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
 __global__ void __launch_bounds__(1024)
 scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
             uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
-            Counters* __restrict__ counters, uint32_t capacity)
+            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight)
 {
     __shared__ uint32_t ovf_s;
     __shared__ uint32_t wtot[16];
@@ -440,7 +440,7 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
         const int key = sort_subclass_of(v);
         class_tiles[(size_t)(key >> 3) * T + sub_s[key] + atomicAdd(&sub_cur[key], 1u)] = (uint32_t)i;
     }
-    if (tid == 0) counters->max_tile_count = maxc_s;
+    if (tid == 0) { counters->max_tile_count = maxc_s; counters->tight_binning = tight; }
     if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = cls_s[tid];
 }
 
@@ -475,14 +475,17 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
                const Counters* __restrict__ counters, const float4* __restrict__ conic_opacity)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
-    if (counters->overflow) return;   // wave-uniform: the binning buffer is too small for this frame
+    // wave-uniform: the binning buffer is too small for this frame.  Nothing is scattered (every tile list
+    // was left empty by scan_kernel), but point_offsets is still finished: a backward issued before the
+    // caller has seen the overflow walks it, and must find this frame's scan, not a stale one
+    const bool overflow = counters->overflow != 0;
     __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
     __shared__ float2 emit_xy[TIGHT ? FRG_BIN_THREADS : 1];
     __shared__ float4 emit_co[TIGHT ? FRG_BIN_THREADS : 1];
     const int T = gx * gy;
-    if (LDS_BINS) {
+    if (LDS_BINS && !overflow) {
         const uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
         for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = row[t];
         __syncthreads();
@@ -494,6 +497,7 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
         uint32_t total;
         const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
         if (idx < P) point_offsets[idx] = chunk_prefix[c] + inc;
+        if (overflow) continue;
         int x0 = 0, y0 = 0, x1 = 1, y1 = 0;
         uint32_t dbits = 0;
         if (touched) {
@@ -583,7 +587,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     if (img.lds_bins)
         hipLaunchKernelGGL(colsum_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
-                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity);
+                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity, (uint32_t)vp.tight);
     if (img.lds_bins)
         hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     return hipGetLastError();

@@ -37,7 +37,7 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool SH16, bool TIGHT>
+template <bool SH16>
 __global__ void __launch_bounds__(BWD_THREADS, 4)
 preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
@@ -47,7 +47,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float4* __restrict__ xydr, const float4* __restrict__ rgb_clamped,
                       const float4* __restrict__ conic_opacity,
                       const uint32_t* __restrict__ point_offsets, const uint2* __restrict__ cutoff,
-                      const float* __restrict__ slots,
+                      const Counters* __restrict__ counters, const float* __restrict__ slots,
                       float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
@@ -87,7 +87,10 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     if (lane == 0) own_start[64] = S;
     own_info[lane] = make_int4(x0, y0, x1 - x0, (int)__float_as_uint(g.z));
     // tight binning: slots of instances that were never binned (tile_hit false) hold nothing; the
-    // owner's centre and conic sit in the (still unused) SH transpose buffer during this phase
+    // owner's centre and conic sit in the (still unused) SH transpose buffer during this phase.
+    // The mode is the one the FORWARD that filled these buffers ran in (stamped into its counters by
+    // scan_kernel), not the process-wide option at the time of the backward: wave-uniform scalar load.
+    const bool TIGHT = __builtin_amdgcn_readfirstlane((int)counters->tight_binning) != 0;
     float4* own_co = shbuf;                                         // [64]
     float2* own_xy = reinterpret_cast<float2*>(shbuf + 64);         // [64]
     if (TIGHT) {
@@ -442,13 +445,12 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
     const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(o.dL_dsh) % 16 == 0);
-#define FRG_PBW(S16, TI)                                                                                              \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<S16, TI>), grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,          \
+#define FRG_PBW(S16)                                                                                                  \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<S16>), grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,              \
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
-                       g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, slots, o.dL_dmean2D, o.dL_dconic,      \
-                       o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot)
-    if (sh16) { if (vp.tight) FRG_PBW(true, true); else FRG_PBW(true, false); }
-    else      { if (vp.tight) FRG_PBW(false, true); else FRG_PBW(false, false); }
+                       g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
+                       o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot)
+    if (sh16) FRG_PBW(true); else FRG_PBW(false);
 #undef FRG_PBW
     return hipGetLastError();
 }

@@ -9,6 +9,8 @@
 #include "frg_common.h"
 #include "kernels.h"
 
+#include <atomic>
+
 namespace frg {
 
 // Lanes of the wave holding the same 8-bit digit as this lane (invalid lanes excluded).
@@ -354,12 +356,19 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
 {
     if (count <= 0) return hipSuccess;
     const size_t lds = (size_t)CAP * 8 + NW * 1024 + 260 * 4;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_tiles_lds_kernel<NW, CAP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {
+        // the attribute is per device: remember it per device, not per process
+        static std::atomic<unsigned long long> attr_set{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_set.load() & bit)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_tiles_lds_kernel<NW, CAP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set.fetch_or(bit);
+        }
     }
     hipLaunchKernelGGL((sort_tiles_lds_kernel<NW, CAP>), dim3(count), dim3(NW * 64), lds, stream, tile_list, list_len, ranges, pairs, point_list);
     return hipGetLastError();

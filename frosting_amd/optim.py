@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .parallel import PARAM_ORDER
+from .parallel import PARAM_ORDER, flat_layout
 
 
 class FlatAdam:
@@ -32,29 +32,83 @@ class FlatAdam:
         if not 1 <= len(names) <= 8:
             raise ValueError("1..8 parameter groups expected")
         self.names = names
-        self.shapes = {k: tuple(shapes[k]) for k in names}
-        sizes = [int(torch.Size(self.shapes[k]).numel()) for k in names]
-        self.numel = sum(sizes)
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.params, ends, o = {}, [], 0
-        for k, n in zip(names, sizes):
-            self.params[k] = self.flat[o:o + n].view(self.shapes[k])
-            o += n
-            ends.append(o)
-        self._ends = (C.c_longlong * len(names))(*ends)
         self.lrs = {k: float(lrs[k]) for k in names}
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.steps = 0
         self.sh_dc_lr = None if sh_dc_lr is None else float(sh_dc_lr)
+        self._build({k: tuple(shapes[k]) for k in names})
+
+    def _build(self, shapes: dict, old=None):
+        """(Re)allocate the flat buffers for `shapes`; `old` = (params, exp_avg views, exp_avg_sq views,
+        row selector per name) carries state over (densification / pruning)."""
+        names = self.names
+        self.shapes = shapes
+        _, self.layout, self.numel = flat_layout(shapes, names)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        view = lambda buf: {k: buf[o:o + n].view(shapes[k]) for k, (o, n) in self.layout.items()}
+        self.params, self.m, self.v = view(self.flat), view(self.exp_avg), view(self.exp_avg_sq)
+        # segment k ends where segment k+1 starts (its alignment pad rides along with it, all zeros)
+        ends = [self.layout[names[i + 1]][0] if i + 1 < len(names) else self.numel for i in range(len(names))]
+        self._ends = (C.c_longlong * len(names))(*ends)
         n = len(names)
         self._period, self._head = (C.c_int * n)(*([0] * n)), (C.c_int * n)(*([0] * n))
         if self.sh_dc_lr is not None:
-            if "shs" not in self.shapes or len(self.shapes["shs"]) != 3:
+            if "shs" not in shapes or len(shapes["shs"]) != 3:
                 raise ValueError('sh_dc_lr needs a "shs" group of shape [P,K,3]')
             k = names.index("shs")
-            self._period[k], self._head[k] = int(self.shapes["shs"][1] * self.shapes["shs"][2]), int(self.shapes["shs"][2])
+            self._period[k], self._head[k] = int(shapes["shs"][1] * shapes["shs"][2]), int(shapes["shs"][2])
+        if old is not None:
+            for k in names:
+                for dst, src in ((self.params, old[0]), (self.m, old[1]), (self.v, old[2])):
+                    rows = src[k] if old[3] is None else src[k][old[3]]
+                    dst[k][: rows.shape[0]].copy_(rows)
+
+    # ---- densification / pruning (reference: gaussian_model.py _prune_optimizer, cat_tensors_to_optimizer,
+    # replace_tensor_to_optimizer; frosting_optimizer.py keeps the same per-group state) -------------------
+    def _per_gaussian(self):
+        P = {self.shapes[k][0] for k in self.names}
+        if len(P) != 1:
+            raise RuntimeError("prune / append need every group to be per-Gaussian (same leading dimension)")
+        return P.pop()
+
+    def prune(self, keep_mask: torch.Tensor):
+        """Keep the Gaussians with a true entry: parameters and both moments of every group are
+        compacted consistently (gaussian_model.py:_prune_optimizer).  Returns the new params dict."""
+        P = self._per_gaussian()
+        keep = keep_mask.to(self.device).reshape(-1).bool()
+        if keep.numel() != P:
+            raise RuntimeError(f"keep_mask has {keep.numel()} entries, the model has {P} Gaussians")
+        n = int(keep.sum())
+        old = (self.params, self.m, self.v, keep)
+        self._build({k: (n,) + tuple(self.shapes[k][1:]) for k in self.names}, old)
+        return self.params
+
+    def append(self, new_params: dict):
+        """Add Gaussians: new_params[name] is [n, ...]; their moments start at zero
+        (gaussian_model.py:cat_tensors_to_optimizer).  Returns the new params dict."""
+        P = self._per_gaussian()
+        n = {int(new_params[k].shape[0]) for k in self.names}
+        if len(n) != 1:
+            raise RuntimeError("every group needs the same number of new rows")
+        n = n.pop()
+        old = (self.params, self.m, self.v, None)
+        self._build({k: (P + n,) + tuple(self.shapes[k][1:]) for k in self.names}, old)
+        for k in self.names:
+            self.params[k][P:].copy_(new_params[k].to(self.device))
+        return self.params
+
+    def reset(self, name: str, values: torch.Tensor = None, rows=None):
+        """Overwrite a group (or some of its rows) and zero the matching moments
+        (gaussian_model.py:replace_tensor_to_optimizer, used by the opacity reset)."""
+        if name not in self.params:
+            raise KeyError(name)
+        sel = slice(None) if rows is None else rows
+        if values is not None:
+            self.params[name][sel] = values.to(self.device)
+        self.m[name][sel] = 0.0
+        self.v[name][sel] = 0.0
 
     def set_lr(self, name: str, lr: float):
         """Per-group learning-rate schedule hook (reference: update_learning_rate)."""
@@ -68,7 +122,6 @@ class FlatAdam:
             raise RuntimeError("FlatAdam runs on the GPU only (no CPU path)")
         if g.dtype != torch.float32 or g.numel() != self.numel or not g.is_contiguous() or g.device != self.flat.device:
             raise RuntimeError(f"expected a contiguous float32 gradient buffer of {self.numel} elements on {self.flat.device}")
-        self.steps += 1
         lrs = (C.c_float * len(self.names))(*[self.lrs[k] for k in self.names])
         head_lrs = (C.c_float * len(self.names))(*[(self.sh_dc_lr if (k == "shs" and self.sh_dc_lr is not None) else 0.0)
                                                     for k in self.names])
@@ -77,7 +130,8 @@ class FlatAdam:
                                       C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
                                       self._ends, lrs, self._period, self._head, head_lrs, len(self.names),
                                       self.betas[0], self.betas[1], self.eps,
-                                      self.steps, float(grad_scale), stream)
+                                      self.steps + 1, float(grad_scale), stream)
         if rc < 0:
             raise RuntimeError(f"frg_adam_step failed ({rc}): {_lib.last_error()}")
+        self.steps += 1                       # only a step that ran advances the bias correction
         return self.params

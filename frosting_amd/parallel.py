@@ -20,6 +20,21 @@ import torch
 from . import _lib
 
 PARAM_ORDER = ("means3D", "scales", "rotations", "opacities", "shs")
+SEGMENT_ALIGN = 4   # floats: every parameter's segment of the flat layout starts on a 16-byte boundary
+
+
+def flat_layout(shapes: dict, names=None):
+    """Offsets of the named tensors inside the flat fp32 buffer shared by the gradient exchange and the
+    fused optimizer.  Each segment starts on a 16-byte boundary (the backward stores float4 rows into
+    these views); the pad elements belong to the segment before them and stay zero.
+    Returns (names, {name: (offset, numel)}, total)."""
+    names = list(names) if names is not None else [k for k in PARAM_ORDER if k in shapes]
+    out, o = {}, 0
+    for k in names:
+        n = int(torch.Size(tuple(shapes[k])).numel())
+        out[k] = (o, n)
+        o = (o + n + SEGMENT_ALIGN - 1) // SEGMENT_ALIGN * SEGMENT_ALIGN
+    return names, out, o
 
 
 def _hip_sh_reducer(ex: "GradientExchange"):
@@ -57,18 +72,14 @@ class GradientExchange:
         self.device = torch.device(device)
         self.group = process_group
         self.average = average
-        sizes = {k: int(torch.Size(s).numel()) for k, s in self.shapes.items()}
-        self.numel = sum(sizes.values())
+        _, self.layout, self.numel = flat_layout(self.shapes)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
-        self.views, o = {}, 0
-        for k, n in sizes.items():
-            self.views[k] = self.flat[o:o + n].view(self.shapes[k])
-            o += n
+        self.views = {k: self.flat[o:o + n].view(self.shapes[k]) for k, (o, n) in self.layout.items()}
         self.factor_sh = bool(factor_sh) and "shs" in self.shapes
         self._works = []
         if self.factor_sh:
             # "shs" is last in PARAM_ORDER: the dense prefix is everything before it
-            self.dense = self.flat[: self.numel - sizes["shs"]]
+            self.dense = self.flat[: self.layout["shs"][0]]
             P = self.shapes["shs"][0]
             self.payload_numel = 3 * P + 4                  # dRGB[P,3], camera centre[3], pad
             self.own = torch.zeros(self.payload_numel, dtype=torch.float32, device=self.device)
@@ -311,10 +322,9 @@ class ViewParallelRasterizer:
                 rc = L.frg_sh_color_grad(self.P, _p(self.geom.buf), _p(self.radii), _p(self.dL_dcolors), _p(ex.own_drgb), stream)
                 if rc < 0:
                     raise RuntimeError(f"frg_sh_color_grad failed ({rc}): {_lib.last_error()}")
-            tag = (cam.campos.data_ptr(), cam.campos._version)
-            if getattr(ex, "_campos_tag", None) != tag:     # same camera tensor as last time: already there
-                ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
-                ex._campos_tag = tag
+            # 12 bytes, copied every time: a (pointer, version) tag cannot tell a fresh camera tensor that
+            # the caching allocator placed at the previous one's address from the previous one
+            ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
         return g
 
     def allreduce_grads(self, slot: int = 0):

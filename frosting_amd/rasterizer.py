@@ -122,6 +122,11 @@ class _NativeOps:
         return rc, out_color, radii, bufs.geom, bufs.binning, bufs.img
 
     @staticmethod
+    def rasterize_gaussians_masked(*args):
+        """(the 19 arguments of rasterize_gaussians, keep_mask) -- same name as the compiled module's export."""
+        return _NativeOps.rasterize_gaussians(*args[:19], keep_mask=args[19])
+
+    @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                      degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
@@ -203,53 +208,67 @@ def _snapshot(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
-class _RasterizeGaussians(torch.autograd.Function):
-    """Autograd wiring (reference: __init__.py:44-155).  Gradients come back in
-    input order; the settings argument gets None."""
+def _make_autograd_function(ops):
+    """The reference's _RasterizeGaussians (__init__.py:44-155) over one native binding `ops`
+    (an object exporting rasterize_gaussians / rasterize_gaussians_masked / rasterize_gaussians_backward):
+    the ctypes binding above, or the compiled torch extension diff_gaussian_rasterization._C."""
 
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, keep_mask=None):
-        s = raster_settings
-        native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
-                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh,
-                       s.sh_degree, s.campos, s.prefiltered, s.debug)
-        if s.debug:
-            saved = _snapshot(native_args)
-            try:
-                out = _C.rasterize_gaussians(*native_args, keep_mask=keep_mask)
-            except Exception:
-                torch.save(saved, "snapshot_fw.dump")  # same replay fixture as the reference (:83-90)
-                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
-                raise
-        else:
-            out = _C.rasterize_gaussians(*native_args, keep_mask=keep_mask)
-        num_rendered, color, radii, geom, binning, img = out
-        ctx.raster_settings = s
-        ctx.num_rendered = num_rendered
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
-        ctx.mark_non_differentiable(radii)
-        return color, radii
+    class _RasterizeGaussians(torch.autograd.Function):
+        """Autograd wiring.  Gradients come back in input order; the settings argument gets None."""
 
-    @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii):
-        s = ctx.raster_settings
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
-                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, sh, s.sh_degree, s.campos,
-                       geom, ctx.num_rendered, binning, img, s.debug)
-        if s.debug:
-            saved = _snapshot(native_args)
-            try:
-                grads = _C.rasterize_gaussians_backward(*native_args)
-            except Exception:
-                torch.save(saved, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-                raise
-        else:
-            grads = _C.rasterize_gaussians_backward(*native_args)
-        g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots = grads
-        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None, None
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings, keep_mask=None):
+            s = raster_settings
+            native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                           s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh,
+                           s.sh_degree, s.campos, s.prefiltered, s.debug)
+
+            def run():
+                if keep_mask is None:
+                    return ops.rasterize_gaussians(*native_args)
+                return ops.rasterize_gaussians_masked(*native_args, keep_mask)
+            if s.debug:
+                saved = _snapshot(native_args)
+                try:
+                    out = run()
+                except Exception:
+                    torch.save(saved, "snapshot_fw.dump")  # same replay fixture as the reference (:83-90)
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise
+            else:
+                out = run()
+            num_rendered, color, radii, geom, binning, img = out
+            ctx.raster_settings = s
+            ctx.num_rendered = num_rendered
+            ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+            ctx.mark_non_differentiable(radii)
+            return color, radii
+
+        @staticmethod
+        def backward(ctx, grad_out_color, _grad_radii):
+            s = ctx.raster_settings
+            colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+            native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                           s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, sh, s.sh_degree, s.campos,
+                           geom, ctx.num_rendered, binning, img, s.debug)
+            if s.debug:
+                saved = _snapshot(native_args)
+                try:
+                    grads = ops.rasterize_gaussians_backward(*native_args)
+                except Exception:
+                    torch.save(saved, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise
+            else:
+                grads = ops.rasterize_gaussians_backward(*native_args)
+            g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots = grads
+            return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None, None
+
+    return _RasterizeGaussians
+
+
+_RasterizeGaussians = _make_autograd_function(_C)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -262,6 +281,9 @@ class GaussianRasterizer(nn.Module):
     """``GaussianRasterizer(raster_settings)(means3D=..., means2D=..., opacities=..., shs=|colors_precomp=,
     scales=+rotations=|cov3D_precomp=) -> (image [3,H,W], radii [P] int32)`` (reference :171-220)."""
 
+    _ops = _C                              # native binding (subclasses rebind: make_rasterizer_class)
+    _function = _RasterizeGaussians
+
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
@@ -269,7 +291,7 @@ class GaussianRasterizer(nn.Module):
     def markVisible(self, positions):
         with torch.no_grad():
             s = self.raster_settings
-            return _C.mark_visible(positions, s.viewmatrix, s.projmatrix)
+            return self._ops.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, keep_mask=None):
@@ -282,7 +304,7 @@ class GaussianRasterizer(nn.Module):
         if (not have_sr and cov3D_precomp is None) or (partial_sr and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         empty = torch.Tensor([])  # the reference's encoding of an absent input
-        return rasterize_gaussians(
+        return self._function.apply(
             means3D, means2D,
             empty if shs is None else shs,
             empty if colors_precomp is None else colors_precomp,
@@ -291,3 +313,11 @@ class GaussianRasterizer(nn.Module):
             empty if rotations is None else rotations,
             empty if cov3D_precomp is None else cov3D_precomp,
             self.raster_settings, keep_mask)
+
+
+def make_rasterizer_class(ops):
+    """GaussianRasterizer bound to another native binding with the same exports (the compiled
+    torch extension): returns (GaussianRasterizer subclass, its autograd Function)."""
+    fn = _make_autograd_function(ops)
+    cls = type("GaussianRasterizer", (GaussianRasterizer,), {"_ops": ops, "_function": fn, "__doc__": GaussianRasterizer.__doc__})
+    return cls, fn

@@ -28,7 +28,9 @@ def test_flat_adam_matches_torch_adam(gpu_device, P, K):
             grads["opacities"].zero_()                      # a group without gradient signal this step
             ours.set_lr("means3D", 0.8e-4)                  # schedule hook
             ref.param_groups[0]["lr"] = 0.8e-4
-        flat = torch.cat([grads[k].reshape(-1) for k in PARAM_ORDER]).to(dev)
+        flat = torch.zeros(ours.numel, device=dev)          # the optimizer's layout (16-byte aligned segments)
+        for k, (o, n) in ours.layout.items():
+            flat[o:o + n] = grads[k].reshape(-1).to(dev)
         ours.step(flat)
         for p, k in zip(ref_params, PARAM_ORDER):
             p.grad = grads[k].to(dev)
@@ -41,10 +43,8 @@ def test_flat_adam_matches_torch_adam(gpu_device, P, K):
     for p, k in zip(ref_params, PARAM_ORDER):
         close(ours.params[k], p.detach())
         st = ref.state[p]
-        lo = sum(int(torch.Size(shapes[n]).numel()) for n in PARAM_ORDER[:PARAM_ORDER.index(k)])
-        hi = lo + p.numel()
-        close(ours.exp_avg[lo:hi].view_as(p), st["exp_avg"])
-        close(ours.exp_avg_sq[lo:hi].view_as(p), st["exp_avg_sq"])
+        close(ours.m[k], st["exp_avg"])
+        close(ours.v[k], st["exp_avg_sq"])
 
 
 def test_flat_adam_grad_scale_and_errors(gpu_device):
@@ -52,7 +52,7 @@ def test_flat_adam_grad_scale_and_errors(gpu_device):
     shapes = dict(means3D=(10, 3), opacities=(10, 1))
     a = FlatAdam(shapes, dict(means3D=1e-2, opacities=1e-2), dev)
     b = FlatAdam(shapes, dict(means3D=1e-2, opacities=1e-2), dev)
-    g = torch.randn(40, device=dev)
+    g = torch.randn(a.numel, device=dev)
     a.step(g, grad_scale=0.125)          # mean over 8 views folded into the update
     b.step(g * 0.125)
     assert torch.equal(a.flat, b.flat)
@@ -87,3 +87,64 @@ def test_flat_adam_dc_and_rest_groups_on_one_sh_tensor(gpu_device):
     # the two learning rates really differ: DC moved ~20x further than the rest
     moved = (ours.params["shs"].cpu() - sh0).abs()
     assert float(moved[:, 0].mean()) > 10 * float(moved[:, 1:].mean())
+
+
+def test_flat_adam_prune_append_reset_follow_torch(gpu_device):
+    """Densification / pruning (gaussian_model.py: _prune_optimizer, cat_tensors_to_optimizer,
+    replace_tensor_to_optimizer): the surviving rows keep parameters and both moments, new rows start
+    with zero moments -- checked against torch.optim.Adam whose state is edited the reference's way."""
+    dev = gpu_device
+    P, K = 37, 4
+    shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
+    lrs = dict(means3D=1e-3, scales=5e-3, rotations=1e-3, opacities=5e-2, shs=2.5e-3)
+    g = torch.Generator().manual_seed(7)
+    ours = FlatAdam(shapes, lrs, dev)
+    ref_p = {}
+    for k in PARAM_ORDER:
+        init = torch.randn(shapes[k], generator=g)
+        ours.params[k].copy_(init)
+        ref_p[k] = torch.nn.Parameter(init.clone().to(dev))
+    ref = torch.optim.Adam([{"params": [ref_p[k]], "lr": lrs[k], "name": k} for k in PARAM_ORDER], lr=0.0, eps=1e-15)
+
+    def both_step():
+        flat = torch.zeros(ours.numel, device=dev)
+        for k, (o, n) in ours.layout.items():
+            gr = torch.randn(ours.shapes[k], generator=g).to(dev)
+            flat[o:o + n] = gr.reshape(-1)
+            ref_p[k].grad = gr
+        ours.step(flat)
+        ref.step()
+
+    def ref_replace(k, tensor, m, v):
+        grp = next(gr for gr in ref.param_groups if gr["name"] == k)
+        st = ref.state.pop(grp["params"][0])
+        newp = torch.nn.Parameter(tensor)
+        st["exp_avg"], st["exp_avg_sq"] = m, v
+        grp["params"][0] = newp
+        ref.state[newp] = st
+        ref_p[k] = newp
+
+    for _ in range(3):
+        both_step()
+    keep = torch.rand(P, generator=g) > 0.3
+    ours.prune(keep)
+    kd = keep.to(dev)
+    for k in PARAM_ORDER:
+        st = ref.state[ref_p[k]]
+        ref_replace(k, ref_p[k].detach()[kd].clone(), st["exp_avg"][kd].clone(), st["exp_avg_sq"][kd].clone())
+    n_new = 9
+    new = {k: torch.randn((n_new,) + tuple(shapes[k][1:]), generator=g) for k in PARAM_ORDER}
+    ours.append(new)
+    for k in PARAM_ORDER:
+        st = ref.state[ref_p[k]]
+        z = torch.zeros((n_new,) + tuple(shapes[k][1:]), device=dev)
+        ref_replace(k, torch.cat([ref_p[k].detach(), new[k].to(dev)]), torch.cat([st["exp_avg"], z]), torch.cat([st["exp_avg_sq"], z]))
+    ours.reset("opacities", torch.full_like(ours.params["opacities"], 0.01))
+    ref_replace("opacities", torch.full_like(ref_p["opacities"].detach(), 0.01), torch.zeros_like(ref_p["opacities"]),
+                torch.zeros_like(ref_p["opacities"]))
+    assert ours.params["means3D"].shape[0] == int(keep.sum()) + n_new
+    for _ in range(3):
+        both_step()
+    for k in PARAM_ORDER:
+        torch.testing.assert_close(ours.params[k], ref_p[k].detach(), rtol=2e-6, atol=4e-7 * float(ref_p[k].abs().max()))
+        torch.testing.assert_close(ours.m[k], ref.state[ref_p[k]]["exp_avg"], rtol=2e-6, atol=1e-7)

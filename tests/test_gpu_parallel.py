@@ -182,7 +182,10 @@ def _rank_worker(rank, world, port, factored, P, q):
             vpr.backward(gpix, slot)                                       # ... under this backward
             vpr.wait_exchange(slot)                                        # joined before the buffer is exchanged again
             vpr.start_exchange(slot)
-        out = [vpr.wait_exchange(s).clone() for s in (0, 1)]
+        out = []
+        for s in (0, 1):                                                   # named views, packed: the flat buffer pads
+            vpr.wait_exchange(s)                                           # every segment to a 16-byte boundary
+            out.append(torch.cat([vpr.exchanges[s].views[n].reshape(-1) for n in PARAM_ORDER]))
         torch.cuda.synchronize(dev)
         assert torch.equal(out[0], out[1])
         q.put((rank, out[0].cpu().numpy()))

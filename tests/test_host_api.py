@@ -89,9 +89,20 @@ def test_product_does_not_import_oracle():
 
 
 def test_drop_in_import_name():
+    """The reference's package name serves the same host API over the COMPILED torch extension
+    (diff_gaussian_rasterization._C, built by setup.py), not over the ctypes binding."""
     import diff_gaussian_rasterization as d
-    assert d.GaussianRasterizer is GaussianRasterizer
-    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(d._C))
+    assert issubclass(d.GaussianRasterizer, GaussianRasterizer) and d.GaussianRasterizer.__name__ == "GaussianRasterizer"
+    assert d.GaussianRasterizationSettings is GaussianRasterizationSettings
+    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(d._C))   # DGR/ext.cpp:15-18
+    assert type(d._C).__name__ == "module" and d._C.__file__.endswith(".so") and d.GaussianRasterizer._ops is d._C
+    assert d._C.library_version() == _lib.lib().frg_version()
+    # same argument validation on the compiled path, before any device work (rasterize_points.cu:57-59)
+    e = torch.Tensor([])
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        d._C.rasterize_gaussians(e, torch.zeros(4, 2), e, e, e, e, 1.0, e, e, e, 1.0, 1.0, 8, 8, e, 0, e, False, False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        d._C.rasterize_gaussians(e, torch.zeros(4, 3), e, e, e, e, 1.0, e, e, e, 1.0, 1.0, 8, 8, e, 0, e, False, False)
 
 
 def test_extended_entry_points_validate_arguments_without_a_gpu():

@@ -41,7 +41,9 @@ def _worker(rank, world, port, P, K, q):
 
 def test_flat_buffer_layout():
     ex = GradientExchange(dict(means3D=(5, 3), scales=(5, 3), rotations=(5, 4), opacities=(5, 1), shs=(5, 16, 3)), "cpu")
-    assert ex.numel == 5 * 59 and ex.nbytes == 5 * 236
+    # 15 + 15 + 20 + 5 + 240 floats, every segment padded to a 16-byte boundary: 16 + 16 + 20 + 8 + 240
+    assert ex.numel == 300 and ex.nbytes == 1200
+    assert all(v.data_ptr() % 16 == 0 for v in ex.views.values())
     ex.views["shs"].fill_(2.0)
     assert float(ex.flat.sum()) == 2.0 * 5 * 48
     assert ex.views["means3D"].data_ptr() == ex.flat.data_ptr()
@@ -120,7 +122,8 @@ def _factored_worker(rank, world, port, P, K, deg, q):
     ex.views["shs"].copy_(shs)                   # what the backward leaves there; replaced by the rebuild
     ex.own_drgb.copy_(drgb)
     ex.own_campos.copy_(campos)
-    assert ex.wire_floats_per_rank == 11 * P + 3 * P + 4
+    # 11 dense floats per Gaussian (segments padded to 16 bytes) + the all-gather payload
+    assert 11 * P + 3 * P + 4 <= ex.wire_floats_per_rank == ex.layout["shs"][0] + 3 * P + 4 <= 11 * P + 12 + 3 * P + 4
     ex.start()
     ex.wait()
     q.put((rank, {k: ex.views[k].numpy().copy() for k in PARAM_ORDER}))
