@@ -7,7 +7,8 @@
 //   rast [H,W,4] float32 = (u, v, z/w, triangle_id + 1), all zero where no triangle;
 //        u, v = perspective-correct barycentrics of vertex 0 and 1; pixel (col i, row j) is
 //        sampled at NDC ((i+0.5)/W*2-1, (j+0.5)/H*2-1); fragments outside -1 <= z/w <= 1 or
-//        behind the eye are discarded; nearest z/w wins, ties go to the smaller triangle id.
+//        behind the eye are discarded; nearest z/w wins, ties go to the smaller triangle id;
+//        coverage by the top-left fill rule on exactly shared edge functions (see FILL RULE below).
 //
 // 2-D homogeneous rasterisation (edge functions from the adjugate of [x y w]), so triangles
 // that cross the w = 0 plane need no clipping.  One thread per triangle walks its pixel
@@ -22,8 +23,11 @@ namespace frg {
 #define MESH_BIG_AREA 1024  // bounding boxes above this many pixels go to the cooperative pass
 
 struct TriSetup {
-    // edge functions e_i(X,Y) = a_i X + b_i Y + c_i (NDC), e_i / sum(e) = perspective-correct barycentric
-    float a[3], b[3], c[3];
+    // Edge functions e_i(X,Y) = a_i X + b_i Y + c_i over NDC, e_i = sign(det) * det[(X,Y,1), v_{i+1}, v_{i+2}]
+    // (2-D homogeneous rasterisation): the pixel is covered iff every e_i >= 0 under the tie rule below, and
+    // e_i / sum(e) is the perspective-correct barycentric of vertex i.  Float64, evaluated with the same
+    // fused expression from both sides of a shared edge -- see edge_coeffs().
+    double a[3], b[3], c[3];
     float z[3], w[3];
     int x0, y0, x1, y1;  // pixel bounding box [x0,x1) x [y0,y1)
     bool ok;
@@ -35,21 +39,48 @@ __device__ __forceinline__ uint32_t ordered_depth(float z)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
 }
 
+// FILL RULE.  Coverage is decided by the three edge functions at the pixel centre
+// ((i + 0.5) / W * 2 - 1, (j + 0.5) / H * 2 - 1) -- OpenGL's sample position, which is what nvdiffrast's
+// rasterizers use.  A centre strictly inside (all e > 0) is covered; a centre exactly ON an edge (e == 0)
+// belongs to the triangle for which that edge is a "left" edge (a > 0), or a horizontal one with b > 0: the
+// top-left rule of D3D / the usual OpenGL implementations, written on the edge normal (a, b).  Two
+// triangles sharing an edge see it with opposite normals, so exactly one of them owns the centre: no
+// double hits, no cracks.
+// For that to hold in floating point both triangles must compute the SAME value for the shared edge.
+// The coefficients are therefore built from the edge's two end points in a canonical order (by position
+// bits, so duplicated vertices -- sphere poles, UV seams -- behave like shared ones) and only negated,
+// which is exact, when the triangle traverses the edge the other way or faces away; the evaluation
+// fma(a, X, fma(b, Y, c)) commutes with that negation bit for bit.
+__device__ __forceinline__ bool pos_less(const float4 p, const float4 q)
+{
+    if (p.x != q.x) return p.x < q.x;
+    if (p.y != q.y) return p.y < q.y;
+    return p.w < q.w;
+}
+
+__device__ __forceinline__ void edge_coeffs(const float4 p, const float4 q, double sgn, double& a, double& b, double& c)
+{
+    // det[(X,Y,1), p, q] = X (p.y q.w - q.y p.w) + Y (q.x p.w - p.x q.w) + (p.x q.y - q.x p.y)
+    const bool swap = pos_less(q, p);
+    const float4 lo = swap ? q : p, hi = swap ? p : q;
+    const double lx = lo.x, ly = lo.y, lw = lo.w, hx = hi.x, hy = hi.y, hw = hi.w;
+    const double ca = fma(ly, hw, -(hy * lw)), cb = fma(hx, lw, -(lx * hw)), cc = fma(lx, hy, -(hx * ly));
+    const double s = swap ? -sgn : sgn;
+    a = s * ca; b = s * cb; c = s * cc;
+}
+
 __device__ __forceinline__ TriSetup tri_setup(const float4 v0, const float4 v1, const float4 v2, int W, int H)
 {
     TriSetup t;
     t.ok = false;
-    // adjugate of M = [[x0 x1 x2],[y0 y1 y2],[w0 w1 w2]] (double: the determinant cancels badly for slivers)
+    // det of M = [[x0 x1 x2],[y0 y1 y2],[w0 w1 w2]] (double: it cancels badly for slivers); its sign is the facing
     const double x0 = v0.x, y0 = v0.y, w0 = v0.w, x1 = v1.x, y1 = v1.y, w1 = v1.w, x2 = v2.x, y2 = v2.y, w2 = v2.w;
-    const double a0 = y1 * w2 - y2 * w1, b0 = x2 * w1 - x1 * w2, c0 = x1 * y2 - x2 * y1;
-    const double a1 = y2 * w0 - y0 * w2, b1 = x0 * w2 - x2 * w0, c1 = x2 * y0 - x0 * y2;
-    const double a2 = y0 * w1 - y1 * w0, b2 = x1 * w0 - x0 * w1, c2 = x0 * y1 - x1 * y0;
-    const double det = x0 * a0 + y0 * b0 + w0 * c0;
+    const double det = x0 * (y1 * w2 - y2 * w1) + y0 * (x2 * w1 - x1 * w2) + w0 * (x1 * y2 - x2 * y1);
     if (!(det != 0.0) || det != det) return t;   // degenerate (zero area in homogeneous space)
-    const double inv = 1.0 / det;                 // dividing by det also folds the facing into the sign
-    t.a[0] = (float)(a0 * inv); t.b[0] = (float)(b0 * inv); t.c[0] = (float)(c0 * inv);
-    t.a[1] = (float)(a1 * inv); t.b[1] = (float)(b1 * inv); t.c[1] = (float)(c1 * inv);
-    t.a[2] = (float)(a2 * inv); t.b[2] = (float)(b2 * inv); t.c[2] = (float)(c2 * inv);
+    const double sgn = det > 0.0 ? 1.0 : -1.0;    // both facings are rasterised (nvdiffrast does not cull)
+    edge_coeffs(v1, v2, sgn, t.a[0], t.b[0], t.c[0]);
+    edge_coeffs(v2, v0, sgn, t.a[1], t.b[1], t.c[1]);
+    edge_coeffs(v0, v1, sgn, t.a[2], t.b[2], t.c[2]);
     t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
     t.w[0] = v0.w; t.w[1] = v1.w; t.w[2] = v2.w;
     // bounding box: exact when every vertex is in front of the eye, whole screen otherwise
@@ -59,11 +90,11 @@ __device__ __forceinline__ TriSetup tri_setup(const float4 v0, const float4 v1, 
         const float mnx = fminf(nx0, fminf(nx1, nx2)), mxx = fmaxf(nx0, fmaxf(nx1, nx2));
         const float mny = fminf(ny0, fminf(ny1, ny2)), mxy = fmaxf(ny0, fmaxf(ny1, ny2));
         if (mxx < -1.f || mnx > 1.f || mxy < -1.f || mny > 1.f) return t;
-        // pixel i centre at ((i + 0.5) / W) * 2 - 1  =>  i = (ndc + 1) * W / 2 - 0.5
-        t.x0 = max(0, (int)floorf((mnx + 1.f) * 0.5f * W - 0.5f));
-        t.x1 = min(W, (int)ceilf((mxx + 1.f) * 0.5f * W - 0.5f) + 1);
-        t.y0 = max(0, (int)floorf((mny + 1.f) * 0.5f * H - 0.5f));
-        t.y1 = min(H, (int)ceilf((mxy + 1.f) * 0.5f * H - 0.5f) + 1);
+        // pixel i centre at ((i + 0.5) / W) * 2 - 1  =>  i = (ndc + 1) * W / 2 - 0.5; one pixel of slack
+        t.x0 = max(0, (int)floorf((mnx + 1.f) * 0.5f * W - 0.5f) - 1);
+        t.x1 = min(W, (int)ceilf((mxx + 1.f) * 0.5f * W - 0.5f) + 2);
+        t.y0 = max(0, (int)floorf((mny + 1.f) * 0.5f * H - 0.5f) - 1);
+        t.y1 = min(H, (int)ceilf((mxy + 1.f) * 0.5f * H - 0.5f) + 2);
     } else if (v0.w <= 1e-6f && v1.w <= 1e-6f && v2.w <= 1e-6f) {
         return t;  // entirely behind the eye
     } else {
@@ -73,24 +104,29 @@ __device__ __forceinline__ TriSetup tri_setup(const float4 v0, const float4 v1, 
     return t;
 }
 
+__device__ __forceinline__ bool edge_owns(double e, double a, double b)
+{
+    return e > 0.0 || (e == 0.0 && (a > 0.0 || (a == 0.0 && b > 0.0)));
+}
+
 // Evaluate one pixel; returns true and (u, v, z/w) when the pixel centre is covered.
 __device__ __forceinline__ bool tri_sample(const TriSetup& t, int px, int py, int W, int H, float& u, float& v, float& zw)
 {
-    const float X = ((float)px + 0.5f) / (float)W * 2.f - 1.f;
-    const float Y = ((float)py + 0.5f) / (float)H * 2.f - 1.f;
-    const float e0 = t.a[0] * X + t.b[0] * Y + t.c[0];
-    const float e1 = t.a[1] * X + t.b[1] * Y + t.c[1];
-    const float e2 = t.a[2] * X + t.b[2] * Y + t.c[2];
-    if (e0 < 0.f || e1 < 0.f || e2 < 0.f) return false;
-    const float s = e0 + e1 + e2;          // = 1 / w at the pixel
-    if (!(s > 0.f)) return false;          // behind the eye or exactly degenerate
-    const float r = 1.f / s;
-    const float b0 = e0 * r, b1 = e1 * r, b2 = e2 * r;
-    const float zc = b0 * t.z[0] + b1 * t.z[1] + b2 * t.z[2];
-    const float wc = b0 * t.w[0] + b1 * t.w[1] + b2 * t.w[2];
-    zw = zc / wc;
+    const double X = ((double)px + 0.5) / (double)W * 2.0 - 1.0;
+    const double Y = ((double)py + 0.5) / (double)H * 2.0 - 1.0;
+    const double e0 = fma(t.a[0], X, fma(t.b[0], Y, t.c[0]));
+    const double e1 = fma(t.a[1], X, fma(t.b[1], Y, t.c[1]));
+    const double e2 = fma(t.a[2], X, fma(t.b[2], Y, t.c[2]));
+    if (!edge_owns(e0, t.a[0], t.b[0]) || !edge_owns(e1, t.a[1], t.b[1]) || !edge_owns(e2, t.a[2], t.b[2])) return false;
+    const double s = e0 + e1 + e2;         // = |det| / w at the pixel
+    if (!(s > 0.0)) return false;          // exactly degenerate
+    const double r = 1.0 / s;
+    const double b0 = e0 * r, b1 = e1 * r, b2 = e2 * r;
+    const double zc = b0 * t.z[0] + b1 * t.z[1] + b2 * t.z[2];
+    const double wc = b0 * t.w[0] + b1 * t.w[1] + b2 * t.w[2];
+    zw = (float)(zc / wc);
     if (!(zw >= -1.f && zw <= 1.f)) return false;
-    u = b0; v = b1;
+    u = (float)b0; v = (float)b1;
     return true;
 }
 

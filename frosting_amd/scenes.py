@@ -122,11 +122,83 @@ CONFIGS = {
                  log_scale=math.log(0.04)),
     "c2": dict(P=100_000, width=800, height=800, fx=1111.0, fy=1111.0, seed=SEED_BASE + 2, bg=(1.0, 1.0, 1.0)),
     "c3": dict(P=3_000_000, width=1600, height=1056, fx=1334.0, fy=1334.0, seed=SEED_BASE + 3, bg=(0.0, 0.0, 0.0)),
+    # BASELINE configs[3]: Frosting refine step, 2 M shell-bound Gaussians + 200 704-triangle occlusion mesh
+    "c4": dict(P=2_000_000, width=1600, height=1056, fx=1334.0, fy=1334.0, seed=SEED_BASE + 4, bg=(0.0, 0.0, 0.0),
+               kind="shell", n_lat=224, n_lon=448),
 }
+
+
+def sphere_mesh(n_lat: int, n_lon: int, radius: float = 1.0):
+    """Lat-long sphere with 2 * n_lat * n_lon triangles (the C4 shell stand-in):
+    verts [ (n_lat + 1) * n_lon, 3 ] float32, faces [F, 3] int32."""
+    th = torch.linspace(0, math.pi, n_lat + 1, dtype=torch.float64)
+    ph = torch.linspace(0, 2 * math.pi, n_lon + 1, dtype=torch.float64)[:-1]
+    T, Pp = torch.meshgrid(th, ph, indexing="ij")
+    verts = (torch.stack([torch.sin(T) * torch.cos(Pp), torch.cos(T), torch.sin(T) * torch.sin(Pp)], -1).reshape(-1, 3) * radius).float()
+    i, j = torch.meshgrid(torch.arange(n_lat), torch.arange(n_lon), indexing="ij")
+    a, b = (i * n_lon + j).reshape(-1), (i * n_lon + (j + 1) % n_lon).reshape(-1)
+    c, d = ((i + 1) * n_lon + j).reshape(-1), ((i + 1) * n_lon + (j + 1) % n_lon).reshape(-1)
+    faces = torch.cat([torch.stack([a, c, b], 1), torch.stack([b, c, d], 1)]).int()
+    return verts.contiguous(), faces.contiguous()
+
+
+@dataclass
+class ShellScene:
+    """BASELINE configs[3] (C4): Gaussians bound to the cells of a shell mesh + that mesh for occlusion culling."""
+    scene: Scene
+    verts: torch.Tensor      # [V,3] float32 (the shell's base mesh, frosting_model.py:1534-1535)
+    faces: torch.Tensor      # [F,3] int32
+    cell: torch.Tensor       # [P] int64: base face of each Gaussian's cell (_point_cell_indices)
+
+    def to(self, device):
+        return ShellScene(self.scene.to(device), self.verts.to(device), self.faces.to(device), self.cell.to(device))
+
+
+def make_shell_scene(P: int, seed: int, n_lat: int = 224, n_lon: int = 448) -> ShellScene:
+    """SURVEY.md 8(d) C4 generator: lat-long unit sphere (224 x 448 -> 200 704 triangles); Gaussians =
+    area-weighted face pick + Dirichlet(1,1,1) barycentrics + normal offset U(-0.02, 0.02)."""
+    verts, faces = sphere_mesh(n_lat, n_lon)
+    g = torch.Generator().manual_seed(seed)
+    v = verts[faces.long()].double()
+    area = torch.linalg.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]).norm(dim=1)
+    cell = torch.multinomial(area / area.sum(), P, replacement=True, generator=g)
+    e = -torch.log(torch.rand(P, 3, generator=g, dtype=torch.float64).clamp_min(1e-300))   # Dirichlet(1,1,1)
+    bary = e / e.sum(1, keepdim=True)
+    pts = (v[cell] * bary[:, :, None]).sum(1)
+    nrm = pts / pts.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    pts = pts + nrm * (torch.rand(P, 1, generator=g, dtype=torch.float64) * 0.04 - 0.02)
+    sc = make_scene(P, seed + 1000)
+    scene = Scene(pts.float().contiguous(), sc.scales, sc.rotations, sc.opacities, sc.shs, sc.sh_degree)
+    return ShellScene(scene, verts, faces, cell.contiguous())
+
+
+def make_skew_scene(P: int, seed: int) -> Scene:
+    """Stress scene for the binning / sort / blend balance: half of the Gaussians in a few
+    tight clusters (tile lists of 10^4-10^5 entries next to empty tiles), a few hundred large near-camera
+    Gaussians (tile rectangles of hundreds of tiles), the rest a thin uniform ball."""
+    g = torch.Generator().manual_seed(seed)
+    base = make_scene(P, seed + 1)
+    f64 = torch.float64
+    n_cl = P // 2
+    centres = torch.tensor([[0.0, 0.0, 0.0], [0.9, 0.3, 0.2], [-0.8, -0.4, 0.5], [0.2, 0.7, -0.6]], dtype=f64)
+    which = torch.randint(0, centres.shape[0], (n_cl,), generator=g)
+    means = base.means3D.double().clone()
+    means[:n_cl] = centres[which] + 0.03 * torch.randn(n_cl, 3, generator=g, dtype=f64)
+    scales = base.scales.double().clone()
+    n_big = min(400, P // 100)
+    if n_big:
+        # large and close to camera 0 (which sits at (0, 0, -4) looking at the origin)
+        means[n_cl:n_cl + n_big] = torch.tensor([0.0, 0.0, -2.8], dtype=f64) + torch.tensor([0.8, 0.5, 0.3], dtype=f64) * \
+            torch.randn(n_big, 3, generator=g, dtype=f64)
+        scales[n_cl:n_cl + n_big] = 0.05 * torch.exp(0.5 * torch.randn(n_big, 3, generator=g, dtype=f64))
+    return Scene(means.float().contiguous(), scales.float().contiguous(), base.rotations, base.opacities, base.shs,
+                 base.sh_degree)
 
 
 def config_scene(name: str, view: int = 0, P: int | None = None):
     cfg = CONFIGS[name]
+    if cfg.get("kind") == "shell":
+        raise ValueError(f"{name} is a shell config: use config_shell_scene()")
     scene = make_scene(P or cfg["P"], cfg["seed"], log_scale=cfg.get("log_scale", math.log(0.005)))
     cam = ring_camera(view, cfg["width"], cfg["height"], cfg["fx"], cfg["fy"])
     bg = torch.tensor(cfg["bg"], dtype=torch.float32)
@@ -139,3 +211,12 @@ def l1_target_grad(image: torch.Tensor, seed: int):
     g = torch.Generator().manual_seed(seed)
     target = torch.rand(image.shape, generator=g).to(image.device)
     return torch.sign(image - target) / image.numel(), target
+
+
+def config_shell_scene(name: str = "c4", view: int = 0, P: int | None = None, n_lat: int | None = None,
+                       n_lon: int | None = None):
+    """(ShellScene, Camera, bg) of a shell config (C4)."""
+    cfg = CONFIGS[name]
+    shell = make_shell_scene(P or cfg["P"], cfg["seed"], n_lat or cfg["n_lat"], n_lon or cfg["n_lon"])
+    cam = ring_camera(view, cfg["width"], cfg["height"], cfg["fx"], cfg["fy"])
+    return shell, cam, torch.tensor(cfg["bg"], dtype=torch.float32)

@@ -44,3 +44,18 @@ build() { # $1 = variant name, rest = extra flags
 }
 build exact -ffp-contract=off
 build fast
+
+# ---- simple-knn (distCUDA2): gaussian_splatting/submodules/simple-knn/simple_knn.cu, same recipe ----------
+# hipCUB / rocThrust stand in for CUB / Thrust through the same shims; -ffp-contract=off so that the squared
+# distances are the reference's left-to-right float32 sums (its own build leaves contraction to nvcc).
+KNN="${FROSTING_REFERENCE:-/root/reference}/gaussian_splatting/submodules/simple-knn"
+if [ -f "$KNN/simple_knn.cu" ]; then
+  mkdir -p "$TMP/knn"
+  sed -e 's/<< </<<</g' -e 's/>> >/>>>/g' "$KNN/simple_knn.cu" > "$TMP/knn/simple_knn.cu"
+  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -I"$HERE/shims" -I"$KNN" -w -ffp-contract=off \
+      -c "$TMP/knn/simple_knn.cu" -o "$TMP/knn/simple_knn.o"
+  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -I"$HERE/shims" -I"$KNN" -w \
+      -c "$HERE/ref_knn_wrapper.cpp" -o "$TMP/knn/wrapper.o"
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$TMP/knn/simple_knn.o" "$TMP/knn/wrapper.o" -o "$HERE/_ref/libref_simple_knn.so"
+  echo "built $HERE/_ref/libref_simple_knn.so"
+fi

@@ -11,3 +11,5 @@
 #define cudaSuccess hipSuccess
 #define cudaGetErrorString hipGetErrorString
 #define cudaError_t hipError_t
+#define cudaMalloc hipMalloc
+#define cudaFree hipFree

@@ -35,7 +35,29 @@ def precomp_colors(scene):
     return torch.sigmoid(scene.shs[:, 0, :].double()).float().contiguous()
 
 
-def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False):
+def native_ops(binding: str):
+    """'ctypes': frosting_amd.rasterizer._C (ctypes over the C ABI); 'ext': the compiled torch extension
+    diff_gaussian_rasterization._C (setup.py).  Both end in the same HIP library."""
+    if binding == "ext":
+        import diff_gaussian_rasterization
+        return diff_gaussian_rasterization._C
+    return _C
+
+
+# Per-tensor bars for gradients against the reference's own backward (rel. L2 over the whole tensor).
+# Ours is bit-reproducible; the reference sums 9 float atomics per (pixel, Gaussian) pair in scheduling
+# order, so it differs from ITSELF run to run by 5e-8 (colour) .. 6e-5 (quaternion) at the C2/C3 sizes
+# (profiles/r01_gpu_check_c3.log).  A comparison passes within max(5 x that measured spread, floor);
+# the floors sit 2-5x above the differences measured there (2e-7 .. 4e-5), two orders below the old 3e-4.
+GRAD_FLOOR = {"dL_dmeans2D": 5e-6, "dL_dcolors": 3e-6, "dL_dopacity": 3e-6, "dL_dmeans3D": 1e-5, "dL_dcov3D": 5e-5,
+              "dL_dsh": 3e-6, "dL_dscales": 8e-5, "dL_drotations": 3e-4}
+
+
+def grad_bar(name, noise=0.0):
+    return max(5.0 * noise, GRAD_FLOOR[name])
+
+
+def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False, ops=None):
     """Call the native entry points directly (what _RasterizeGaussians.forward does)."""
     sc = scene.to(device)
     e = torch.Tensor([])
@@ -47,7 +69,7 @@ def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False):
     args = (bg.to(device), sc.means3D, colors, sc.opacities, scales, rots, 1.0, cov3, cam.viewmatrix.to(device),
             cam.projmatrix.to(device), cam.tanfovx, cam.tanfovy, cam.image_height, cam.image_width, sh,
             sc.sh_degree, cam.campos.to(device), False, debug)
-    out = _C.rasterize_gaussians(*args)
+    out = (ops or _C).rasterize_gaussians(*args)
     return out, args
 
 

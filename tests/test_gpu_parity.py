@@ -45,6 +45,15 @@ def _reset_options():
     yield
     _lib.set_option("exact_blend", 0)
     _lib.set_option("profile", 0)
+    _lib.set_option("tight_binning", 0)
+    _lib.set_option("global_bins", 0)
+
+
+@pytest.fixture(params=["ctypes", "ext"])
+def ops(request):
+    """Both host bindings of the C ABI: ctypes (frosting_amd.rasterizer._C) and the compiled torch
+    extension (diff_gaussian_rasterization._C)."""
+    return Hh.native_ops(request.param)
 
 
 def test_native_library_is_loaded(gpu_device):
@@ -56,11 +65,11 @@ def test_native_library_is_loaded(gpu_device):
 
 @pytest.mark.parametrize("exact", [1, 0])
 @pytest.mark.parametrize("path", RASTER_FIXTURES, ids=[os.path.basename(p) for p in RASTER_FIXTURES])
-def test_against_reference_golden_fixture(gpu_device, path, exact):
+def test_against_reference_golden_fixture(gpu_device, path, exact, ops):
     fx = np.load(path)
     scene, cam, bg = scenes.config_scene(str(fx["cfg"]), int(fx["view"]), P=int(fx["P"]))
     _lib.set_option("exact_blend", exact)
-    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device, str(fx["mode"]), str(fx["cov"]))
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device, str(fx["mode"]), str(fx["cov"]), ops=ops)
     R, color, radii, geom, binning, img = out
     st = State(scene.P, cam.image_width, cam.image_height, R, geom, binning, img)
     vis = fx["radii"] > 0
@@ -80,12 +89,13 @@ def test_against_reference_golden_fixture(gpu_device, path, exact):
     else:
         assert np.abs(image - fx["image"]).mean() <= L1_BAR
     gpix, _ = scenes.l1_target_grad(torch.from_numpy(fx["image"]), int(fx["loss_seed"]))
-    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+    grads = ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
     for name, g in zip(GRAD_NAMES, grads):
         ref = fx["grad_" + name]
         if ref.size == 0 or not np.any(ref):
             continue
-        assert Hh.rel_l2(g.cpu().numpy(), ref) < 3e-4, (name, Hh.rel_l2(g.cpu().numpy(), ref))
+        # one run of the reference's atomics is frozen in the fixture: 5 x its typical spread as noise term
+        assert Hh.rel_l2(g.cpu().numpy(), ref) < Hh.grad_bar(name), (name, Hh.rel_l2(g.cpu().numpy(), ref))
 
 
 @pytest.mark.parametrize("mode,cov", [("sh", "sr"), ("colors", "sr"), ("sh", "cov"), ("colors", "cov")])
@@ -109,7 +119,7 @@ def test_against_c_oracle_all_input_modes(gpu_device, mode, cov):
         if og[name].size == 0 or not np.any(og[name]):
             assert not g.cpu().numpy().any() or og[name].size == 0
             continue
-        assert Hh.rel_l2(g.cpu().numpy(), og[name]) < 2e-4, (name, Hh.rel_l2(g.cpu().numpy(), og[name]))
+        assert Hh.rel_l2(g.cpu().numpy(), og[name]) < Hh.grad_bar(name), (name, Hh.rel_l2(g.cpu().numpy(), og[name]))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
@@ -124,17 +134,20 @@ def test_lower_sh_degrees(gpu_device, deg):
     grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
     og = G.backward(o, gpix.numpy())
     dsh = grads[5].cpu().numpy()
-    assert Hh.rel_l2(dsh, og["dL_dsh"]) < 2e-4
+    assert Hh.rel_l2(dsh, og["dL_dsh"]) < Hh.grad_bar("dL_dsh")
     assert not dsh[:, (deg + 1) ** 2:, :].any()  # coefficients above the active degree get zero gradient
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
-@pytest.mark.parametrize("cfg,P,view", [("c2", 100_000, 0), ("c3", 400_000, 2)])
-def test_bit_exact_vs_reference_rasterizer(gpu_device, cfg, P, view):
-    """The reference's own code (hipcc, -ffp-contract=off) run beside ours on the same tensors."""
+@pytest.mark.parametrize("cfg,P,view,binding", [("c2", 100_000, 0, "ext"), ("c3", 400_000, 2, "ctypes"),
+                                                ("c3", 3_000_000, 0, "ext")])
+def test_bit_exact_vs_reference_rasterizer(gpu_device, cfg, P, view, binding):
+    """The reference's own code (hipcc, -ffp-contract=off) run beside ours on the same tensors, at the FULL
+    sizes of BASELINE.json's configs[1] (C2) and configs[2] (C3: 3 M Gaussians, 1600x1056, 16.4 M instances)."""
+    ops = Hh.native_ops(binding)
     scene, cam, bg = scenes.config_scene(cfg, view, P=P)
     _lib.set_option("exact_blend", 1)
-    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device, ops=ops)
     R, color, radii, geom, binning, img = out
     st = State(P, cam.image_width, cam.image_height, R, geom, binning, img)
     Rr, rcolor, rradii, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
@@ -145,20 +158,30 @@ def test_bit_exact_vs_reference_rasterizer(gpu_device, cfg, P, view):
     assert torch.equal(st.ranges, rst.ranges)
     assert torch.equal(st.point_list, rst.point_list)
     assert torch.equal(st.sort_keys(), rst.point_list_keys)
+    vis = radii > 0
+    assert torch.equal(st.depths[vis], rst.depths[vis]) and torch.equal(st.means2D[vis], rst.means2D[vis])
+    assert torch.equal(st.conic_opacity[vis], rst.conic_opacity[vis])
     assert torch.equal(st.n_contrib, rst.n_contrib)
+    assert torch.equal(st.final_T, rst.final_T)
     assert torch.equal(color, rcolor)
+    del st
     _lib.set_option("exact_blend", 0)  # default product arithmetic: tolerance bar
-    out2, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    out2, _ = Hh.run_ours_native(scene, cam, bg, gpu_device, ops=ops)
     assert float((out2[1] - rcolor).abs().mean()) <= L1_BAR
     assert torch.equal(out2[2], rradii)
     gpix, _ = scenes.l1_target_grad(color.cpu(), 9)
     gpix = gpix.to(gpu_device)
-    grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out2, gpix))
+    grads = ops.rasterize_gaussians_backward(*_bwd_args(args, out2, gpix))
     rg = REF.backward(rst, gpix)
     rg2 = REF.backward(rst, gpix)
+    report = {}
     for name, g in zip(GRAD_NAMES, grads):
-        noise = Hh.rel_l2(rg2[name].cpu(), rg[name].cpu())  # the reference's own run-to-run spread
-        assert Hh.rel_l2(g.cpu(), rg[name].cpu()) < max(5e-4, 20 * noise), name
+        noise = Hh.rel_l2(rg2[name], rg[name])  # the reference's own run-to-run spread
+        report[name] = (Hh.rel_l2(g, rg[name]), noise)
+    print(f"\n[{cfg} P={P}] gradient rel-L2 vs reference (reference vs itself): " +
+          ", ".join(f"{k[3:]} {v[0]:.1e} ({v[1]:.1e})" for k, v in report.items()))
+    for name, (err, noise) in report.items():
+        assert err < Hh.grad_bar(name, noise), (name, err, noise)
 
 
 def test_backward_is_bit_reproducible(gpu_device):
@@ -248,9 +271,9 @@ def test_autograd_module_api_matches_call_sites(gpu_device):
     (rendered_image - target).abs().mean().backward()
     o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
     og = G.backward(o, (torch.sign(rendered_image.detach() - target) / target.numel()).cpu().numpy())
-    assert Hh.rel_l2(means3D.grad.cpu(), og["dL_dmeans3D"]) < 2e-4
-    assert Hh.rel_l2(shs.grad.cpu(), og["dL_dsh"]) < 2e-4
-    assert Hh.rel_l2(screenspace_points.grad.cpu(), og["dL_dmeans2D"]) < 2e-4  # densification statistic
+    assert Hh.rel_l2(means3D.grad.cpu(), og["dL_dmeans3D"]) < Hh.grad_bar("dL_dmeans3D")
+    assert Hh.rel_l2(shs.grad.cpu(), og["dL_dsh"]) < Hh.grad_bar("dL_dsh")
+    assert Hh.rel_l2(screenspace_points.grad.cpu(), og["dL_dmeans2D"]) < Hh.grad_bar("dL_dmeans2D")  # densification statistic
     assert not screenspace_points.grad[:, 2].any()
     vis = rasterizer.markVisible(sc.means3D)
     np.testing.assert_array_equal(vis.cpu().numpy(), G.mark_visible(scene.means3D.numpy(), cam.viewmatrix.numpy(),
@@ -401,3 +424,91 @@ def test_tile_sort_every_size_class(gpu_device, P, spread, planes):
     pl = st.point_list.cpu().numpy().astype(np.int64)
     assert np.array_equal(np.lexsort((pl, keys)), np.arange(R))
     assert np.array_equal(np.bincount(pl, minlength=P), st.tiles_touched.cpu().numpy())
+
+
+def test_backward_follows_the_forwards_modes_not_the_process_options(gpu_device):
+    """The backward takes the binning mode from what the forward stamped into its image chunk: flipping
+    tight_binning / global_bins / between a forward and its backward (two rasterizers in one process, a
+    bench pass in another mode) must not change a single gradient bit."""
+    scene, cam, bg = scenes.config_scene("c2", 4, P=40_000)
+    want = {}
+    for tight in (0, 1):
+        _lib.set_option("tight_binning", tight)
+        out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 23)
+        b = _bwd_args(args, out, gpix.to(gpu_device))
+        want[tight] = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
+        for t2, gb in ((1 - tight, 0), (1 - tight, 1), (tight, 1)):
+            _lib.set_option("tight_binning", t2)            # options changed AFTER the forward
+            _lib.set_option("global_bins", gb)
+            got = _C.rasterize_gaussians_backward(*b)
+            assert all(torch.equal(a, c) for a, c in zip(want[tight], got)), (tight, t2, gb)
+        _lib.set_option("global_bins", 0)
+    for a, c in zip(want[0], want[1]):                       # and the two modes agree with each other
+        assert torch.equal(a, c)
+
+
+def test_radii_may_be_null_like_the_reference(gpu_device):
+    """rasterizer.h:54 / rasterizer_impl.cu:228-231,375-377: radii == nullptr -> the op keeps them in its own
+    geometry state, forward and backward."""
+    import ctypes as C
+    from frosting_amd.parallel import _Arena, _p
+    scene, cam, bg = scenes.config_scene("mini", 5, P=2000)
+    sc, cd, bgd = scene.to(gpu_device), cam.to(gpu_device), bg.to(gpu_device)
+    L = _lib.lib()
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 31)
+    gpix = gpix.to(gpu_device)
+    want = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix))
+    geom, binning, img, work = (_Arena(gpu_device) for _ in range(4))
+    color = torch.empty_like(out[1])
+    stream = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    P = scene.P
+    R = L.frg_forward(geom.cb, binning.cb, img.cb, None, P, 3, 16, _p(bgd), cam.image_width, cam.image_height,
+                      _p(sc.means3D), _p(sc.shs), None, _p(sc.opacities), _p(sc.scales), 1.0, _p(sc.rotations), None,
+                      _p(cd.viewmatrix), _p(cd.projmatrix), _p(cd.campos), float(cam.tanfovx), float(cam.tanfovy), 0,
+                      _p(color), None, 0, stream)
+    assert R == out[0] and torch.equal(color, out[1])
+    ws = int(L.frg_backward_workspace_bytes(P, R))
+    w = work.ensure(ws)
+    f = lambda *s: torch.empty(s, device=gpu_device)
+    g = dict(m2=f(P, 3), op=f(P, 1), col=f(P, 3), m3=f(P, 3), cov=f(P, 6), sh=f(P, 16, 3), sc=f(P, 3), rot=f(P, 4))
+    rc = L.frg_backward(P, 3, 16, R, _p(bgd), cam.image_width, cam.image_height, _p(sc.means3D), _p(sc.shs), None,
+                        _p(sc.scales), 1.0, _p(sc.rotations), None, _p(cd.viewmatrix), _p(cd.projmatrix), _p(cd.campos),
+                        float(cam.tanfovx), float(cam.tanfovy), None, _p(geom.buf), _p(binning.buf), _p(img.buf), _p(gpix),
+                        _p(g["m2"]), None, _p(g["op"]), _p(g["col"]), _p(g["m3"]), _p(g["cov"]), _p(g["sh"]), _p(g["sc"]),
+                        _p(g["rot"]), _p(w), w.numel(), 0, stream)
+    assert rc == 0, _lib.last_error()
+    for a, c in zip(want, (g["m2"], g["col"], g["op"], g["m3"], g["cov"], g["sh"], g["sc"], g["rot"])):
+        assert torch.equal(a, c)
+
+
+def test_deferred_forward_overflow_then_backward_before_finish(gpu_device):
+    """Capacity exceeded on a DIFFERENT view than the one rendered before, and the backward issued before
+    finish() has reported it (the documented order of a pipelined step): nothing may be read out of range,
+    the frame is the background, every gradient is zero, and the repeated view is exact."""
+    from frosting_amd.parallel import ViewParallelRasterizer
+    scene, cam_a, bg = scenes.config_scene("c2", 0, P=60_000)
+    cam_b = scenes.ring_camera(3, cam_a.image_width, cam_a.image_height, 1111.0, 1111.0)
+    dev = gpu_device
+    ref = ViewParallelRasterizer(scene.to(dev), dev)
+    img_b, _ = ref.forward(cam_b.to(dev), bg.to(dev))
+    img_b = img_b.clone()
+    gpix, _ = scenes.l1_target_grad(img_b.cpu(), 77)
+    gpix = gpix.to(dev)
+    ref.backward(gpix)
+    flat_b = ref.exchange.flat.clone()
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, deferred_counters=True)
+    vpr.forward(cam_a.to(dev), bg.to(dev))          # synchronous first view: sizes the arenas
+    vpr.backward(gpix)
+    vpr.capacity = 1000                              # far below view B's instance count
+    img, radii = vpr.forward(cam_b.to(dev), bg.to(dev))
+    vpr.backward(gpix)                               # before finish(): must be harmless
+    torch.cuda.synchronize(dev)
+    assert float(vpr.exchange.flat.abs().max()) == 0.0 and bool(torch.isfinite(vpr.exchange.flat).all())
+    assert torch.equal(img, bg.to(dev)[:, None, None].expand_as(img))
+    assert vpr.finish() is False and vpr.capacity > 1000
+    img2, _ = vpr.forward(cam_b.to(dev), bg.to(dev))
+    vpr.backward(gpix)
+    assert vpr.finish() is True
+    assert torch.equal(img2, img_b) and torch.equal(vpr.exchange.flat, flat_b)

@@ -55,3 +55,40 @@ def test_large_cloud_properties_and_module_shim(gpu_device):
         assert got[i] == ((b[0] + b[1]) + b[2]) / np.float32(3.0)
     with pytest.raises(RuntimeError, match="GPU only"):
         distCUDA2(pts[:10])
+
+
+def _ref_knn(points_dev):
+    """The reference's own SimpleKNN::knn (oracle/_ref/libref_simple_knn.so, built from
+    gaussian_splatting/submodules/simple-knn/simple_knn.cu by oracle/build_ref.sh)."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_simple_knn.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_simple_knn.so not built")
+    L = C.CDLL(path)
+    out = torch.zeros(points_dev.shape[0], dtype=torch.float32, device=points_dev.device)
+    torch.cuda.synchronize()
+    rc = L.ref_knn(C.c_int(points_dev.shape[0]), C.c_void_p(points_dev.data_ptr()), C.c_void_p(out.data_ptr()))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,kind", [(4, "ball"), (1025, "clustered"), (100_000, "clustered"), (3_000_000, "c3"),
+                                    (2_000_000, "shell")])
+def test_hip_matches_the_reference_binary_bit_for_bit(gpu_device, n, kind):
+    """PINNED: frg_knn_mean_dist2 against the reference's simple-knn compiled from its own source, on the
+    3 M points of C3, the 2 M shell-bound points of C4 and clouds with duplicates / far clumps."""
+    from frosting_amd import scenes
+    from frosting_amd.knn import distCUDA2
+    if kind == "c3":
+        p = scenes.make_scene(n, scenes.CONFIGS["c3"]["seed"]).means3D
+    elif kind == "shell":
+        p = scenes.make_shell_scene(n, scenes.CONFIGS["c4"]["seed"]).scene.means3D
+    else:
+        p = torch.from_numpy(_cloud(n, n, kind == "clustered"))
+    p = p.to(gpu_device).contiguous()
+    got = distCUDA2(p)
+    want = _ref_knn(p.clone())
+    assert torch.equal(got, want), f"{int((got != want).sum())} of {n} differ"
+    assert bool(torch.isfinite(got).all())
