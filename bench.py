@@ -7,11 +7,15 @@ Metric (BASELINE.json): train views/sec, forward + backward rasterization at
 
 One "step" = one pass of the hot path over one view: frg_forward + frg_backward
 through the C ABI (the loss gradient dL/dimage is a fixed tensor; the loss itself
-is outside the op and outside the byte model).  With --gpus N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank renders its own camera of
-the 8-camera ring (view-parallel, weak scaling) and the per-Gaussian parameter
-gradients are summed across ranks with one RCCL all-reduce per step -- the
-exchange step north_star names.
+is outside the op and outside the byte model).  --config c2 times the forward only
+(BASELINE configs[1]); --config c4 times the Frosting refine step (configs[3]: triangle
+occlusion raster -> visible-face mask -> culled forward -> backward).
+
+--gpus N > 1: one rank per GPU.  Launched as the driver does it (torch.distributed.run sets
+WORLD_SIZE) the process is one rank; launched bare (`python bench.py --gpus N`) it re-executes
+itself under torch.distributed.run with N ranks on 127.0.0.1.  Every rank renders its own camera
+of the 8-camera ring (view-parallel, weak scaling) and the per-Gaussian parameter gradients are
+summed across ranks over RCCL every step -- the exchange step north_star names.
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,20 +24,72 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from frosting_amd import _lib, scenes  # noqa: E402
-from frosting_amd.parallel import ViewParallelRasterizer  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spinup-steps", type=int, default=100,
+                    help="untimed steps before the W warm-up steps: the process spends seconds on the host building the "
+                         "scene, the idle GPU drops its clocks, and a short warm-up can end before they are back up")
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "mini"])
+    ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informative passes after the timed region (tight binning, API path, reference on this GPU, "
+                         "skewed scene); used under rocprofv3 so that per-kernel averages are those of the headline mode only")
+    ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
+    ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
+    ap.add_argument("--tight-binning", action="store_true",
+                    help="time the whole run with frg_set_option('tight_binning', 1): instances that cannot reach alpha >= "
+                         "1/255 anywhere in their tile are dropped when the tile lists are built (outputs bit-identical, "
+                         "lists = order-preserving sub-lists of the reference's).  Without the flag the headline run keeps "
+                         "the reference's exact lists and the tight mode is timed in an extra pass (field 'tight_binning')")
+    ap.add_argument("--no-tight-pass", action="store_true", help="(kept for older scripts) same as --no-extras")
+    ap.add_argument("--deferred-counters", action="store_true",
+                    help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
+                         "which like the reference blocks on a read-back of num_rendered")
+    ap.add_argument("--exchange", default="factored", choices=["factored", "allreduce"],
+                    help="N>1: 'allreduce' = all 59 floats per Gaussian are summed across ranks; 'factored' = the 11 non-SH "
+                         "floats are summed + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
+                         "every rank (frosting_amd/parallel.py)")
+    ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "direct"],
+                    help="N>1: how the summed part travels: 'allreduce' = one RCCL all-reduce; 'direct' = all-to-all of "
+                         "1/N shards over every xGMI link at once + local sum + all-gather (reduce-scatter / all-gather "
+                         "form of SURVEY 8(e))")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo only for functional tests of the multi-rank path on one GPU")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the exchange path on a single-rank RCCL group when launched without torch.distributed.run")
+    ap.add_argument("--sync-exchange", action="store_true",
+                    help="N>1: wait for the gradient exchange at the end of every step (no overlap with the next render)")
+    return ap.parse_args()
+
+
+def self_launch_if_needed(args):
+    """`python bench.py --gpus N` from a bare shell: become N ranks (one per GPU) under torch.distributed.run."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def stage_bytes(P, V, R, N, T):
@@ -52,20 +108,25 @@ def stage_bytes(P, V, R, N, T):
 
 def pmc_traffic(stage: str, cfg_name: str, P: int):
     """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes of this very
-    workload (profiles/r01_pmc_traffic.json; counters cannot be read from inside the process).
-    None when the run is not the profiled configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"] or not os.path.exists(path):
+    workload (profiles/r0N_pmc_traffic.json, newest round first; counters cannot be read from inside
+    the process).  None when the run is not the profiled configuration."""
+    from frosting_amd import scenes
+    if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"]:
         return None
-    try:
-        return json.load(open(path))["per_launch"][stage]["hbm_bytes_corrected"]
-    except Exception:
-        return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        try:
+            return json.load(open(path))["per_launch"][stage]["hbm_bytes_corrected"]
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(cfg_name: str, P: int):
+def cpu_baseline(cfg_name: str, P: int, backward: bool = True):
     """C restatement of the reference (oracle/gs_oracle.c, OpenMP) timed on the host
-    cores for ONE forward+backward of the same workload -- reported, not a target."""
+    cores for ONE view of the same workload -- reported, not a target."""
+    import numpy as np
+    from frosting_amd import scenes
     from oracle import gs_oracle as G
     G.build()
     scene, cam, bg = scenes.config_scene(cfg_name, 0, P=P)
@@ -75,50 +136,55 @@ def cpu_baseline(cfg_name: str, P: int):
               scales=scene.scales.numpy(), rotations=scene.rotations.numpy(), sh_degree=scene.sh_degree)
     t0 = time.perf_counter()
     st = G.forward(**kw)
-    gpix = (np.sign(st["out_color"] - 0.5) / st["out_color"].size).astype(np.float32)
-    G.backward(st, gpix)
+    if backward:
+        gpix = (np.sign(st["out_color"] - 0.5) / st["out_color"].size).astype(np.float32)
+        G.backward(st, gpix)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "views/s", "cores": G.num_threads(), "kind": "port",
-            "sample": f"1 view fwd+bwd of {cfg_name} at P={P} (R={st['num_rendered']}), {dt:.2f} s wall, OpenMP C port "
-                      f"of the reference algorithm (oracle/gs_oracle.c)"}
+            "sample": f"1 view {'fwd+bwd' if backward else 'forward'} of {cfg_name} at P={P} (R={st['num_rendered']}), {dt:.2f} s "
+                      f"wall, OpenMP C port of the reference algorithm (oracle/gs_oracle.c)"}
+
+
+def reference_on_this_gpu(scene_d, cam_d, bg_d, gpix, backward: bool, iters: int = 5):
+    """The reference's own rasterizer (oracle/_ref fast build = hipcc defaults, compiled from /root/reference by
+    oracle/build_ref.sh) on the same tensors: 'the reference on MI355X' beside ours.  Baseline leg only."""
+    import torch
+    from oracle import ref_rasterizer as REF
+    if not REF.available("fast"):
+        return None
+    kw = dict(means3D=scene_d.means3D, opacities=scene_d.opacities, viewmatrix=cam_d.viewmatrix, projmatrix=cam_d.projmatrix,
+              campos=cam_d.campos, bg=bg_d, width=cam_d.image_width, height=cam_d.image_height, tanfovx=cam_d.tanfovx,
+              tanfovy=cam_d.tanfovy, shs=scene_d.shs, scales=scene_d.scales, rotations=scene_d.rotations,
+              sh_degree=scene_d.sh_degree, variant="fast")
+    fw, bw = [], []
+    for it in range(iters + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        R, _, _, st = REF.forward(**kw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if backward:
+            REF.backward(st, gpix)
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it:   # first iteration: module load
+            fw.append(1e3 * (t1 - t0))
+            bw.append(1e3 * (t2 - t1))
+    return {"forward_ms": statistics.median(fw), "backward_ms": statistics.median(bw) if backward else None,
+            "ms_per_step": statistics.median(fw) + (statistics.median(bw) if backward else 0.0),
+            "note": "the reference's own CUDA sources built for gfx950 with hipcc (oracle/_ref, fast variant), host wall "
+                    "clock per call incl. its allocations and the zero-fill of its gradient outputs, median of "
+                    f"{iters}"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--spinup-steps", type=int, default=100,
-                    help="untimed steps before the W warm-up steps: the process spends seconds on the host building the "
-                         "scene, the idle GPU drops its clocks, and a short warm-up can end before they are back up "
-                         "(seen once: 5.1 ms/step in the timed region against 2.05 in every other run)")
-    ap.add_argument("--config", default="c3", choices=list(scenes.CONFIGS))
-    ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
-    ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
-    ap.add_argument("--tight-binning", action="store_true",
-                    help="time the whole run with frg_set_option('tight_binning', 1): instances that cannot reach alpha >= "
-                         "1/255 anywhere in their tile are dropped when the tile lists are built (outputs bit-identical, "
-                         "lists = order-preserving sub-lists of the reference's).  Without the flag the headline run keeps "
-                         "the reference's exact lists and the tight mode is timed in an extra pass (field 'tight_binning')")
-    ap.add_argument("--no-tight-pass", action="store_true",
-                    help="skip the informative extra pass that times tight binning after the timed region (used under "
-                         "rocprofv3 so that per-kernel averages are not a mix of the two modes)")
-    ap.add_argument("--deferred-counters", action="store_true",
-                    help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
-                         "which like the reference blocks on a read-back of num_rendered; measured equal at C3")
-    ap.add_argument("--exchange", default="factored", choices=["factored", "allreduce"],
-                    help="N>1: 'allreduce' = one all-reduce of all 59 floats per Gaussian; 'factored' = all-reduce of the "
-                         "11 non-SH floats + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
-                         "every rank (frosting_amd/parallel.py)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend; gloo only for functional tests of the multi-rank path on one GPU")
-    ap.add_argument("--force-exchange", action="store_true",
-                    help="run the exchange path on a single-rank RCCL group when launched without torch.distributed.run")
-    ap.add_argument("--sync-exchange", action="store_true",
-                    help="N>1: wait for the gradient all-reduce at the end of every step (no overlap with the next render)")
-    args = ap.parse_args()
+    args = parse_args()
+    self_launch_if_needed(args)
+
+    import torch
+    from frosting_amd import _lib, scenes
+    from frosting_amd import mesh as M
+    from frosting_amd.parallel import ViewParallelRasterizer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -138,47 +204,72 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
 
+    extras = not (args.no_extras or args.no_tight_pass)
     cfg = scenes.CONFIGS[args.config]
     P = args.points or cfg["P"]
-    scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
+    shell = None
+    if cfg.get("kind") == "shell":
+        shell, cam, bg = scenes.config_shell_scene(args.config, rank % 8, P=P)
+        scene = shell.scene
+    else:
+        scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
+    do_backward = args.config != "c2"
     _lib.set_option("exact_blend", 1 if args.exact else 0)
     _lib.set_option("profile", 0 if args.no_stage_timers else 1)
     _lib.set_option("tight_binning", 1 if args.tight_binning else 0)
-    vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD if dist else None,
-                                 factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters)
-    exchanging = dist is not None
+    scene_d = scene.to(dev)
+    vpr = ViewParallelRasterizer(scene_d, dev, process_group=dist.group.WORLD if dist else None,
+                                 factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters,
+                                 reduce=args.reduce)
+    exchanging = dist is not None and do_backward
     cam_d = cam.to(dev)
     bg_d = bg.to(dev)
+    mesh_ctx = M.RasterizeGLContext() if shell is not None else None
+    if shell is not None:
+        verts_d, faces_d, cell_d = shell.verts.to(dev), shell.faces.to(dev), shell.cell.to(dev)
 
-    image, radii = vpr.forward(cam_d, bg_d)
+    def cull_mask():
+        """C4: triangle occlusion raster of the shell's base mesh -> visible faces -> per-Gaussian keep flag
+        (frosting_model.py:1524-1539,1564-1586), every step (the per-frame inference form)."""
+        if shell is None:
+            return None
+        fm = M.visible_face_mask(verts_d, faces_d, cam_d.projmatrix, cam.image_height, cam.image_width, mesh_ctx)
+        return M.occlusion_mask_from_face_mask(cell_d, fm)
+
+    image, radii = vpr.forward(cam_d, bg_d, keep_mask=cull_mask())
     gpix, _ = scenes.l1_target_grad(image.cpu(), 20241022 + rank)
     gpix = gpix.to(dev)
 
-    # Software-pipelined exchange (N > 1): the all-reduce of step k is enqueued right behind its
-    # backward and only waited for when its gradient buffer is needed again (two buffers), so it
-    # overlaps the render of step k+1.  Every step still performs its full forward, backward and
-    # all-reduce, and all of them have completed when the timer stops.  --sync-exchange waits at
+    # Software-pipelined exchange (N > 1): the collectives of step k are enqueued right behind its
+    # backward and only waited for when its gradient buffer is needed again (two buffers), so they
+    # overlap the render of step k+1.  Every step still performs its full forward, backward and
+    # exchange, and all of them have completed when the timer stops.  --sync-exchange waits at
     # the end of every step instead.
     counter = [0]
+    exchange_on = [exchanging]
 
     def step():
         slot = counter[0] % 2
         counter[0] += 1
-        vpr.forward(cam_d, bg_d)
-        if exchanging and not args.sync_exchange:
+        ex = exchange_on[0]
+        vpr.forward(cam_d, bg_d, keep_mask=cull_mask())
+        if not do_backward:
+            vpr.finish()
+            return
+        if ex and not args.sync_exchange:
             # the exchange launched two steps ago on this buffer: its collectives are waited for here, its
             # SH rebuild runs on a side stream under the backward below
             vpr.prefetch_exchange(slot)
         vpr.backward(gpix, slot)             # writes straight into the flat gradient buffer
         if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
-            vpr.forward(cam_d, bg_d, deferred=False)
+            vpr.forward(cam_d, bg_d, deferred=False, keep_mask=cull_mask())
             vpr.backward(gpix, slot)
-        if exchanging and not args.sync_exchange:
+        if ex and not args.sync_exchange:
             vpr.wait_exchange(slot)          # join the rebuild before this buffer's collectives start again
-        if exchanging:
+        if ex:
             vpr.start_exchange(slot)
             if args.sync_exchange:
                 vpr.wait_exchange(slot)
@@ -187,6 +278,21 @@ def main():
         if exchanging:
             vpr.wait_exchange(0)
             vpr.wait_exchange(1)
+
+    def timed(nsteps, fn=step, with_drain=True):
+        """(wall seconds, per-step GPU milliseconds from one event per step boundary on the launch stream)"""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(nsteps):
+            fn()
+            evs[i + 1].record()
+        if with_drain:
+            drain()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(nsteps)]
 
     timers = not args.no_stage_timers
     for _ in range(max(0, args.spinup_steps)):
@@ -207,15 +313,9 @@ def main():
         _lib.set_option("profile_stage", _lib.STAGE_NAMES.index(dom_stage))
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize(dev)
+    dt, per_step_ms = timed(args.steps)
     if dist:
         dist.barrier()
-    dt = time.perf_counter() - t0
     stage_avg, dom_ms = {}, None
     if timers:
         # hipEvents recorded by the C ABI on the launch stream around the dominant kernel of every
@@ -228,27 +328,102 @@ def main():
         drain()
         torch.cuda.synchronize(dev)
         stage_avg = {k: v for k, v in _lib.stage_times().items() if v > 0}
-    tight = None
-    if world == 1 and not exchanging and not args.tight_binning and not args.no_tight_pass:
-        # informative extra pass, after and outside the timed region: the same steps with tight binning
         _lib.set_option("profile", 0)
-        _lib.set_option("tight_binning", 1)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        dt_t = time.perf_counter() - t1
-        _lib.set_option("tight_binning", 0)
-        tight = {"ms_per_step": 1e3 * dt_t / args.steps, "value": args.steps / dt_t, "unit": "views/s",
-                 "note": "option tight_binning=1 (off in the headline run): tile lists without the instances that provably "
-                         "touch no pixel of their tile; image, radii, num_rendered and gradients bit-identical"}
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # ---- informative passes, all after and outside the timed region -------------------------------------------
+    compute_only = None
+    if exchanging:
+        # the same steps without the exchange: what the collectives add to a step that overlaps them
+        drain()
+        exchange_on[0] = False
+        for _ in range(3):
+            step()
+        dt_c, _ = timed(args.steps, with_drain=False)
+        exchange_on[0] = True
+        tc = torch.tensor([dt_c], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        compute_only = 1e3 * float(tc.item()) / args.steps
+    single = world == 1 and not exchanging
+    tight = None
+    if single and extras and not args.tight_binning:
+        _lib.set_option("tight_binning", 1)
+        for _ in range(3):
+            step()
+        dt_t, ms_t = timed(args.steps)
+        _lib.set_option("tight_binning", 0)
+        vpr.forward(cam_d, bg_d, deferred=False, keep_mask=cull_mask())   # leave reference-identical lists in the buffers
+        vpr.finish()
+        tight = {"ms_per_step": 1e3 * dt_t / args.steps, "median_ms_per_step": statistics.median(ms_t),
+                 "value": args.steps / dt_t, "unit": "views/s",
+                 "note": "option tight_binning=1 (off in the headline run): tile lists without the instances that provably "
+                         "touch no pixel of their tile; image, radii, num_rendered and gradients bit-identical"}
+    api_path = None
+    if single and extras and shell is None:
+        # The path the reference's callers take: diff_gaussian_rasterization.GaussianRasterizer (compiled torch
+        # extension _C, autograd, torch's allocator) instead of the persistent arenas of the C-ABI loop above.
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        settings = GaussianRasterizationSettings(
+            image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg_d,
+            scale_modifier=1.0, viewmatrix=cam_d.viewmatrix, projmatrix=cam_d.projmatrix, sh_degree=scene.sh_degree,
+            campos=cam_d.campos, prefiltered=False, debug=False)
+        rast = GaussianRasterizer(raster_settings=settings)
+        leaves = [t.detach().clone().requires_grad_(do_backward) for t in
+                  (scene_d.means3D, scene_d.shs, scene_d.opacities, scene_d.scales, scene_d.rotations)]
+        means2D = torch.zeros_like(leaves[0], requires_grad=do_backward)
+
+        def api_step():
+            img, _ = rast(means3D=leaves[0], means2D=means2D, shs=leaves[1], colors_precomp=None, opacities=leaves[2],
+                          scales=leaves[3], rotations=leaves[4], cov3D_precomp=None)
+            if do_backward:
+                for t in leaves + [means2D]:
+                    t.grad = None                # optimizer.zero_grad(set_to_none=True), as training loops do
+                img.backward(gpix)
+        for _ in range(5):
+            api_step()
+        dt_a, ms_a = timed(args.steps, fn=api_step, with_drain=False)
+        api_path = {"ms_per_step": 1e3 * dt_a / args.steps, "median_ms_per_step": statistics.median(ms_a),
+                    "vs_c_abi": (dt_a / args.steps) / (dt / args.steps),
+                    "note": "GaussianRasterizer(...)(...) + image.backward(dL) through the compiled extension "
+                            "diff_gaussian_rasterization._C (autograd, outputs and scratch from torch's caching allocator)"}
+        del leaves, means2D, rast
+    ref_gpu = None
+    if single and extras and rank == 0 and shell is None and not args.no_cpu_baseline:
+        try:
+            ref_gpu = reference_on_this_gpu(scene_d, cam_d, bg_d, gpix, do_backward)
+        except Exception as ex:
+            ref_gpu = {"error": repr(ex)}
+    skew = None
+    if single and extras and args.config == "c3":
+        # a second seeded scene with heavy skew (clusters -> tile lists of 10^4..10^5 entries beside empty tiles,
+        # near-camera giants): the >8192 global-memory sort path and the blend makespan under imbalance
+        sk = scenes.make_skew_scene(P, cfg["seed"] + 77).to(dev)
+        vs = ViewParallelRasterizer(sk, dev)
+        img_s, radii_s = vs.forward(cam_d, bg_d)
+        g_s, _ = scenes.l1_target_grad(img_s.cpu(), 5)
+        g_s = g_s.to(dev)
+
+        def skew_step():
+            vs.forward(cam_d, bg_d)
+            vs.backward(g_s, 0)
+        for _ in range(5):
+            skew_step()
+        _lib.set_option("profile", 1)
+        _lib.stage_times()
+        dt_s, ms_s = timed(10, fn=skew_step, with_drain=False)
+        st_s = {k: v for k, v in _lib.stage_times().items() if v > 0}
+        _lib.set_option("profile", 0)
+        from frosting_amd.introspect import State
+        rng_s = State(P, cam.image_width, cam.image_height, vs.true_num_rendered, vs.geom.buf, vs.binning.buf, vs.img.buf).ranges
+        tl = (rng_s[:, 1] - rng_s[:, 0])
+        skew = {"ms_per_step": 1e3 * dt_s / 10, "median_ms_per_step": statistics.median(ms_s), "num_rendered": int(vs.true_num_rendered),
+                "visible": int((radii_s > 0).sum()), "tile_list_max": int(tl.max()), "tile_list_mean": float(tl.float().mean()),
+                "tiles_over_8192": int((tl > 8192).sum()), "empty_tiles": int((tl == 0).sum()), "stage_ms": st_s,
+                "note": "scenes.make_skew_scene: half the Gaussians in four tight clusters, 400 large near-camera Gaussians"}
+        del vs, sk
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -258,25 +433,33 @@ def main():
         N = cam.image_width * cam.image_height
         T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
         from frosting_amd.introspect import State      # report-only: per-tile list statistics
-        if not args.tight_binning and tight is not None:
-            vpr.forward(cam_d, bg_d, deferred=False)   # the extra pass left tight lists in the buffers
         rng = State(P, cam.image_width, cam.image_height, R, vpr.geom.buf, vpr.binning.buf, vpr.img.buf).ranges
         tile_len = (rng[:, 1] - rng[:, 0]).float()
         B = stage_bytes(P, V, R, N, T)
-        total_bytes = 312 * P + 614 * V + 160 * R + 40 * N + 8 * T
+        if do_backward:
+            total_bytes = 312 * P + 614 * V + 160 * R + 40 * N + 8 * T
+        else:
+            total_bytes = 28 * P + 311 * V + 84 * R + 20 * N + 8 * T
+        what = {"c2": "forward only", "c4": "mesh occlusion raster + cull + forward + backward"}.get(args.config, "forward+backward")
         out = {
-            "metric": "train views/sec (fwd+bwd raster)", "value": views_per_s, "unit": "views/s",
+            "metric": "train views/sec (fwd+bwd raster)" if do_backward else "views/sec (forward raster)",
+            "value": views_per_s, "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "median_ms_per_step": statistics.median(per_step_ms),
+            "median_note": "median over the timed steps of the GPU time between step boundaries (one event per step on the "
+                           "launch stream, rank 0); value and ms_per_step are wall clock over all steps, max over ranks",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, "
-                                   f"forward+backward, 1 view per GPU per step", "P": P, "visible": V,
+                                   f"{what}, 1 view per GPU per step", "P": P, "visible": V,
                        "num_rendered": R, "instances_per_visible": R / max(V, 1), "tiles": T,
                        "tile_list_mean": float(tile_len.mean()), "tile_list_max": int(tile_len.max()),
-                       "parallelism": f"view-parallel x{world}",
+                       "parallelism": f"view-parallel x{world}", "ranks": world, "backend": (args.backend if dist else "none"),
                        "exchange": ("none" if not exchanging else
-                                    ("all-reduce of 59 floats/Gaussian" if args.exchange == "allreduce" else
-                                     "factored: all-reduce of 11 floats/Gaussian + all-gather of dRGB (3 floats), "
+                                    ("all 59 floats/Gaussian summed" if args.exchange == "allreduce" else
+                                     "factored: 11 floats/Gaussian summed + all-gather of dRGB (3 floats), "
                                      "summed SH gradient rebuilt per rank") +
+                                    (", RCCL all-reduce" if args.reduce == "allreduce" else
+                                     ", direct: all-to-all of 1/N shards + local sum + all-gather") +
                                     (", synchronous" if args.sync_exchange else
                                      ", overlapped with the next step's render (2 gradient buffers)")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
@@ -288,6 +471,12 @@ def main():
                        "achieved_GBps_per_gpu": total_bytes / (dt / args.steps) / 1e9,
                        "frac_of_8TBps": total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        if shell is not None:
+            out["config"]["mesh_triangles"] = int(shell.faces.shape[0])
+        if compute_only is not None:
+            out["exchange_timing"] = {"ms_per_step_without_exchange": compute_only,
+                                      "exposed_ms_per_step": ms_per_step - compute_only,
+                                      "note": "the same steps with the collectives switched off, timed after the timed region"}
         if dom_ms and dom_ms > 0:
             dom = dom_stage
             ach = B[dom] / (dom_ms * 1e-3) / 1e9
@@ -299,9 +488,15 @@ def main():
             out["stage_ms_note"] = "all stages, 5 extra steps after the timed region"
         if tight:
             out["tight_binning"] = tight
-        if not args.no_cpu_baseline and world == 1:
+        if api_path:
+            out["api_path"] = api_path
+        if ref_gpu:
+            out["reference_on_mi355x"] = ref_gpu
+        if skew:
+            out["skew_scene"] = skew
+        if not args.no_cpu_baseline and world == 1 and shell is None:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.config, P)
+                out["cpu_baseline"] = cpu_baseline(args.config, P, do_backward)
             except Exception as ex:  # the baseline is informative; never lose the GPU number over it
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))

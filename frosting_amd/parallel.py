@@ -67,7 +67,13 @@ class GradientExchange:
         independent of the collective's reduction order for the SH part."""
 
     def __init__(self, shapes: dict, device, process_group=None, average: bool = False,
-                 factor_sh: bool = False, sh_reducer=None):
+                 factor_sh: bool = False, sh_reducer=None, reduce: str = "allreduce"):
+        """reduce: how the summed part travels.  "allreduce": one collective, the backend picks the
+        algorithm (RCCL: rings / trees over xGMI).  "direct": reduce-scatter written as ONE all-to-all of
+        1/N shards -- every GPU sends shard j straight to GPU j over its own xGMI link, all seven links of
+        the fully connected node busy at once -- a local sum of the N received shards, then an all-gather of
+        the reduced shards (a ring is bound by one link, ~153 GB/s; the direct form by
+        seven)."""
         self.shapes = {k: tuple(shapes[k]) for k in PARAM_ORDER if k in shapes}
         self.device = torch.device(device)
         self.group = process_group
@@ -76,6 +82,10 @@ class GradientExchange:
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         self.views = {k: self.flat[o:o + n].view(self.shapes[k]) for k, (o, n) in self.layout.items()}
         self.factor_sh = bool(factor_sh) and "shs" in self.shapes
+        if reduce not in ("allreduce", "direct"):
+            raise ValueError("reduce must be 'allreduce' or 'direct'")
+        self.reduce = reduce
+        self._direct = None          # (send view, recv buffer, shard length) of the direct plan, sized at first start()
         self._works = []
         if self.factor_sh:
             # "shs" is last in PARAM_ORDER: the dense prefix is everything before it
@@ -124,10 +134,45 @@ class GradientExchange:
             if self.gathered is None or self.gathered.shape[0] != world:
                 self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
             self._works.append(dist.all_gather_into_tensor(self.gathered.view(-1), self.own, group=self.group, async_op=True))
-            self._works.append(dist.all_reduce(self.dense, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            summed = self.dense
         else:
-            self._works.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            summed = self.flat
+        if self.reduce == "direct":
+            self._start_direct(summed)
+        else:
+            self._works.append(dist.all_reduce(summed, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return self._works
+
+    def _start_direct(self, summed):
+        """Phase 1 of the direct plan: all-to-all of the N shards (the tail shard is zero-padded in a staging
+        copy only when the length does not divide).  Phase 2 (local sum + all-gather) runs in wait()."""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        n = summed.numel()
+        shard = (n + world - 1) // world
+        if self._direct is None or self._direct[2] != shard or self._direct[1].shape[0] != world:
+            send = summed if shard * world == n else torch.zeros(shard * world, dtype=torch.float32, device=self.device)
+            recv = torch.empty((world, shard), dtype=torch.float32, device=self.device)
+            mine = torch.empty(shard, dtype=torch.float32, device=self.device)
+            self._direct = (send, recv, shard, mine)
+        send, recv, shard, mine = self._direct
+        if send is not summed:
+            send[:n].copy_(summed)
+        self._direct_target = summed
+        self._works.append(dist.all_to_all_single(recv.view(-1), send, group=self.group, async_op=True))
+
+    def _finish_direct(self):
+        import torch.distributed as dist
+        send, recv, shard, mine = self._direct
+        summed = self._direct_target
+        n = summed.numel()
+        torch.sum(recv, dim=0, out=mine)          # fixed order over source ranks: identical on every rank after the gather
+        world = recv.shape[0]
+        if shard * world == n:
+            dist.all_gather_into_tensor(summed, mine, group=self.group)
+        else:
+            dist.all_gather_into_tensor(send, mine, group=self.group)
+            summed.copy_(send[:n])
 
     def wait(self):
         """Make the current stream (CPU backends: the caller) wait for the pending collectives;
@@ -142,6 +187,8 @@ class GradientExchange:
         for w in self._works:
             w.wait()
         self._works = []
+        if self.reduce == "direct":
+            self._finish_direct()
         if self.factor_sh:
             if self.means3D is None:
                 raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
@@ -166,6 +213,8 @@ class GradientExchange:
         for w in self._works:
             w.wait()
         self._works = []
+        if self.reduce == "direct":
+            self._finish_direct()
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.flat.device)
         self._side.wait_stream(torch.cuda.current_stream(self.flat.device))
@@ -210,7 +259,7 @@ class ViewParallelRasterizer:
     in place into the flat exchange buffer (no copies, no zero-fill)."""
 
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
-                 deferred_counters: bool = False, capacity_slack: float = 1.25):
+                 deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce"):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
@@ -225,7 +274,8 @@ class ViewParallelRasterizer:
         shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
         # two gradient buffers: the exchange of step k may still be in flight on the
         # collective stream while step k+1 renders and writes the other buffer
-        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average, factor_sh=factor_sh) for _ in range(2)]
+        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average, factor_sh=factor_sh, reduce=reduce)
+                          for _ in range(2)]
         for ex in self.exchanges:
             if ex.factor_sh:
                 ex.set_sh_context(scene.means3D, scene.sh_degree)
@@ -239,9 +289,10 @@ class ViewParallelRasterizer:
         self.num_rendered = 0
         self._view = None
 
-    def forward(self, cam, bg, deferred=None):
+    def forward(self, cam, bg, deferred=None, keep_mask=None):
         """Render one view.  With deferred counters the returned image is valid only if the
-        following finish() returns True."""
+        following finish() returns True.  keep_mask (bool / uint8 [P], optional): Frosting's occlusion
+        culling as a skip flag (frg_forward_ex)."""
         L = _lib.lib()
         s = self.scene
         H, W = cam.image_height, cam.image_width
@@ -249,14 +300,27 @@ class ViewParallelRasterizer:
             self.out_color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         use_deferred = (self.deferred_counters if deferred is None else deferred) and self.capacity > 0
-        fn = L.frg_forward_deferred if use_deferred else L.frg_forward
-        rc = fn(self.geom.cb, self.binning.cb, self.img.cb, None,
-                self.P, s.sh_degree, self.K, _p(bg), W, H,
-                _p(s.means3D), _p(s.shs), None, _p(s.opacities),
-                _p(s.scales), 1.0, _p(s.rotations), None,
-                _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
-                float(cam.tanfovx), float(cam.tanfovy), 0,
-                _p(self.out_color), _p(self.radii), self.capacity if use_deferred else 0, stream)
+        if keep_mask is not None:
+            v = lambda t: None if t is None else t.data_ptr()
+            a = _lib.ForwardArgs(
+                struct_size=C.sizeof(_lib.ForwardArgs), geometry_alloc=self.geom.cb, binning_alloc=self.binning.cb,
+                image_alloc=self.img.cb, user=None, P=self.P, D=s.sh_degree, M=self.K, background=v(bg), width=W, height=H,
+                means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, opacities=v(s.opacities), scales=v(s.scales),
+                scale_modifier=1.0, rotations=v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix),
+                projmatrix=v(cam.projmatrix), cam_pos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy),
+                prefiltered=0, out_color=v(self.out_color), radii=v(self.radii), debug=0, hip_stream=stream.value,
+                instance_capacity=self.capacity if use_deferred else 0, keep_mask=v(keep_mask))
+            self._keep_alive = keep_mask
+            rc = L.frg_forward_ex(C.byref(a))
+        else:
+            fn = L.frg_forward_deferred if use_deferred else L.frg_forward
+            rc = fn(self.geom.cb, self.binning.cb, self.img.cb, None,
+                    self.P, s.sh_degree, self.K, _p(bg), W, H,
+                    _p(s.means3D), _p(s.shs), None, _p(s.opacities),
+                    _p(s.scales), 1.0, _p(s.rotations), None,
+                    _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
+                    float(cam.tanfovx), float(cam.tanfovy), 0,
+                    _p(self.out_color), _p(self.radii), self.capacity if use_deferred else 0, stream)
         if rc < 0:
             raise RuntimeError(f"{'frg_forward_deferred' if use_deferred else 'frg_forward'} failed ({rc}): {_lib.last_error()}")
         # deferred: rc is the capacity, which is what the backward carves its buffers with

@@ -222,3 +222,27 @@ def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
         else:
             torch.testing.assert_close(got, want, rtol=0, atol=0)
     assert (res[0] == res[1]).all()
+
+
+@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
+    """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under
+    torch.distributed.run, both ranks share GPU 0 (FRG_BENCH_ONE_GPU) and exchange over gloo; rank 0 prints
+    ONE JSON line that says two ranks ran and what they exchanged."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FRG_BENCH_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--exchange", exchange,
+                        "--points", "30000", "--steps", "3", "--warmup", "2", "--spinup-steps", "2", "--no-cpu-baseline",
+                        "--no-extras"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["exchange_bytes_per_rank"] > 0 and "exchange_timing" in out
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]

@@ -139,3 +139,27 @@ def test_adam_entry_point_validates_arguments_without_a_gpu():
     assert L.frg_adam_step(8, None, None, None, None, ends, lrs, None, None, None, 2, 0.9, 0.999, 1e-15, 0, 1.0, None) == -1   # step is 1-based
     ends0 = (C.c_longlong * 1)(0)
     assert L.frg_adam_step(0, None, None, None, None, ends0, lrs, None, None, None, 1, 0.9, 0.999, 1e-15, 1, 1.0, None) == 0    # nothing to do
+
+
+def test_bench_self_launches_n_ranks_from_a_bare_shell(monkeypatch):
+    """`python bench.py --gpus 8` without torch.distributed.run around it must become 8 ranks
+    (the driver's N=1 form, applied to N>1, used to run ONE rank)."""
+    import sys
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.os, "execv", lambda exe, argv: seen.update(exe=exe, argv=argv))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7"])
+    args = bench.parse_args()
+    bench.self_launch_if_needed(args)
+    a = seen["argv"]
+    assert a[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-4:] == ["--gpus", "8", "--steps", "7"]
+    # already under a launcher (WORLD_SIZE set), or N == 1: no re-exec
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    bench.self_launch_if_needed(args)
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench.self_launch_if_needed(bench.parse_args())
+    assert not seen

@@ -17,13 +17,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, P, K, q):
+def _worker(rank, world, port, P, K, q, reduce="allreduce"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
-    ex = GradientExchange(shapes, "cpu", dist.group.WORLD)
+    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, reduce=reduce)
     g = torch.Generator().manual_seed(100 + rank)
     for k in PARAM_ORDER:  # a rank-specific "per-view gradient"
         ex.views[k].copy_(torch.randn(shapes[k], generator=g))
@@ -51,12 +51,15 @@ def test_flat_buffer_layout():
 
 
 @pytest.mark.timeout(120)
-def test_allreduce_sums_per_view_gradients_gloo():
-    world, P, K = 2, 257, 16
+@pytest.mark.parametrize("reduce,P", [("allreduce", 257), ("direct", 257), ("direct", 64)])
+def test_allreduce_sums_per_view_gradients_gloo(reduce, P):
+    """Both reduction plans: the backend's all-reduce, and the direct form (all-to-all of shards + local sum +
+    all-gather), with a length that does and does not divide by the world size."""
+    world, K = 2, 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, P, K, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, K, q, reduce)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=100) for _ in range(world))
@@ -72,6 +75,8 @@ def test_allreduce_sums_per_view_gradients_gloo():
     for r in range(world):
         for k in PARAM_ORDER:
             torch.testing.assert_close(torch.from_numpy(res[r][k]), expect[k], rtol=1e-6, atol=1e-6)
+    for k in PARAM_ORDER:
+        assert (res[0][k] == res[1][k]).all()          # every rank ends with the same bits
 
 
 # ---- factored SH exchange: all-gather of dRGB + all-reduce of the 11 dense floats ----------------
@@ -108,13 +113,13 @@ def _view_inputs(rank, P, K, deg):
     return means, campos, drgb, dense, shs
 
 
-def _factored_worker(rank, world, port, P, K, deg, q):
+def _factored_worker(rank, world, port, P, K, deg, q, reduce="allreduce"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
-    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=True, sh_reducer=torch_sh_reducer)
+    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=True, sh_reducer=torch_sh_reducer, reduce=reduce)
     means, campos, drgb, dense, shs = _view_inputs(rank, P, K, deg)
     ex.set_sh_context(means, deg)
     for k, v in dense.items():
@@ -132,13 +137,13 @@ def _factored_worker(rank, world, port, P, K, deg, q):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("deg,K", [(3, 16), (1, 16)])
-def test_factored_sh_exchange_equals_sum_of_view_gradients_gloo(deg, K):
+@pytest.mark.parametrize("deg,K,reduce", [(3, 16, "allreduce"), (1, 16, "allreduce"), (3, 16, "direct")])
+def test_factored_sh_exchange_equals_sum_of_view_gradients_gloo(deg, K, reduce):
     world, P = 2, 193
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, P, K, deg, q)) for r in range(world)]
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, P, K, deg, q, reduce)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=100) for _ in range(world))
