@@ -48,9 +48,10 @@ def native_ops(binding: str):
 # Ours is bit-reproducible; the reference sums 9 float atomics per (pixel, Gaussian) pair in scheduling
 # order, so it differs from ITSELF run to run by 5e-8 (colour) .. 6e-5 (quaternion) at the C2/C3 sizes
 # (profiles/r01_gpu_check_c3.log).  A comparison passes within max(5 x that measured spread, floor);
-# the floors sit 2-5x above the differences measured there (2e-7 .. 4e-5), two orders below the old 3e-4.
-GRAD_FLOOR = {"dL_dmeans2D": 5e-6, "dL_dcolors": 3e-6, "dL_dopacity": 3e-6, "dL_dmeans3D": 1e-5, "dL_dcov3D": 5e-5,
-              "dL_dsh": 3e-6, "dL_dscales": 8e-5, "dL_drotations": 3e-4}
+# the floors sit ~2x above the largest differences measured at C2 / C3 / C4 full size (profiles/r02_pytest_gpu.log:
+# 4e-6 means2D .. 7e-5 quaternion at 3 M Gaussians), 3 .. 60x below the old blanket 3e-4.
+GRAD_FLOOR = {"dL_dmeans2D": 1e-5, "dL_dcolors": 5e-6, "dL_dopacity": 5e-6, "dL_dmeans3D": 1.5e-5, "dL_dcov3D": 8e-5,
+              "dL_dsh": 5e-6, "dL_dscales": 1e-4, "dL_drotations": 3e-4}
 
 
 def grad_bar(name, noise=0.0):

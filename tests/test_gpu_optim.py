@@ -78,7 +78,11 @@ def test_flat_adam_dc_and_rest_groups_on_one_sh_tensor(gpu_device):
                             {"params": [rest], "lr": 2.5e-3 / 20.0}], lr=0.0, eps=1e-15)
     for _ in range(6):
         gs, gm = torch.randn(P, K, 3, generator=g) * 1e-2, torch.randn(P, 3, generator=g) * 1e-2
-        ours.step(torch.cat([gm.reshape(-1), gs.reshape(-1)]).to(dev))
+        flat = torch.zeros(ours.numel, device=dev)
+        for k, t in (("means3D", gm), ("shs", gs)):
+            o, n = ours.layout[k]
+            flat[o:o + n] = t.reshape(-1).to(dev)
+        ours.step(flat)
         xyz.grad, dc.grad, rest.grad = gm.to(dev), gs[:, :1].contiguous().to(dev), gs[:, 1:].contiguous().to(dev)
         ref.step()
     want = torch.cat([dc.detach(), rest.detach()], dim=1)
