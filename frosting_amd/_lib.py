@@ -150,13 +150,13 @@ def get_option(name: str) -> int:
     return lib().frg_get_option(name.encode())
 
 
-STAGE_NAMES = ["preprocess", "scan", "scatter", "sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+STAGE_NAMES = ["preprocess", "scan", "scatter", "sort", "blend_fwd", "blend_bwd", "preprocess_bwd", "sh_color"]
 
 
 def stage_times() -> dict:
     """Milliseconds per stage of the last forward/backward (needs set_option('profile', 1))."""
-    buf = (C.c_float * 8)()
-    n = lib().frg_stage_times(buf, 8)
+    buf = (C.c_float * 16)()
+    n = lib().frg_stage_times(buf, 16)
     return {STAGE_NAMES[k]: float(buf[k]) for k in range(min(n, len(STAGE_NAMES)))}
 
 

@@ -34,12 +34,14 @@ std::atomic<int> g_profile_stage{-1};  // -1: every stage; k: only stage k gets 
 // buffers travels with those buffers: the carve of every field the backward reads depends on (P, W, H, R)
 // alone, and the binning mode is stamped into the image chunk's counters (Counters::tight_binning).
 std::atomic<int> g_global_bins{0};    // test hook: force the large-image (global-atomic) binning path
+std::atomic<int> g_async_sh{0};       // SH colours on a side stream beside the binning stages (0: inside preprocess)
+std::atomic<int> g_bwd_batch{2};      // tuning: instances per reduction step of the backward blend (2 | 3)
 std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
 // recorded on the caller's stream between the kernels of one forward / backward;
 // frg_stage_times() synchronises and returns the elapsed milliseconds.
-enum { ST_PREPROCESS = 0, ST_SCAN, ST_SCATTER, ST_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+enum { ST_PREPROCESS = 0, ST_SCAN, ST_SCATTER, ST_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_SH_COLOR, ST_COUNT };
 // Event pairs are kept for the last ST_SLOTS launches of every stage and only read (and
 // synchronised on) by frg_stage_times(), so timing a run of steps does not serialise them.
 constexpr int ST_SLOTS = 64;
@@ -157,6 +159,33 @@ struct PendingRing {
 };
 thread_local PendingRing g_pending;
 
+// Side stream of the deferred SH colour kernel (one per host thread and device, like the sort's).
+struct ShSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t geo_done = nullptr, sh_done = nullptr;
+    int device = -1;
+    bool ensure()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev == device) return true;
+        if (stream) (void)hipStreamDestroy(stream);
+        if (geo_done) (void)hipEventDestroy(geo_done);
+        if (sh_done) (void)hipEventDestroy(sh_done);
+        stream = nullptr; geo_done = nullptr; sh_done = nullptr; device = -1;
+        // lowest priority: the colour kernel floods every CU with streaming waves; the small latency-bound kernels
+        // of the binning stages on the caller's stream must win the arbitration
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&geo_done, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&sh_done, hipEventDisableTiming) != hipSuccess) return false;
+        device = dev;
+        return true;
+    }
+};
+thread_local ShSide g_sh_side;
+
 #define FRG_HIP(call)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
@@ -205,6 +234,8 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.exchange(value < 0 || value >= ST_COUNT ? -1 : value);
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value);
+    if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -239,6 +270,8 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.load();
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.load();
+    if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
+    if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
@@ -333,8 +366,35 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
     in.keep_mask = keep_mask;
-    { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, stream), "preprocess"); }
+    // SH colours: nothing before the blend needs them, and the stages in between (scan, scatter, sort) leave the
+    // HBM nearly idle -- the colour kernel (the largest single stream of the forward, 192 B per visible Gaussian)
+    // runs beside them on a side stream; the blend joins it.
+    const int sh_mode = shs != nullptr ? g_async_sh.load() : 0;   // 0 inside preprocess | side stream forked after: 1 preprocess, 2 scan, 3 scatter
+    const bool defer_sh = sh_mode != 0 && g_sh_side.ensure();
+    bool sh_forked = false;
+    // an error return between the fork and the join must not leave the side kernel running on the caller's inputs
+    struct ShJoin {
+        bool armed; hipStream_t side;
+        ~ShJoin() { if (armed) (void)hipStreamSynchronize(side); }
+    } sh_join{false, g_sh_side.stream};
+    auto fork_sh = [&](int at) -> int {
+        if (!defer_sh || sh_forked || (at < sh_mode && at < 3)) return FRG_OK;
+        sh_forked = true;
+        sh_join.armed = true;
+        FRG_HIP(hipEventRecord(g_sh_side.geo_done, stream));
+        FRG_HIP(hipStreamWaitEvent(g_sh_side.stream, g_sh_side.geo_done, 0));
+        {
+            StageScope sc_(ST_SH_COLOR, g_sh_side.stream);
+            FRG_HIP(frg::launch_sh_color(P, vp, in, radii, g, g_sh_side.stream));
+        }
+        FRG_HIP(hipEventRecord(g_sh_side.sh_done, g_sh_side.stream));
+        if (debug) FRG_HIP(hipStreamSynchronize(g_sh_side.stream));
+        return FRG_OK;
+    };
+    { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, defer_sh, stream), "preprocess"); }
+    { const int rc_ = fork_sh(1); if (rc_ < 0) return rc_; }
     { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, (uint32_t)capacity, stream), "scan"); }
+    { const int rc_ = fork_sh(2); if (rc_ < 0) return rc_; }
 
     int R = capacity;
     if (capacity > 0) {
@@ -348,7 +408,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
         const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1);
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
+        { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
         { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
+        if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
         StageScope sc_(ST_BLEND_FWD, stream);
         if (exact_blend())
             FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
@@ -375,11 +437,14 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
 
     if (R > 0) {
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
+        { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
         { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
     } else {
         // point_offsets must still be defined for backward
         FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
+        { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
     }
+    if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
     {
         StageScope sc_(ST_BLEND_FWD, stream);
         if (exact_blend())
@@ -488,9 +553,9 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact_blend())
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
     }
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};

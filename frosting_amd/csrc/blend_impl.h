@@ -45,18 +45,24 @@ struct BlendMath<true> {
     static __device__ __forceinline__ float expo(float p) { return expf(p); }
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
     static __device__ __forceinline__ float recip(float x) { return 1.0f / x; }
+    static __device__ __forceinline__ float mad(float a, float b, float c) { return a * b + c; }   // two roundings (this TU: contraction off)
 };
 
 template <>
 struct BlendMath<false> {
+    // Every fused multiply-add of the fast path is written out (the TU is compiled with contraction off): what
+    // gets fused must not depend on where the compiler unrolled or inlined a copy of the code, or the same
+    // (pixel, Gaussian) pair would round differently at different positions of a tile list.
     static __device__ __forceinline__ float power(float x, float y, float4 co, float px, float py, float& dx, float& dy)
     {
         dx = x - px; dy = y - py;
-        return -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        const float q = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);
+        return __builtin_fmaf(-0.5f, q, -(co.y * dx * dy));
     }
     static __device__ __forceinline__ float expo(float p) { return __expf(p); }
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
+    static __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 };
 
 #define BLEND_THREADS 256   // 4 waves = the 4 quadrants of one tile
@@ -141,9 +147,9 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             done |= stop;
             if (!skip & !stop) {
                 const float4 gc = s_rgb[j];
-                C0 += M::mul3(gc.x, alpha, Tr);
-                C1 += M::mul3(gc.y, alpha, Tr);
-                C2 += M::mul3(gc.z, alpha, Tr);
+                C0 = M::mad(gc.x * alpha, Tr, C0);
+                C1 = M::mad(gc.y * alpha, Tr, C1);
+                C2 = M::mad(gc.z * alpha, Tr, C2);
                 Tr = test_T;
                 last = __float_as_uint(ga.w);
             }
@@ -155,9 +161,9 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         const size_t pid = (size_t)py * W + px;
         final_T[pid] = Tr;
         n_contrib[pid] = last;
-        out_color[pid] = C0 + Tr * bg[0];
-        out_color[plane + pid] = C1 + Tr * bg[1];
-        out_color[2 * plane + pid] = C2 + Tr * bg[2];
+        out_color[pid] = M::mad(Tr, bg[0], C0);
+        out_color[plane + pid] = M::mad(Tr, bg[1], C1);
+        out_color[2 * plane + pid] = M::mad(Tr, bg[2], C2);
     }
     // how deep this tile's list was walked: the backward blend's work per tile, used to
     // dispatch its long tiles first (bwd_order_kernel)
@@ -234,14 +240,15 @@ __device__ __forceinline__ float fold_two(float a, float b)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool EXACT>
+// BWD_BATCH: instances whose partial sums are reduced together (2 or 3: 18 / 27 matrix rows, two lanes per row)
+template <bool EXACT, int BWD_BATCH>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order)
+                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order, int ablate)
 {
     using M = BlendMath<EXACT>;
     const int tile = order ? (int)order[blockIdx.x] : xcd_tile_of_block(blockIdx.x, T);
@@ -254,6 +261,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     __shared__ float4 s_co[64];
     __shared__ float4 s_rgb[64];   // r, g, b, Gaussian-major slot index
     __shared__ float s_part[64 * FRG_SLOT_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_red[BWD_BATCH * FRG_SLOT_FLOATS * 64];   // reduction matrix, one column per lane
 
     // Per-pixel state of the back-to-front walk.  The reference carries the colour
     // composited behind the current Gaussian (accum_rec, last_color, last_alpha:
@@ -278,7 +286,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         maxc = max(maxc, lastcon[q]);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) dLp[q][ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
-        S[q] = Tr[q] * (bg0 * dLp[q][0] + bg1 * dLp[q][1] + bg2 * dLp[q][2]);
+        S[q] = Tr[q] * M::mad(bg2, dLp[q][2], M::mad(bg1, dLp[q][1], bg0 * dLp[q][0]));
     }
     // per-quadrant and tile-wide number of list entries that can still receive gradient
     uint32_t qmax[4];
@@ -337,19 +345,25 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 #pragma unroll
         for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[lane * FRG_SLOT_FLOATS + c] = 0.0f;
         __syncthreads();
-        // Two surviving instances per iteration: their 2 x 9 partial sums are reduced together
-        // (v_permlane32_swap folds the two 64-lane vectors into one register, then one DPP tree
-        // finishes both halves), 40 instead of 92 VALU instructions per Gaussian.
-        for (int k = 0; k < nkeep; k += 2) {
-            float pa[FRG_SLOT_FLOATS], pb[FRG_SLOT_FLOATS];
+        // BWD_BATCH surviving instances per iteration; their BWD_BATCH x 9 per-lane partial sums are
+        // reduced across the wave THROUGH LDS: every lane stores its 27 partials as one column of a
+        // [27][64] matrix (conflict-free ds_write), then two lanes per row add up 32 entries each
+        // (8 ds_read_b128, chunk order skewed by the row so that the rows spread over the banks) and one
+        // DPP add joins the halves.  Measured on gfx950 (tools/micro/pk_rate.hip): v_add_f32 2.8 cycles per
+        // wave-instruction, v_add_f32_dpp 7, v_permlane32_swap 12.6 -- the former swap + DPP tree cost
+        // ~240 cycles per instance, almost as much as the per-pixel mathematics; this form ~75.
+        for (int k = 0; k < nkeep; k += BWD_BATCH) {
+            float acc[BWD_BATCH][FRG_SLOT_FLOATS];
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) { pa[c] = 0.0f; pb[c] = 0.0f; }
-            bool any_a = false, any_b = false;
+            for (int h = 0; h < BWD_BATCH; h++)
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int kk = k + half;
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[h][c] = 0.0f;
+            bool any = false;
+#pragma unroll
+            for (int h = 0; h < BWD_BATCH; h++) {
+                const int kk = k + h;
                 if (kk >= nkeep) break;
-                float* part = half ? pb : pa;
+                float* part = acc[h];
                 const float4 ca = s_a[kk], cco = s_co[kk];
                 const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(ca.z));
                 const uint32_t pos = __float_as_uint(ca.w);  // 0-based position in the tile list
@@ -364,8 +378,9 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                     alpha[q] = fminf(0.99f, cco.w * G[q]);
                     if (pos < lastcon[q] && !(power > 0.0f) && !(alpha[q] < 1.0f / 255.0f)) ok |= 1u << q;
                 }
-                if (__ballot(ok != 0) == 0ull) continue;  // row kk of s_part stays zero
-                if (half) any_b = true; else any_a = true;
+                if (__ballot(ok != 0) == 0ull) continue;  // this instance's partials stay zero
+                any = true;
+                if (ablate == 2) continue;   // TIMING EXPERIMENT ONLY
                 // phase 2: gradient contributions of the pixels that blended this Gaussian
                 // (part[3..7] are accumulated without their constant factors; see the write-out)
                 const float4 gc = s_rgb[kk];
@@ -376,47 +391,50 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                     const float rinv = M::recip(1.f - alpha[q]);  // 1 - alpha >= 0.01
                     Tr[q] = Tr[q] * rinv;                        // transmittance in front of this Gaussian
                     const float w = alpha[q] * Tr[q];            // dC/dcolour
-                    const float cdot = gc.x * dLp[q][0] + gc.y * dLp[q][1] + gc.z * dLp[q][2];
-                    part[0] += w * dLp[q][0];
-                    part[1] += w * dLp[q][1];
-                    part[2] += w * dLp[q][2];
-                    const float dL_dalpha = Tr[q] * cdot - S[q] * rinv;
-                    S[q] += w * cdot;
+                    const float cdot = M::mad(gc.z, dLp[q][2], M::mad(gc.y, dLp[q][1], gc.x * dLp[q][0]));
+                    part[0] = M::mad(w, dLp[q][0], part[0]);
+                    part[1] = M::mad(w, dLp[q][1], part[1]);
+                    part[2] = M::mad(w, dLp[q][2], part[2]);
+                    const float dL_dalpha = M::mad(Tr[q], cdot, -(S[q] * rinv));
+                    S[q] = M::mad(w, cdot, S[q]);
                     // moments of v = G dL/dalpha over the pixels; opacity, conic and the NDC factors
                     // are applied once per (tile, Gaussian) at the write-out below
                     const float v = G[q] * dL_dalpha;
                     const float vx = v * dxs[q], vy = v * dys[q];
                     part[3] += vx;
                     part[4] += vy;
-                    part[5] += vx * dxs[q];
-                    part[6] += vx * dys[q];
-                    part[7] += vy * dys[q];
+                    part[5] = M::mad(vx, dxs[q], part[5]);
+                    part[6] = M::mad(vx, dys[q], part[6]);
+                    part[7] = M::mad(vy, dys[q], part[7]);
                     part[8] += v;
                 }
             }
-            if (!(any_a || any_b)) continue;
-            // step-major order: the nine chains advance together, so every DPP add has eight
-            // independent instructions between it and its consumer (no s_nop padding)
+            if (!any) continue;      // s_part rows of this batch stay zero
+            if (ablate == 1) { if (acc[0][0] == 12345.f) s_part[0] = 1.f; continue; }   // TIMING EXPERIMENT ONLY
+            wave_lds_sync();         // the previous batch's readers are done with s_red
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = fold_two(pa[c], pb[c]);  // lanes 0-31: a[l]+a[l+32], 32-63: b
+            for (int h = 0; h < BWD_BATCH; h++)
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0xB1, 0xf>(pa[c]);   // quad_perm [1,0,3,2]
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_red[(h * FRG_SLOT_FLOATS + c) * 64 + lane] = acc[h][c];
+            wave_lds_sync();
+            const int row = lane >> 1, half = lane & 1;
+            const int inst = row / FRG_SLOT_FLOATS;              // which instance of the batch
+            const int comp = row - inst * FRG_SLOT_FLOATS;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (row < BWD_BATCH * FRG_SLOT_FLOATS) {
+                const float4* src = reinterpret_cast<const float4*>(s_red + row * 64 + half * 32);
+                // chunk order skewed by the COMPONENT, not by the row: the order in which an instance's partials
+                // are added must not depend on its place in the batch (hence in the tile list)
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x4E, 0xf>(pa[c]);   // quad_perm [2,3,0,1]
-#pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x141, 0xf>(pa[c]);  // row_half_mirror
-#pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x140, 0xf>(pa[c]);  // row_mirror
-#pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) pa[c] = dpp_step<0x142, 0xa>(pa[c]);  // row_bcast:15 -> lane 31: sum(a), lane 63: sum(b)
-            if (lane == 31 && any_a) {
-#pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[k * FRG_SLOT_FLOATS + c] = pa[c];
+                for (int j = 0; j < 8; j++) {
+                    const float4 v = src[(j + comp) & 7];
+                    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+                }
             }
-            if (lane == 63 && any_b) {
-#pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[(k + 1) * FRG_SLOT_FLOATS + c] = pa[c];
-            }
+            float sum = (s0 + s1) + (s2 + s3);
+            sum = dpp_step<0xB1, 0xf>(sum);                      // quad_perm [1,0,3,2]: the row's other half
+            if (half == 0 && row < BWD_BATCH * FRG_SLOT_FLOATS && k + inst < nkeep)
+                s_part[(k + inst) * FRG_SLOT_FLOATS + comp] = sum;
         }
         __syncthreads();
         if (lane < nkeep) {
@@ -430,8 +448,8 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             const float4 kc = s_co[lane];
             const float o = kc.w;
             dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2];
-            dst[3] = -o * (kc.x * m[3] + kc.y * m[4]) * ddelx_dx;
-            dst[4] = -o * (kc.z * m[4] + kc.y * m[3]) * ddely_dy;
+            dst[3] = -o * M::mad(kc.y, m[4], kc.x * m[3]) * ddelx_dx;
+            dst[4] = -o * M::mad(kc.y, m[3], kc.z * m[4]) * ddely_dy;
             dst[5] = -0.5f * o * m[5];
             dst[6] = -0.5f * o * m[6];
             dst[7] = -0.5f * o * m[7];

@@ -11,8 +11,10 @@ struct FwdInputs {
     const unsigned char* keep_mask = nullptr;   // optional per-Gaussian skip flag (0 = not in this view)
 };
 
+// defer_sh: the SH colours are left to launch_sh_color (any stream ordered after this launch, before the blend)
 hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
-                                 const ImageState& img, int prefiltered, hipStream_t s);
+                                 const ImageState& img, int prefiltered, bool defer_sh, hipStream_t s);
+hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g, hipStream_t s);
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s);
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
                           const BinningState& b, hipStream_t s);
@@ -29,10 +31,11 @@ hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, cons
                                   const float* bg, float* out_color, hipStream_t s);
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                  const float* bg, float* out_color, hipStream_t s);
+// batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, const float* dL_dpix, float* slots, hipStream_t s);
+                                  const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, hipStream_t s);
+                                 const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;

@@ -184,7 +184,13 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool LDS_BINS, bool SH16, bool TIGHT>
+// SHMODE: how the SH colour of a visible Gaussian is produced.
+//   SH_INLINE  in this kernel, one strided read per coefficient (any layout)
+//   SH_STREAM  in this kernel, coefficients streamed as float4 and transposed through LDS (M == 16)
+//   SH_DEFER   not here: sh_color_kernel computes it on a side stream while the binning stages (scan, scatter,
+//              sort -- LDS / latency bound, HBM nearly idle) run on the caller's; the blend waits for both
+enum { SH_INLINE = 0, SH_STREAM = 1, SH_DEFER = 2 };
+template <bool LDS_BINS, int SHMODE, bool TIGHT>
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
 preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
@@ -197,6 +203,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered)
 {
+    constexpr bool SH16 = SHMODE == SH_STREAM;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
@@ -249,7 +256,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             if (touched)
                 rgb_clamped[idx] = make_float4(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2],
                                                __uint_as_float(0u));
-        } else {
+        } else if (SHMODE != SH_DEFER) {
             float w[16];
             const int ncoef = sh_weights(vp.D, dir.x, dir.y, dir.z, w);
             ShAccum sa;
@@ -330,6 +337,90 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
         for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) row[t] = lds_bins[t];
     }
+}
+
+// SH colour of the visible Gaussians as a kernel of its own (SH_DEFER): same arithmetic, same summation
+// order, same float4 stream through wave-private LDS as the in-kernel form -- the colours are bit-identical.
+// One wave = 64 consecutive Gaussians; nothing here depends on the binning, so the kernel runs on a side
+// stream beside scan / scatter / sort and only the blend joins it.
+#define SHC_THREADS 256
+template <bool SH16>
+__global__ void __launch_bounds__(SHC_THREADS)
+sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const float* __restrict__ means3D,
+                const int* __restrict__ radii, const float* __restrict__ shs, float4* __restrict__ rgb_clamped)
+{
+    __shared__ float4 sh_lds[SH16 ? (SHC_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx0 = blockIdx.x * SHC_THREADS + wave * 64;
+    const int idx = idx0 + lane;
+    const bool touched = idx < P && radii[idx] > 0;
+    if (__ballot(touched) == 0ull) return;                      // wave-uniform: nothing visible here
+    float3 dir = make_float3(0.f, 0.f, 1.f);
+    if (touched) {   // unit view direction (forward.cu:25-27), the expressions of preprocess_one
+        const float cx = cam_pos[0], cy = cam_pos[1], cz = cam_pos[2];
+        const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dir = make_float3(dx / len, dy / len, dz / len);
+    }
+    float w[16];
+    const int ncoef = sh_weights(D, dir.x, dir.y, dir.z, w);
+    ShAccum sa;
+    sa.acc[0] = sa.acc[1] = sa.acc[2] = 0.f;
+    if (SH16) {
+        float4* shbuf = sh_lds + wave * (PRE_SUB * PRE_ROW_F4);
+        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
+        const int nvalid = min(64, P - idx0);
+        const uint64_t vis = __ballot(touched);
+        uint32_t need = 0;
+#pragma unroll
+        for (int h = 0; h < 64 / PRE_SUB; h++)
+            if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
+        float4 pre[PRE_SUB * 12 / 64];
+        auto issue = [&](int h) {
+#pragma unroll
+            for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
+                const int f = k * 64 + lane, gl = f / 12;
+                pre[k] = (h * PRE_SUB + gl < nvalid) ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        int h = __builtin_ctz(need);
+        issue(h);
+#pragma unroll 1
+        while (h < 64 / PRE_SUB) {
+#pragma unroll
+            for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
+                const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
+                shbuf[gl * PRE_ROW_F4 + j] = pre[k];
+            }
+            const uint32_t rest = need >> (h + 1);
+            const int hn = rest ? h + 1 + __builtin_ctz(rest) : 64 / PRE_SUB;
+            if (hn < 64 / PRE_SUB) issue(hn);
+            wave_sync_lds();
+            if ((lane / PRE_SUB) == h && touched) {
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    const float4 v = shbuf[(lane % PRE_SUB) * PRE_ROW_F4 + j];
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int e = 4 * j + t, i = e / 3, ch = e % 3;
+                        if (i < ncoef) sa.add(i, ch, w[i], vv[t]);
+                    }
+                }
+            }
+            wave_sync_lds();
+            h = hn;
+        }
+    } else if (touched) {
+        const float* sh = shs + (size_t)idx * M * 3;
+#pragma unroll
+        for (int e = 0; e < 48; e++) {
+            const int i = e / 3, ch = e % 3;
+            if (i < ncoef) sa.add(i, ch, w[i], sh[e]);
+        }
+    }
+    if (touched) rgb_clamped[idx] = sa.finish();
 }
 
 // Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
@@ -551,32 +642,48 @@ static hipError_t allow_big_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS_BINS, bool SH16, bool TIGHT>
+template <bool LDS_BINS, int SHMODE, bool TIGHT>
 static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
                                      const ImageState& img, int prefiltered, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
     const size_t lds = LDS_BINS ? (size_t)T * 4 : 0;
-    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SH16, TIGHT>, lds);
+    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SH16, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
+    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
-                                 const ImageState& img, int prefiltered, hipStream_t s)
+// float4-streamed SH needs the reference's usual layout: 16 coefficients per channel, 16-byte aligned
+static bool sh_streamable(const FwdInputs& in, const ViewParams& vp)
 {
-    // float4-streamed SH needs the reference's usual layout: 16 coefficients per channel, 16-byte aligned
-    const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0);
+    return in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0);
+}
+
+hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
+                                 const ImageState& img, int prefiltered, bool defer_sh, hipStream_t s)
+{
+    const int mode = (defer_sh && in.shs) ? SH_DEFER : sh_streamable(in, vp) ? SH_STREAM : SH_INLINE;
 #define FRG_PRE(L, S) (vp.tight ? launch_pre_variant<L, S, true>(P, vp, in, radii, g, img, prefiltered, s) \
                                 : launch_pre_variant<L, S, false>(P, vp, in, radii, g, img, prefiltered, s))
-    if (img.lds_bins) return sh16 ? FRG_PRE(true, true) : FRG_PRE(true, false);
-    return sh16 ? FRG_PRE(false, true) : FRG_PRE(false, false);
+    if (img.lds_bins) return mode == SH_DEFER ? FRG_PRE(true, SH_DEFER) : mode == SH_STREAM ? FRG_PRE(true, SH_STREAM) : FRG_PRE(true, SH_INLINE);
+    return mode == SH_DEFER ? FRG_PRE(false, SH_DEFER) : mode == SH_STREAM ? FRG_PRE(false, SH_STREAM) : FRG_PRE(false, SH_INLINE);
 #undef FRG_PRE
+}
+
+hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g, hipStream_t s)
+{
+    if (!in.shs || P <= 0) return hipSuccess;
+    const dim3 grid((P + SHC_THREADS - 1) / SHC_THREADS), block(SHC_THREADS);
+    if (sh_streamable(in, vp))
+        hipLaunchKernelGGL((sh_color_kernel<true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped);
+    else
+        hipLaunchKernelGGL((sh_color_kernel<false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s)

@@ -1,0 +1,49 @@
+"""A/B timing of library options on the C3 step (one process, one scene build).
+usage: python tools/ab.py [--config c3] [--points N] [--steps 30] "bwd_batch=3" "bwd_batch=2" ...
+Each positional argument is a comma-separated list of option=value applied through frg_set_option; prints the
+per-stage hipEvent times, the wall ms per step and the rel. L2 difference of the gradient buffer to the first setting."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from frosting_amd import _lib, scenes
+from frosting_amd.parallel import ViewParallelRasterizer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c3")
+ap.add_argument("--points", type=int, default=0)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--view", type=int, default=0)
+ap.add_argument("settings", nargs="*", default=[""])
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cfg = scenes.CONFIGS[a.config]
+scene, cam, bg = scenes.config_scene(a.config, a.view, P=a.points or cfg["P"])
+vpr = ViewParallelRasterizer(scene.to(dev), dev)
+cam_d, bg_d = cam.to(dev), bg.to(dev)
+img, radii = vpr.forward(cam_d, bg_d)
+gpix, _ = scenes.l1_target_grad(img.cpu(), 1)
+gpix = gpix.to(dev)
+def step():
+    vpr.forward(cam_d, bg_d); vpr.backward(gpix, 0)
+for _ in range(100): step()
+base = None
+defaults = {}
+for setting in a.settings:
+    pairs = [kv.split("=") for kv in setting.split(",") if kv]
+    for k, v in pairs:
+        old = _lib.set_option(k, int(v)); defaults.setdefault(k, old)
+    for _ in range(10): step()
+    _lib.set_option("profile", 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps): step()
+    torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    _lib.set_option("profile", 1); _lib.stage_times()
+    for _ in range(10): step()
+    torch.cuda.synchronize()
+    st = _lib.stage_times(); _lib.set_option("profile", 0)
+    flat = vpr.exchange.flat.clone()
+    if base is None: base = flat
+    d = float((flat.double() - base.double()).norm() / base.double().norm())
+    print(f"[{setting or 'default':32s}] {ms:.4f} ms/step | " + " ".join(f"{k} {v:.3f}" for k, v in st.items() if v > 0) + f" | sum {sum(v for v in st.values() if v > 0):.3f} | grad diff vs first {d:.2e}", flush=True)
+    for k, v in defaults.items(): _lib.set_option(k, v)
