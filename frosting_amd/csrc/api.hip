@@ -34,8 +34,9 @@ std::atomic<int> g_profile_stage{-1};  // -1: every stage; k: only stage k gets 
 // buffers travels with those buffers: the carve of every field the backward reads depends on (P, W, H, R)
 // alone, and the binning mode is stamped into the image chunk's counters (Counters::tight_binning).
 std::atomic<int> g_global_bins{0};    // test hook: force the large-image (global-atomic) binning path
+std::atomic<int> g_ablate{0};         // TIMING EXPERIMENTS ONLY: kernels skip parts of their work (results are wrong)
 std::atomic<int> g_async_sh{0};       // SH colours on a side stream beside the binning stages (0: inside preprocess)
-std::atomic<int> g_bwd_batch{2};      // tuning: instances per reduction step of the backward blend (2 | 3)
+std::atomic<int> g_bwd_batch{3};      // tuning: instances per reduction step of the backward blend (2 | 3)
 std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
@@ -234,7 +235,8 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "profile_stage") == 0) return g_profile_stage.exchange(value < 0 || value >= ST_COUNT ? -1 : value);
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
-    if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value);
+    if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
+    if (name && strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -560,7 +562,7 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
-    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, stream), "preprocess_bwd"); }
+    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), stream), "preprocess_bwd"); }
     return FRG_OK;
 }
 

@@ -23,8 +23,8 @@ hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const
 #define FRG_BWD(B)                                                                                                         \
     hipLaunchKernelGGL((blend_bwd_kernel<FRG_EXACT, B>), dim3(xcd_grid_blocks(T)), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
-                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, batch >> 8)
-    if ((batch & 255) == 2) FRG_BWD(2); else FRG_BWD(3);
+                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order)
+    if (batch == 2) FRG_BWD(2); else FRG_BWD(3);
 #undef FRG_BWD
     return hipGetLastError();
 }

@@ -67,6 +67,10 @@ struct BlendMath<false> {
 
 #define BLEND_THREADS 256   // 4 waves = the 4 quadrants of one tile
 
+// 64-bit lane mask of a predicate, straight from the compare (HIP's __ballot(int) first materialises the
+// predicate as 0 / 1 in a VGPR and compares it again)
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ int lanes_before(uint64_t mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
 
 // wave-private LDS hand-off (no workgroup barrier anywhere in these kernels)
@@ -110,7 +114,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     uint32_t last = 0;
 
     for (int base = 0; base < n; base += 64) {
-        if (__ballot(!done) == 0ull) break;      // this quadrant is saturated
+        if (wave_ballot(!done) == 0ull) break;   // this quadrant is saturated
         const int cnt = min(64, n - base);
         bool hit = false;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
@@ -121,7 +125,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             col = rgb_clamped[id];
             hit = quadrant_hit(a.x, a.y, co, qx0, qy0);
         }
-        const uint64_t keep = __ballot(hit);
+        const uint64_t keep = wave_ballot(hit);
         const int nkeep = __popcll(keep);
         wave_lds_sync();                          // previous round's readers are done
         if (hit) {
@@ -248,7 +252,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order, int ablate)
+                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order)
 {
     using M = BlendMath<EXACT>;
     const int tile = order ? (int)order[blockIdx.x] : xcd_tile_of_block(blockIdx.x, T);
@@ -260,7 +264,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     __shared__ float4 s_a[64];     // x, y, quadrant mask, 0-based list position
     __shared__ float4 s_co[64];
     __shared__ float4 s_rgb[64];   // r, g, b, Gaussian-major slot index
-    __shared__ float s_part[64 * FRG_SLOT_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_red[BWD_BATCH * FRG_SLOT_FLOATS * 64];   // reduction matrix, one column per lane
 
     // Per-pixel state of the back-to-front walk.  The reference carries the colour
@@ -305,8 +308,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         const uint32_t id = point_list[rg.x + maxc - 1];
         cutoff[tile] = make_uint2(__float_as_uint(xydr[id].z), id);
     }
-    // gradient of pixel coordinate w.r.t. NDC (backward.cu:460-461)
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
     // walk the processed prefix [0, maxc) back to front, 64 instances at a time
     for (int hi = (int)maxc - 1; hi >= 0; hi -= 64) {
@@ -333,7 +334,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) dst[c] = 0.0f;
             }
         }
-        const uint64_t keep = __ballot(m != 0);
+        const uint64_t keep = wave_ballot(m != 0);
         const int nkeep = __popcll(keep);
         __syncthreads();
         if (m != 0) {
@@ -342,8 +343,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             s_co[d] = co;
             s_rgb[d] = make_float4(col.x, col.y, col.z, __uint_as_float(my_slot));
         }
-#pragma unroll
-        for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_part[lane * FRG_SLOT_FLOATS + c] = 0.0f;
         __syncthreads();
         // BWD_BATCH surviving instances per iteration; their BWD_BATCH x 9 per-lane partial sums are
         // reduced across the wave THROUGH LDS: every lane stores its 27 partials as one column of a
@@ -357,7 +356,12 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 #pragma unroll
             for (int h = 0; h < BWD_BATCH; h++)
 #pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[h][c] = 0.0f;
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) {
+                    acc[h][c] = 0.0f;
+                    // opaque to the optimiser: knowing the zero, it keeps one set of nine temporaries per quadrant
+                    // (zeroed again on every skipped quadrant) and adds them up afterwards
+                    asm volatile("" : "+v"(acc[h][c]));
+                }
             bool any = false;
 #pragma unroll
             for (int h = 0; h < BWD_BATCH; h++) {
@@ -367,59 +371,62 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                 const float4 ca = s_a[kk], cco = s_co[kk];
                 const uint32_t qm = __builtin_amdgcn_readfirstlane(__float_as_uint(ca.z));
                 const uint32_t pos = __float_as_uint(ca.w);  // 0-based position in the tile list
-                // phase 1: falloff on the quadrants the cull kept (wave-uniform mask)
-                float G[4], alpha[4], dxs[4], dys[4];
-                uint32_t ok = 0;
+                const float4 gc = s_rgb[kk];
+                // per quadrant the cull kept (wave-uniform mask): falloff, the reference's three tests, and --
+                // only if some pixel of the quadrant blended this Gaussian -- its gradient contributions
+                // (part[3..8] are pixel MOMENTS of v = G dL/dalpha; opacity, conic and the NDC factors are applied
+                // once per Gaussian by the per-Gaussian backward, after it has summed the instances)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (!(qm & (1u << q))) continue;
-                    const float power = M::power(ca.x, ca.y, cco, pxf[q], pyf[q], dxs[q], dys[q]);
-                    G[q] = M::expo(power);
-                    alpha[q] = fminf(0.99f, cco.w * G[q]);
-                    if (pos < lastcon[q] && !(power > 0.0f) && !(alpha[q] < 1.0f / 255.0f)) ok |= 1u << q;
-                }
-                if (__ballot(ok != 0) == 0ull) continue;  // this instance's partials stay zero
-                any = true;
-                if (ablate == 2) continue;   // TIMING EXPERIMENT ONLY
-                // phase 2: gradient contributions of the pixels that blended this Gaussian
-                // (part[3..7] are accumulated without their constant factors; see the write-out)
-                const float4 gc = s_rgb[kk];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (__ballot((ok >> q) & 1u) == 0ull) continue;   // wave-uniform
-                    if (!((ok >> q) & 1u)) continue;
-                    const float rinv = M::recip(1.f - alpha[q]);  // 1 - alpha >= 0.01
+                    float dx, dy;
+                    const float power = M::power(ca.x, ca.y, cco, pxf[q], pyf[q], dx, dy);
+                    const float G = M::expo(power);
+                    const float alpha = fminf(0.99f, cco.w * G);
+                    const bool ok = pos < lastcon[q] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    if (wave_ballot(ok) == 0ull) continue;       // wave-uniform
+                    any = true;
+                    // No per-lane branch below: a pixel that did not blend this Gaussian runs the same
+                    // instructions with alpha = G = 0, which leaves its state and every sum exactly unchanged
+                    // (T * 1, S + 0 * x, sums + 0).  A divergent `if (ok)` made the compiler merge nine zero-
+                    // initialised temporaries per quadrant into the accumulators (18 extra instructions of ~60).
+                    const float a_eff = ok ? alpha : 0.0f, g_eff = ok ? G : 0.0f;
+                    const float rinv = M::recip(1.f - a_eff);    // 1 - alpha >= 0.01; exactly 1 for a_eff = 0
                     Tr[q] = Tr[q] * rinv;                        // transmittance in front of this Gaussian
-                    const float w = alpha[q] * Tr[q];            // dC/dcolour
+                    const float w = a_eff * Tr[q];               // dC/dcolour
                     const float cdot = M::mad(gc.z, dLp[q][2], M::mad(gc.y, dLp[q][1], gc.x * dLp[q][0]));
                     part[0] = M::mad(w, dLp[q][0], part[0]);
                     part[1] = M::mad(w, dLp[q][1], part[1]);
                     part[2] = M::mad(w, dLp[q][2], part[2]);
                     const float dL_dalpha = M::mad(Tr[q], cdot, -(S[q] * rinv));
                     S[q] = M::mad(w, cdot, S[q]);
-                    // moments of v = G dL/dalpha over the pixels; opacity, conic and the NDC factors
-                    // are applied once per (tile, Gaussian) at the write-out below
-                    const float v = G[q] * dL_dalpha;
-                    const float vx = v * dxs[q], vy = v * dys[q];
+                    const float v = g_eff * dL_dalpha;
+                    const float vx = v * dx, vy = v * dy;
                     part[3] += vx;
                     part[4] += vy;
-                    part[5] = M::mad(vx, dxs[q], part[5]);
-                    part[6] = M::mad(vx, dys[q], part[6]);
-                    part[7] = M::mad(vy, dys[q], part[7]);
+                    part[5] = M::mad(vx, dx, part[5]);
+                    part[6] = M::mad(vx, dy, part[6]);
+                    part[7] = M::mad(vy, dy, part[7]);
                     part[8] += v;
                 }
             }
-            if (!any) continue;      // s_part rows of this batch stay zero
-            if (ablate == 1) { if (acc[0][0] == 12345.f) s_part[0] = 1.f; continue; }   // TIMING EXPERIMENT ONLY
+            const int row = lane >> 1, half = lane & 1;
+            const int inst = row / FRG_SLOT_FLOATS;              // which instance of the batch
+            const int comp = row - inst * FRG_SLOT_FLOATS;
+            // the lane that ends up with (instance, component) stores it straight into the instance's slot:
+            // the nine lanes of an instance write 36 consecutive bytes
+            const bool writer = half == 0 && row < BWD_BATCH * FRG_SLOT_FLOATS && k + inst < nkeep;
+            float* dst = writer ? slots + (size_t)__float_as_uint(s_rgb[k + inst].w) * FRG_SLOT_FLOATS + comp : nullptr;
+            if (!any) {              // nothing blended in this batch: its slots are still owed their zeros
+                if (writer) *dst = 0.0f;
+                continue;
+            }
             wave_lds_sync();         // the previous batch's readers are done with s_red
 #pragma unroll
             for (int h = 0; h < BWD_BATCH; h++)
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_red[(h * FRG_SLOT_FLOATS + c) * 64 + lane] = acc[h][c];
             wave_lds_sync();
-            const int row = lane >> 1, half = lane & 1;
-            const int inst = row / FRG_SLOT_FLOATS;              // which instance of the batch
-            const int comp = row - inst * FRG_SLOT_FLOATS;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             if (row < BWD_BATCH * FRG_SLOT_FLOATS) {
                 const float4* src = reinterpret_cast<const float4*>(s_red + row * 64 + half * 32);
@@ -433,27 +440,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             }
             float sum = (s0 + s1) + (s2 + s3);
             sum = dpp_step<0xB1, 0xf>(sum);                      // quad_perm [1,0,3,2]: the row's other half
-            if (half == 0 && row < BWD_BATCH * FRG_SLOT_FLOATS && k + inst < nkeep)
-                s_part[(k + inst) * FRG_SLOT_FLOATS + comp] = sum;
-        }
-        __syncthreads();
-        if (lane < nkeep) {
-            const uint32_t slot = __float_as_uint(s_rgb[lane].w);
-            float* dst = slots + (size_t)slot * FRG_SLOT_FLOATS;
-            float m[FRG_SLOT_FLOATS];
-#pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) m[c] = s_part[lane * FRG_SLOT_FLOATS + c];
-            // from pixel moments to the reference's per-Gaussian terms (backward.cu:536-554):
-            //   dL/dG = o dL/dalpha, dG/d(delta) = -G (a dx + b dy, c dy + b dx), d(delta)/d(NDC) = (W/2, H/2)
-            const float4 kc = s_co[lane];
-            const float o = kc.w;
-            dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2];
-            dst[3] = -o * M::mad(kc.y, m[4], kc.x * m[3]) * ddelx_dx;
-            dst[4] = -o * M::mad(kc.y, m[3], kc.z * m[4]) * ddely_dy;
-            dst[5] = -0.5f * o * m[5];
-            dst[6] = -0.5f * o * m[6];
-            dst[7] = -0.5f * o * m[7];
-            dst[8] = m[8];
+            if (writer) *dst = sum;
         }
     }
 }

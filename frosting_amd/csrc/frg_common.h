@@ -190,6 +190,26 @@ __device__ __forceinline__ int xcd_of_tile(int t, int T)
 }
 __host__ inline int xcd_grid_blocks(int T) { return ((T + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD; }
 
+// k / w and k % w for 0 <= k < 2^20, 1 <= w < 2^10 (positions inside a tile rectangle) without the ~25-instruction
+// integer division: (k + 0.5) * rcp(w) is within 1e-6 relative of (k + 0.5) / w, whose distance to the next integer
+// is at least 0.5 / w >= 5e-4 -- the truncation is exact.
+__device__ __forceinline__ void rect_divmod(uint32_t k, uint32_t w, uint32_t& q, uint32_t& r)
+{
+    q = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+    r = k - q * w;
+}
+
+// wave64 inclusive prefix sum on DPP moves (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 and
+// row_bcast:31 across them): ~7 cycles per step against ~24 for a ds_bpermute shuffle (tools/micro/pk_rate.hip)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+#define FRG_SCAN_STEP(CTRL, ROWMASK) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+    FRG_SCAN_STEP(0x111, 0xf) FRG_SCAN_STEP(0x112, 0xf) FRG_SCAN_STEP(0x114, 0xf) FRG_SCAN_STEP(0x118, 0xf)
+    FRG_SCAN_STEP(0x142, 0xa) FRG_SCAN_STEP(0x143, 0xc)
+#undef FRG_SCAN_STEP
+    return v;
+}
+
 // float -> int exactly like the reference's C cast on the GPU (v_cvt_i32_f32).
 __device__ __forceinline__ int f2i(float v) { return (int)v; }
 

@@ -15,15 +15,11 @@
 
 namespace frg {
 
-// wave64 inclusive scan with DPP-free shuffles (6 steps); fine for O(P) kernels.
+// wave64 inclusive scan (DPP, frg_common.h)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < FRG_WAVE; d <<= 1) {
-        uint32_t n = __shfl_up(v, d, FRG_WAVE);
-        if (lane >= d) v += n;
-    }
-    return v;
+    (void)lane;
+    return wave_incl_scan_dpp(v);
 }
 
 // Walk all (Gaussian, tile) instances of the wave's 64 Gaussians with the 64 lanes in
@@ -59,8 +55,8 @@ __device__ __forceinline__ void wave_for_each_instance(uint32_t touched, int x0,
             }
             const int4 info = lds_info[owner];
             const uint32_t k = s - lds_start[owner];
-            const uint32_t w = (uint32_t)info.z;
-            const uint32_t ry = k / w, rx = k - ry * w;
+            uint32_t ry, rx;
+            rect_divmod(k, (uint32_t)info.z, ry, rx);
             f(owner, (info.y + (int)ry) * gx + info.x + (int)rx, info.x + (int)rx, info.y + (int)ry, (uint32_t)info.w);
         }
     }

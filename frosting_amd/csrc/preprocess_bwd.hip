@@ -50,7 +50,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const Counters* __restrict__ counters, const float* __restrict__ slots,
                       float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
-                      float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+                      float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,6 +76,19 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         clamp_bits = __float_as_uint(rgb_clamped[idx].w);
         tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
     }
+    // SH rows (192 B per Gaussian, the largest stream of this kernel): the first sub-batch is requested NOW, so
+    // that it is in flight during the whole slot reduction instead of starting after it
+    float4 sh_pre[BWD_SUB * 12 / 64];
+    const int sh_nvalid = min(64, P - idx0);
+    auto sh_issue = [&](int h) {
+        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
+#pragma unroll
+        for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
+            const int f = k * 64 + lane, gl = f / 12;
+            sh_pre[k] = (h * BWD_SUB + gl < sh_nvalid) ? src[(size_t)h * BWD_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (SH16 && shs) sh_issue(0);
     // ---- 1. slot reduction ------------------------------------------------------
     const uint32_t incl = valid ? point_offsets[idx] : 0u;
     const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
@@ -116,8 +129,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         if (in_run) {
             const int4 info = own_info[owner];
             const uint32_t k = s - own_start[owner];
-            const uint32_t w = (uint32_t)info.z;
-            const uint32_t ry = k / w, rx = k - ry * w;
+            uint32_t ry, rx;
+            rect_divmod(k, (uint32_t)info.z, ry, rx);
             const int tx = info.x + (int)rx, ty = info.y + (int)ry;
             const uint2 cut = cutoff[ty * vp.gx + tx];
             const uint32_t dbits = (uint32_t)info.w, gid = (uint32_t)(idx0 + owner);
@@ -137,6 +150,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     int owner_n = 0;
     bool in_run_n = false;
     float part_n[FRG_SLOT_FLOATS];
+    if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
     if (S > 0) fetch(0, owner_n, in_run_n, part_n);
     for (uint32_t s0 = 0; s0 < S; s0 += 64) {
         int owner = owner_n;
@@ -145,17 +159,30 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
         for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = part_n[c];
         if (s0 + 64 < S) fetch(s0 + 64, owner_n, in_run_n, part_n);
-        // segmented inclusive scan over lanes (owners are non-decreasing with the lane)
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o_up = __shfl_up(owner, d, 64);
-            const bool take = lane >= d && o_up == owner;
-#pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) {
-                const float v_up = __shfl_up(part[c], d, 64);
-                part[c] += take ? v_up : 0.0f;
-            }
+        // Segmented inclusive scan over the lanes (owners are non-decreasing with the lane), on DPP moves:
+        // four row_shr steps inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the last lane of a
+        // row (of the lower half) into the lanes above that continue its owner's run.  A ds_bpermute shuffle
+        // costs ~24 cycles per wave on gfx950, a DPP move ~7 (tools/micro/pk_rate.hip): 60 shuffles per batch
+        // of 64 slots were the largest single item of this kernel.  A lane whose source does not exist (start
+        // of the row) or belongs to another owner multiplies what it receives by 0: fma(v, 1, p) == v + p.
+        float tk[6];
+        {
+            const int own_i = owner;
+#define FRG_SEG_STEP(I, CTRL, ROWMASK)                                                                              \
+            { const int o_up = __builtin_amdgcn_update_dpp(-1, own_i, CTRL, ROWMASK, 0xf, false);                   \
+              tk[I] = (o_up == own_i) ? 1.0f : 0.0f; }
+            FRG_SEG_STEP(0, 0x111, 0xf) FRG_SEG_STEP(1, 0x112, 0xf) FRG_SEG_STEP(2, 0x114, 0xf) FRG_SEG_STEP(3, 0x118, 0xf)
+            FRG_SEG_STEP(4, 0x142, 0xa) FRG_SEG_STEP(5, 0x143, 0xc)
+#undef FRG_SEG_STEP
         }
+#define FRG_SEG_ADD(I, CTRL, ROWMASK)                                                                               \
+        _Pragma("unroll") for (int c = 0; c < FRG_SLOT_FLOATS; c++) {                                               \
+            const float v_up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part[c]), CTRL, ROWMASK, 0xf, false)); \
+            part[c] = __builtin_fmaf(v_up, tk[I], part[c]);                                                         \
+        }
+        FRG_SEG_ADD(0, 0x111, 0xf) FRG_SEG_ADD(1, 0x112, 0xf) FRG_SEG_ADD(2, 0x114, 0xf) FRG_SEG_ADD(3, 0x118, 0xf)
+        FRG_SEG_ADD(4, 0x142, 0xa) FRG_SEG_ADD(5, 0x143, 0xc)
+#undef FRG_SEG_ADD
         const int o_next = __shfl_down(owner, 1, 64);
         if (in_run && (lane == 63 || o_next != owner)) {
 #pragma unroll
@@ -166,6 +193,20 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     float part[FRG_SLOT_FLOATS];
 #pragma unroll
     for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = acc[lane * FRG_SLOT_FLOATS + c];
+    // The blend backward stores pixel MOMENTS of v = G dL/dalpha per (tile, Gaussian): sum v dx, v dy, v dx^2,
+    // v dx dy, v dy^2, v.  The map to the reference's terms (backward.cu:536-554: dL/dG = o dL/dalpha,
+    // dG/d(delta) = -G (a dx + b dy, c dy + b dx), d(delta)/d(NDC) = (W/2, H/2)) is linear with per-GAUSSIAN
+    // coefficients, so it is applied here, once per Gaussian after the sum over its tiles, instead of once per
+    // (tile, Gaussian) instance in the blend kernel.
+    if (visible) {
+        const float4 kc = conic_opacity[idx];
+        const float o = kc.w, m3 = part[3], m4 = part[4];
+        part[3] = -o * (kc.x * m3 + kc.y * m4) * (0.5f * vp.W);
+        part[4] = -o * (kc.z * m4 + kc.y * m3) * (0.5f * vp.H);
+        part[5] = -0.5f * o * part[5];
+        part[6] = -0.5f * o * part[6];
+        part[7] = -0.5f * o * part[7];
+    }
 
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -249,7 +290,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     }
 
     // ---- 4. SH path (backward.cu:20-139) ----
-    if (shs) {
+    if (shs && !(ablate & 2)) {
         // dL/dsh[i][ch] = wgt[i] * dRGB[ch]; the view-direction gradient needs
         // d(colour)/d(dir) = sum_i dbasis_i/d(dir) * sh[i], accumulated per channel in ddx/ddy/ddz
         float wgt[16], dRGB[3] = {0.f, 0.f, 0.f};
@@ -310,26 +351,16 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         if (SH16) {
             // coalesced read: the wave's 64 x 48 floats are one contiguous stream of 768 float4,
             // transposed through LDS 16 Gaussians at a time and consumed as they arrive
-            const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
-            const int nvalid = min(64, P - idx0);
-            // software pipeline: sub-batch h + 1 is in flight while sub-batch h is consumed
-            float4 pre[BWD_SUB * 12 / 64];
-            auto issue = [&](int h) {
-#pragma unroll
-                for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
-                    const int f = k * 64 + lane, gl = f / 12;
-                    pre[k] = (h * BWD_SUB + gl < nvalid) ? src[(size_t)h * BWD_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            };
-            issue(0);
+            // software pipeline: sub-batch h + 1 is in flight while sub-batch h is consumed (sub-batch 0 was
+            // requested at the top of the kernel)
 #pragma unroll 1
             for (int h = 0; h < 64 / BWD_SUB; h++) {
 #pragma unroll
                 for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
                     const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                    shbuf[gl * BWD_ROW_F4 + j] = pre[k];
+                    shbuf[gl * BWD_ROW_F4 + j] = sh_pre[k];
                 }
-                if (h + 1 < 64 / BWD_SUB) issue(h + 1);
+                if (h + 1 < 64 / BWD_SUB) sh_issue(h + 1);
                 wave_fence();
                 if ((lane / BWD_SUB) == h && visible) {
 #pragma unroll
@@ -439,7 +470,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 }
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
-                                 const ImageState& img, const float* slots, const BwdOutputs& o, hipStream_t s)
+                                 const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, hipStream_t s)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
@@ -449,7 +480,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
     hipLaunchKernelGGL((preprocess_bwd_kernel<S16>), grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,              \
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
-                       o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot)
+                       o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate)
     if (sh16) FRG_PBW(true); else FRG_PBW(false);
 #undef FRG_PBW
     return hipGetLastError();
