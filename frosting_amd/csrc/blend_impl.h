@@ -46,6 +46,8 @@ struct BlendMath<true> {
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
     static __device__ __forceinline__ float recip(float x) { return 1.0f / x; }
     static __device__ __forceinline__ float mad(float a, float b, float c) { return a * b + c; }   // two roundings (this TU: contraction off)
+    // what the staging lane leaves in LDS for the per-pixel loop: the conic as the reference holds it
+    static __device__ __forceinline__ float4 stage(float4 co) { return co; }
 };
 
 template <>
@@ -53,13 +55,21 @@ struct BlendMath<false> {
     // Every fused multiply-add of the fast path is written out (the TU is compiled with contraction off): what
     // gets fused must not depend on where the compiler unrolled or inlined a copy of the code, or the same
     // (pixel, Gaussian) pair would round differently at different positions of a tile list.
-    static __device__ __forceinline__ float power(float x, float y, float4 co, float px, float py, float& dx, float& dy)
+    // The staging lane folds the -1/2 of the exponent and the log2(e) of exp -> exp2 into the conic once per
+    // Gaussian (stage()); per pixel: power' = dx (a' dx + b' dy) + c' dy^2 in log2 units, G = exp2(power').
+    // Seven instructions and one v_exp instead of ten and one; `power > 0` keeps its sign.
+    static __device__ __forceinline__ float4 stage(float4 co)
+    {
+        const float l2e = 1.4426950408889634f;
+        return make_float4(-0.5f * l2e * co.x, -l2e * co.y, -0.5f * l2e * co.z, co.w);
+    }
+    static __device__ __forceinline__ float power(float x, float y, float4 sc, float px, float py, float& dx, float& dy)
     {
         dx = x - px; dy = y - py;
-        const float q = __builtin_fmaf(co.z * dy, dy, co.x * dx * dx);
-        return __builtin_fmaf(-0.5f, q, -(co.y * dx * dy));
+        const float t = __builtin_fmaf(sc.x, dx, sc.y * dy);
+        return __builtin_fmaf(t, dx, (sc.z * dy) * dy);
     }
-    static __device__ __forceinline__ float expo(float p) { return __expf(p); }
+    static __device__ __forceinline__ float expo(float p) { return __builtin_amdgcn_exp2f(p); }
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
     static __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -131,7 +141,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         if (hit) {
             const int d = lanes_before(keep, lane);
             s_a[d] = make_float4(a.x, a.y, 0.f, __uint_as_float((uint32_t)(base + lane + 1)));
-            s_co[d] = co;
+            s_co[d] = M::stage(co);
             s_rgb[d] = col;
         }
         wave_lds_sync();
@@ -340,7 +350,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         if (m != 0) {
             const int d = lanes_before(keep, lane);
             s_a[d] = make_float4(a.x, a.y, __uint_as_float(m), __uint_as_float((uint32_t)(hi - lane)));
-            s_co[d] = co;
+            s_co[d] = M::stage(co);
             s_rgb[d] = make_float4(col.x, col.y, col.z, __uint_as_float(my_slot));
         }
         __syncthreads();
