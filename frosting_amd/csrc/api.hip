@@ -398,6 +398,8 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, (uint32_t)capacity, stream), "scan"); }
     { const int rc_ = fork_sh(2); if (rc_ < 0) return rc_; }
 
+    int index_bits = 1;
+    while (index_bits < 32 && (1u << index_bits) < (uint32_t)P) index_bits++;
     int R = capacity;
     if (capacity > 0) {
         // deferred counters: everything below is enqueued without knowing R on the host; the
@@ -411,7 +413,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1);
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, 0, index_bits, b.point_list, stream), "sort"); }
         if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
         StageScope sc_(ST_BLEND_FWD, stream);
         if (exact_blend())
@@ -440,7 +442,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (R > 0) {
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, max_tile, index_bits, b.point_list, stream), "sort"); }
     } else {
         // point_offsets must still be defined for backward
         FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");

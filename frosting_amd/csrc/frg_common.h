@@ -131,7 +131,12 @@ struct BinningState {
     uint32_t* point_list;    // sorted Gaussian indices, tile-major
     uint2* pairs;            // (depth bits, index), tile-major, scatter order
     uint2* pairs_tmp;        // ping-pong buffer, only when some tile exceeds the LDS capacity
+    uint32_t* big_hist;      // digit counters of the multi-workgroup sort of those tiles: one 256-entry row per 1024 elements
     size_t bytes;
+    // rows of big_hist: row r of the tile whose list starts at element x has the id (x >> 10) + (x >> 13) + r --
+    // unique and increasing, because only lists longer than 8192 = 2^13 entries own rows
+    __host__ __device__ static size_t big_hist_rows(size_t R) { return (R >> 10) + (R >> 13) + 2; }
+    __host__ __device__ static size_t big_hist_row(uint32_t first, uint32_t r) { return (size_t)(first >> 10) + (first >> 13) + r; }
     __host__ static BinningState carve(char* base, int R, int max_tile_count)
     {
         BinningState s;
@@ -140,7 +145,11 @@ struct BinningState {
         s.point_list = (uint32_t*)(base + o); o = align_up(o + Rr * 4, 256);
         s.pairs = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
         s.pairs_tmp = nullptr;
-        if (max_tile_count > FRG_SORT_LDS_CAP) { s.pairs_tmp = (uint2*)(base + o); o = align_up(o + Rr * 8, 256); }
+        s.big_hist = nullptr;
+        if (max_tile_count > FRG_SORT_LDS_CAP) {
+            s.pairs_tmp = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
+            s.big_hist = (uint32_t*)(base + o); o = align_up(o + big_hist_rows(Rr) * 256 * 4, 256);
+        }
         s.bytes = o;
         return s;
     }

@@ -23,9 +23,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // class_count: host copy of the per-class tile counts, or nullptr when they are only known on the
 // device (deferred-counters forward) -- grid_hint[] then sizes the launches and the workgroups
 // stride over the device-side lists (class_count_dev), whatever their true length.
+// big_hist: digit counters of the multi-workgroup sort (lists longer than the LDS capacity); max_tile_count: longest
+// list (0: unknown, kernels stride); index_bits: bits needed for a Gaussian index (tie order = ascending index)
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
                             const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
-                            uint32_t* point_list, hipStream_t stream);
+                            uint32_t* big_hist, int max_tile_count, int index_bits, uint32_t* point_list, hipStream_t stream);
 
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                   const float* bg, float* out_color, hipStream_t s);

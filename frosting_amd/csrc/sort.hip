@@ -31,87 +31,6 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane)
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// One stable counting pass on digit `shift` from src to dst (n elements).
-// whist: [NWAVES][256] per-wave digit counters, wave-private during the sweeps.
-// Returns false (and moves nothing) when every key has the same digit.
-template <int NWAVES, bool BY_INDEX, typename PtrT>
-__device__ __forceinline__ bool radix_pass(PtrT src, PtrT dst, int n, int shift, uint32_t* whist, uint32_t* scratch)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NT = NWAVES * 64;
-    for (int i = tid; i < NWAVES * 256; i += NT) whist[i] = 0;
-    __syncthreads();
-    // contiguous strip per wave (keeps the pass stable), multiple of 64
-    const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
-    const int begin = wave * strip, end = min(n, begin + strip);
-    uint32_t* myhist = whist + wave * 256;
-    for (int i = begin; i < end; i += 64) {
-        const bool valid = i + lane < end;
-        const uint32_t key = valid ? (BY_INDEX ? src[i + lane].y : src[i + lane].x) : 0u;
-        const uint32_t d = (key >> shift) & 255u;
-        const uint64_t peers = match_digit(d, valid);
-        if (valid && lanes_below(peers, lane) == 0) myhist[d] += (uint32_t)__popcll(peers);
-    }
-    __syncthreads();
-    // digit totals, exclusive over waves then over digits
-    if (tid < 256) {
-        uint32_t run = 0;
-#pragma unroll
-        for (int w = 0; w < NWAVES; w++) {
-            const uint32_t c = whist[w * 256 + tid];
-            whist[w * 256 + tid] = run;
-            run += c;
-        }
-        scratch[tid] = run;  // total for digit tid
-    }
-    __syncthreads();
-    if (tid < 256 && scratch[tid] == (uint32_t)n) scratch[256] = 1;  // one digit holds everything
-    __syncthreads();
-    const bool uniform = scratch[256] != 0;
-    __syncthreads();
-    if (uniform) {
-        if (tid == 0) scratch[256] = 0;
-        __syncthreads();
-        return false;
-    }
-    if (tid < 64) {  // exclusive scan of 256 totals by one wave, 4 per lane
-        uint32_t v0 = scratch[4 * lane], v1 = scratch[4 * lane + 1], v2 = scratch[4 * lane + 2], v3 = scratch[4 * lane + 3];
-        uint32_t s = v0 + v1 + v2 + v3, inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        uint32_t ex = inc - s;
-        scratch[4 * lane] = ex; scratch[4 * lane + 1] = ex + v0;
-        scratch[4 * lane + 2] = ex + v0 + v1; scratch[4 * lane + 3] = ex + v0 + v1 + v2;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const uint32_t base = scratch[tid];
-#pragma unroll
-        for (int w = 0; w < NWAVES; w++) whist[w * 256 + tid] += base;
-    }
-    __syncthreads();
-    for (int i = begin; i < end; i += 64) {
-        const bool valid = i + lane < end;
-        uint2 e = make_uint2(0u, 0u);
-        if (valid) e = src[i + lane];
-        const uint32_t d = ((BY_INDEX ? e.y : e.x) >> shift) & 255u;
-        const uint64_t peers = match_digit(d, valid);
-        const uint32_t rank = lanes_below(peers, lane);
-        uint32_t pos = 0;
-        if (valid) pos = myhist[d] + rank;
-        // all lanes have read myhist before any leader bumps it (same wave, LDS ops in order,
-        // but make the dependence explicit for the compiler)
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) myhist[d] += (uint32_t)__popcll(peers);
-        if (valid) dst[pos] = e;
-    }
-    __syncthreads();
-    return true;
-}
-
 // Depth ties: order equal-depth runs by ascending index (the stable-sort tie rule,
 // SURVEY Appendix A-7).  count_ties() returns the number of adjacent equal-depth
 // pairs; a handful are fixed by insertion (fix_ties), many (coplanar scenes) by
@@ -148,29 +67,6 @@ __device__ __forceinline__ void fix_ties(PtrT a, int n, int nthreads)
         }
     }
     __syncthreads();
-}
-
-// Full (depth, index) ordering of one segment; returns the buffer holding the result.
-template <int NWAVES, typename PtrT>
-__device__ __forceinline__ PtrT sort_segment(PtrT src, PtrT dst, int n, uint32_t* whist, uint32_t* scratch)
-{
-    constexpr int NT = NWAVES * 64;
-#pragma unroll 1
-    for (int pass = 0; pass < 4; pass++) {
-        if (radix_pass<NWAVES, false, PtrT>(src, dst, n, 8 * pass, whist, scratch)) { PtrT t = src; src = dst; dst = t; }
-    }
-    const int ties = count_ties<PtrT>(src, n, NT, scratch);
-    if (ties == 0) return src;
-    if (ties <= 32) { fix_ties<PtrT>(src, n, NT); return src; }
-#pragma unroll 1
-    for (int pass = 0; pass < 4; pass++) {
-        if (radix_pass<NWAVES, true, PtrT>(src, dst, n, 8 * pass, whist, scratch)) { PtrT t = src; src = dst; dst = t; }
-    }
-#pragma unroll 1
-    for (int pass = 0; pass < 4; pass++) {
-        if (radix_pass<NWAVES, false, PtrT>(src, dst, n, 8 * pass, whist, scratch)) { PtrT t = src; src = dst; dst = t; }
-    }
-    return src;
 }
 
 // ---- LDS classes: register-staged, in-place passes --------------------------------
@@ -325,27 +221,114 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __
     }
 }
 
-// Fallback for tile lists longer than the LDS capacity: same passes, ping-pong
-// in global memory (pairs <-> pairs_tmp); only histograms live in LDS.
-template <int NWAVES>
-__global__ void __launch_bounds__(NWAVES * 64)
-sort_tiles_global_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
-                         const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_tmp, uint32_t* __restrict__ point_list)
+// ---- lists longer than the LDS capacity: multi-workgroup LSD radix sort in global memory ----------------
+// One workgroup per list takes milliseconds on a list of 10^5 entries -- clustered scenes
+// have them.  Here every 1024-element strip of such a list is one WAVE's work: per 8-bit digit
+//   big_count   each wave counts the digits of its strip -> one 256-entry row of big_hist
+//   big_offsets per list: exclusive scan of the rows, digit-major then strip-major (stable)
+//   big_move    each wave ranks its strip again (ballot matching keeps the strip's order) and scatters
+// ping-ponging pairs <-> pairs_tmp.  Passes on the INDEX bits first, then on the 32 depth bits: LSD stability
+// leaves equal depths in ascending index order, the reference's tie rule.  The last pass writes point_list.
+#define BIG_STRIP 1024
+#define BIG_THREADS 256    // 4 waves = 4 strips per workgroup
+
+template <bool BY_INDEX>
+__global__ void __launch_bounds__(BIG_THREADS)
+big_count_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
+                 const uint2* __restrict__ ranges, const uint2* __restrict__ src, int shift, uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t whist[NWAVES * 256];
-    __shared__ uint32_t scratch[260];
-    constexpr int NT = NWAVES * 64;
-    const int tid = threadIdx.x;
-    const uint32_t ntiles = *list_len;
-    for (uint32_t item = blockIdx.x; item < ntiles; item += gridDim.x) {
-        __syncthreads();
-        const int tile = (int)tile_list[item];
-        const uint2 rg = ranges[tile];
+    __shared__ uint32_t whist[(BIG_THREADS / 64) * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* myhist = whist + wave * 256;
+    // the grid normally covers every (list, strip) pair once; both loops stride so that a grid sized from an
+    // estimate (deferred-counters forward) still covers everything
+    for (uint32_t item = blockIdx.y; item < *list_len; item += gridDim.y) {
+        const uint2 rg = ranges[tile_list[item]];
         const int n = (int)(rg.y - rg.x);
-        if (tid == 0) scratch[256] = 0;
+        for (int strip = blockIdx.x * (BIG_THREADS / 64) + wave; strip * BIG_STRIP < n; strip += gridDim.x * (BIG_THREADS / 64)) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; i++) myhist[lane * 4 + i] = 0;
+            const int begin = strip * BIG_STRIP, end = min(n, begin + BIG_STRIP);
+            for (int i = begin; i < end; i += 64) {
+                const bool valid = i + lane < end;
+                const uint2 e = valid ? src[rg.x + i + lane] : make_uint2(0u, 0u);
+                const uint32_t d = ((BY_INDEX ? e.y : e.x) >> shift) & 255u;
+                const uint64_t peers = match_digit(d, valid);
+                if (valid && lanes_below(peers, lane) == 0) myhist[d] += (uint32_t)__popcll(peers);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* row = hist + BinningState::big_hist_row(rg.x, (uint32_t)strip) * 256;
+#pragma unroll
+            for (int i = 0; i < 4; i++) row[lane + 64 * i] = myhist[lane + 64 * i];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+big_offsets_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
+                   const uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t tot[256];
+    const int d = threadIdx.x;
+    for (uint32_t item = blockIdx.x; item < *list_len; item += gridDim.x) {
+        const uint2 rg = ranges[tile_list[item]];
+        const int n = (int)(rg.y - rg.x);
+        const int nstrips = (n + BIG_STRIP - 1) / BIG_STRIP;
+        uint32_t* rows = hist + BinningState::big_hist_row(rg.x, 0u) * 256;
+        uint32_t run = 0;
+        for (int r = 0; r < nstrips; r++) { const uint32_t c = rows[(size_t)r * 256 + d]; rows[(size_t)r * 256 + d] = run; run += c; }
         __syncthreads();
-        uint2* src = sort_segment<NWAVES, uint2*>(pairs + rg.x, pairs_tmp + rg.x, n, whist, scratch);
-        for (int i = tid; i < n; i += NT) point_list[rg.x + i] = src[i].y;
+        tot[d] = run;
+        __syncthreads();
+        if (d < 64) {   // exclusive scan of the 256 digit totals by one wave, 4 per lane
+            const uint32_t v0 = tot[4 * d], v1 = tot[4 * d + 1], v2 = tot[4 * d + 2], v3 = tot[4 * d + 3];
+            const uint32_t s = v0 + v1 + v2 + v3;
+            const uint32_t ex = wave_incl_scan_dpp(s) - s;
+            tot[4 * d] = ex; tot[4 * d + 1] = ex + v0; tot[4 * d + 2] = ex + v0 + v1; tot[4 * d + 3] = ex + v0 + v1 + v2;
+        }
+        __syncthreads();
+        const uint32_t base = tot[d];
+        for (int r = 0; r < nstrips; r++) rows[(size_t)r * 256 + d] += base;
+    }
+}
+
+template <bool BY_INDEX, bool LAST>
+__global__ void __launch_bounds__(BIG_THREADS)
+big_move_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
+                const uint2* __restrict__ ranges, const uint2* __restrict__ src, uint2* __restrict__ dst,
+                uint32_t* __restrict__ point_list, int shift, const uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t whist[(BIG_THREADS / 64) * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* cursor = whist + wave * 256;
+    for (uint32_t item = blockIdx.y; item < *list_len; item += gridDim.y) {
+        const uint2 rg = ranges[tile_list[item]];
+        const int n = (int)(rg.y - rg.x);
+        for (int strip = blockIdx.x * (BIG_THREADS / 64) + wave; strip * BIG_STRIP < n; strip += gridDim.x * (BIG_THREADS / 64)) {
+            const uint32_t* row = hist + BinningState::big_hist_row(rg.x, (uint32_t)strip) * 256;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; i++) cursor[lane + 64 * i] = row[lane + 64 * i];
+            __builtin_amdgcn_wave_barrier();
+            const int begin = strip * BIG_STRIP, end = min(n, begin + BIG_STRIP);
+            for (int i = begin; i < end; i += 64) {
+                const bool valid = i + lane < end;
+                const uint2 e = valid ? src[rg.x + i + lane] : make_uint2(0u, 0u);
+                const uint32_t d = ((BY_INDEX ? e.y : e.x) >> shift) & 255u;
+                const uint64_t peers = match_digit(d, valid);
+                const uint32_t rank = lanes_below(peers, lane);
+                uint32_t pos = 0;
+                if (valid) pos = cursor[d] + rank;
+                __builtin_amdgcn_wave_barrier();                  // all lanes read the cursor before a leader bumps it
+                if (valid && rank == 0) cursor[d] += (uint32_t)__popcll(peers);
+                if (valid) {
+                    if (LAST) point_list[rg.x + pos] = e.y;
+                    else dst[rg.x + pos] = e;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
 }
 
@@ -409,7 +392,7 @@ struct SortStreams {
 
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
                             const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
-                            uint32_t* point_list, hipStream_t stream)
+                            uint32_t* big_hist, int max_tile_count, int index_bits, uint32_t* point_list, hipStream_t stream)
 {
     int cc[FRG_SORT_CLASSES];
     for (int k = 0; k < FRG_SORT_CLASSES; k++) {
@@ -439,8 +422,24 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
     // >8192 global ping-pong; longest-running classes first
     auto launch_global_class = [&]() -> hipError_t {
         if (!c4) return hipSuccess;
-        if (!pairs_tmp) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((sort_tiles_global_kernel<16>), dim3(c4), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, len + 4, ranges, pairs, pairs_tmp, point_list);
+        if (!pairs_tmp || !big_hist) return hipErrorInvalidValue;
+        const uint32_t* list = class_tiles + (size_t)4 * T;
+        // strips of the longest list per workgroup row; when its length is only an estimate the kernels stride
+        const int strips = ((max_tile_count > 0 ? max_tile_count : 4 * FRG_SORT_LDS_CAP) + BIG_STRIP - 1) / BIG_STRIP;
+        const dim3 grid((strips + BIG_THREADS / 64 - 1) / (BIG_THREADS / 64), c4 < 4096 ? c4 : 4096);
+        uint2 *src = pairs, *dst = pairs_tmp;
+        const int index_passes = (index_bits + 7) / 8;
+        for (int pass = 0; pass < index_passes + 4; pass++) {
+            const bool by_index = pass < index_passes, last = pass == index_passes + 3;
+            const int shift = 8 * (by_index ? pass : pass - index_passes);
+            if (by_index) hipLaunchKernelGGL((big_count_kernel<true>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, shift, big_hist);
+            else          hipLaunchKernelGGL((big_count_kernel<false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, shift, big_hist);
+            hipLaunchKernelGGL(big_offsets_kernel, dim3(grid.y), dim3(256), 0, s2, list, len + 4, ranges, big_hist);
+            if (by_index)  hipLaunchKernelGGL((big_move_kernel<true, false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
+            else if (last) hipLaunchKernelGGL((big_move_kernel<false, true>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
+            else           hipLaunchKernelGGL((big_move_kernel<false, false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
+            uint2* t = src; src = dst; dst = t;
+        }
         return hipGetLastError();
     };
     // a known non-empty >8192 class runs longest and goes first; when its length is only an estimate
