@@ -39,7 +39,35 @@ class ForwardArgs(C.Structure):
                 ("debug", C.c_int),
                 ("hip_stream", C.c_void_p),
                 ("instance_capacity", C.c_int),
-                ("keep_mask", C.c_void_p)]
+                ("keep_mask", C.c_void_p),
+                # raw-parameter mode (activations and the shell gather inside the per-Gaussian kernels)
+                ("raw_opacities", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_rotations", C.c_void_p),
+                ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p)]
+
+
+class BackwardArgs(C.Structure):
+    """frg_backward_args (include/frosting_rasterizer.h)."""
+    _fields_ = [("struct_size", C.c_size_t),
+                ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("R", C.c_int),
+                ("background", C.c_void_p),
+                ("width", C.c_int), ("height", C.c_int),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("scales", C.c_void_p),
+                ("scale_modifier", C.c_float),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("radii", C.c_void_p),
+                ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("image_buffer", C.c_void_p),
+                ("dL_dpix", C.c_void_p),
+                ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolor", C.c_void_p),
+                ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p),
+                ("dL_drot", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("debug", C.c_int),
+                ("hip_stream", C.c_void_p),
+                ("raw_opacities", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_rotations", C.c_void_p),
+                ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p),
+                ("dL_dshell_logits", C.c_void_p), ("dL_dshell_cell_verts", C.c_void_p)]
 
 
 def build(verbose: bool = False) -> str:
@@ -112,6 +140,8 @@ def lib():
                                 C.c_double, C.c_double, C.c_double, i, f, vp]
     L.frg_forward_ex.restype = i
     L.frg_forward_ex.argtypes = [C.POINTER(ForwardArgs)]
+    L.frg_backward_ex.restype = i
+    L.frg_backward_ex.argtypes = [C.POINTER(BackwardArgs)]
     L.frg_forward_finish.restype = i
     L.frg_forward_finish.argtypes = [vp, i, C.POINTER(C.c_int)]
     L.frg_backward.restype = i
@@ -165,7 +195,7 @@ EXPORTED_SYMBOLS = [
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_sh_color_grad", "frg_sh_grad_from_views",
-    "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_adam_step",
+    "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_backward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",
     "frg_knn_workspace_bytes", "frg_knn_mean_dist2", "frg_shell_points", "frg_shell_points_backward",
 ]

@@ -326,7 +326,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, int prefiltered,
                         float* out_color, int* radii, int debug, void* hip_stream, int capacity,
-                        const unsigned char* keep_mask = nullptr)
+                        const unsigned char* keep_mask = nullptr, const frg::RawInputs* raw = nullptr)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
@@ -335,11 +335,21 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         FRG_HIP(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), stream));
         return 0;
     }
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background)
-        return fail(FRG_EINVAL, "null required pointer");
+    const frg::RawInputs rw = raw ? *raw : frg::RawInputs{};
+    if (!viewmatrix || !projmatrix || !cam_pos || !background) return fail(FRG_EINVAL, "null required pointer");
+    if ((means3D == nullptr) == (rw.shell_logits == nullptr))
+        return fail(FRG_EINVAL, "provide exactly one of means3D / shell_logits");
+    if (rw.shell_logits && (!rw.shell_verts || !rw.shell_cells))
+        return fail(FRG_EINVAL, "shell_logits needs shell_cell_verts and shell_cells");
+    if ((opacities == nullptr) == (rw.raw_opacity == nullptr))
+        return fail(FRG_EINVAL, "provide exactly one of opacities / raw_opacities");
     if ((shs == nullptr) == (colors_precomp == nullptr))
         return fail(FRG_EINVAL, "provide exactly one of shs / colors_precomp");
-    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+    if ((rw.raw_scale == nullptr) != (rw.raw_rot == nullptr))
+        return fail(FRG_EINVAL, "raw_scales and raw_rotations come together");
+    const bool have_sr = (scales && rotations) || rw.raw_scale;
+    if ((scales || rotations) && rw.raw_scale) return fail(FRG_EINVAL, "provide (scales, rotations) or their raw forms, not both");
+    if (((scales == nullptr) != (rotations == nullptr)) || have_sr == (cov3D_precomp != nullptr))
         return fail(FRG_EINVAL, "provide exactly one of (scales, rotations) / cov3D_precomp");
     if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1)))
         return fail(FRG_EINVAL, "SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
@@ -368,10 +378,11 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
     in.keep_mask = keep_mask;
+    in.raw = rw;
     // SH colours: nothing before the blend needs them, and the stages in between (scan, scatter, sort) leave the
     // HBM nearly idle -- the colour kernel (the largest single stream of the forward, 192 B per visible Gaussian)
     // runs beside them on a side stream; the blend joins it.
-    const int sh_mode = shs != nullptr ? g_async_sh.load() : 0;   // 0 inside preprocess | side stream forked after: 1 preprocess, 2 scan, 3 scatter
+    const int sh_mode = (shs != nullptr && !rw.shell_logits) ? g_async_sh.load() : 0;   // 0 inside preprocess | side stream forked after: 1 preprocess, 2 scan, 3 scatter
     const bool defer_sh = sh_mode != 0 && g_sh_side.ensure();
     bool sh_forked = false;
     // an error return between the fork and the join must not leave the side kernel running on the caller's inputs
@@ -488,15 +499,22 @@ int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc
 
 int frg_forward_ex(const frg_forward_args* a)
 {
-    if (!a || a->struct_size != sizeof(frg_forward_args))
-        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_forward_args));
+    // two generations of the struct: up to keep_mask (version 1 callers), or with the raw-parameter fields
+    const size_t v1 = offsetof(frg_forward_args, raw_opacities);
+    if (!a || (a->struct_size != sizeof(frg_forward_args) && a->struct_size != v1))
+        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu (or %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_forward_args), v1);
     if (a->instance_capacity < 0) return fail(FRG_EINVAL, "instance_capacity < 0");
+    frg::RawInputs rw;
+    if (a->struct_size == sizeof(frg_forward_args)) {
+        rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
+        rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
+    }
     return forward_impl(a->geometry_alloc, a->binning_alloc, a->image_alloc, a->user, a->P, a->D, a->M, a->background,
                         a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales,
                         a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->cam_pos,
                         a->tan_fovx, a->tan_fovy, a->prefiltered, a->out_color, a->radii,
-                        a->instance_capacity > 0 ? 0 : a->debug, a->hip_stream, a->instance_capacity, a->keep_mask);
+                        a->instance_capacity > 0 ? 0 : a->debug, a->hip_stream, a->instance_capacity, a->keep_mask, &rw);
 }
 
 int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rendered)
@@ -518,7 +536,9 @@ int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rende
     return FRG_OK;
 }
 
-int frg_backward(int P, int D, int M, int R, const float* background, int width, int height,
+}  // extern "C"
+
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* viewmatrix, const float* projmatrix, const float* campos,
@@ -526,17 +546,21 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
                  char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                 char* workspace, size_t workspace_bytes, int debug, void* hip_stream)
+                 char* workspace, size_t workspace_bytes, int debug, void* hip_stream,
+                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
     if (P == 0) return FRG_OK;
-    if (!means3D || !geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background ||
-        !viewmatrix || !projmatrix || !campos)
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !viewmatrix || !projmatrix || !campos)
         return fail(FRG_EINVAL, "null required pointer");
+    if ((means3D == nullptr) == (rw.shell_logits == nullptr)) return fail(FRG_EINVAL, "provide exactly one of means3D / shell_logits");
+    if (rw.shell_logits && (!rw.shell_verts || !rw.shell_cells || !dL_dshell_logits))
+        return fail(FRG_EINVAL, "shell_logits needs shell_cell_verts, shell_cells and dL_dshell_logits");
     if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
         return fail(FRG_EINVAL, "null gradient output");
-    if ((scales && (!dL_dscale || !dL_drot || !rotations)))
+    if ((rw.raw_scale == nullptr) != (rw.raw_rot == nullptr)) return fail(FRG_EINVAL, "raw_scales and raw_rotations come together");
+    if (((scales && (!dL_dscale || !dL_drot || !rotations))) || (rw.raw_scale && (!dL_dscale || !dL_drot)))
         return fail(FRG_EINVAL, "null gradient output for a provided input");
     if (workspace_bytes < frg_backward_workspace_bytes(P, R) || !workspace)
         return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_backward_workspace_bytes(P, R));
@@ -563,9 +587,46 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
     }
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
+    in.raw = rw;
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
+    out.dL_dshell_logits = dL_dshell_logits;
+    out.dL_dshell_verts = dL_dshell_verts;
     { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), stream), "preprocess_bwd"); }
     return FRG_OK;
+}
+
+extern "C" {
+
+int frg_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 char* workspace, size_t workspace_bytes, int debug, void* hip_stream)
+{
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                         dL_dscale, dL_drot, workspace, workspace_bytes, debug, hip_stream, frg::RawInputs{}, nullptr, nullptr);
+}
+
+int frg_backward_ex(const frg_backward_args* a)
+{
+    if (!a || a->struct_size != sizeof(frg_backward_args))
+        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_backward_args));
+    frg::RawInputs rw;
+    rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
+    rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
+    return backward_impl(a->P, a->D, a->M, a->R, a->background, a->width, a->height, a->means3D, a->shs, a->colors_precomp,
+                         a->scales, a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos,
+                         a->tan_fovx, a->tan_fovy, a->radii, a->geom_buffer, a->binning_buffer, a->image_buffer, a->dL_dpix,
+                         a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh,
+                         a->dL_dscale, a->dL_drot, a->workspace, a->workspace_bytes, a->debug, a->hip_stream, rw,
+                         a->dL_dshell_logits, a->dL_dshell_cell_verts);
 }
 
 int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,

@@ -2,6 +2,7 @@
 // with the floating-point contraction mode its arithmetic contract needs).
 #pragma once
 #include "frg_common.h"
+#include "raw_params.h"
 
 namespace frg {
 
@@ -9,6 +10,7 @@ struct FwdInputs {
     const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
     const unsigned char* keep_mask = nullptr;   // optional per-Gaussian skip flag (0 = not in this view)
+    RawInputs raw;                              // optional: the model's raw parameters instead of activated tensors
 };
 
 // defer_sh: the SH colours are left to launch_sh_color (any stream ordered after this launch, before the blend)
@@ -41,6 +43,10 @@ hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+    // raw-parameter mode (FwdInputs::raw): dL_dopacity / dL_dscale / dL_drot then receive the gradients w.r.t. the RAW
+    // parameters; with shell-bound centres dL_dshell_logits [P,6] is written and, when non-NULL, dL_dshell_verts
+    // [F,6,3] is ACCUMULATED into (caller zeroes it): the learnable shell of learn_shell = True
+    float *dL_dshell_logits = nullptr, *dL_dshell_verts = nullptr;
 };
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, hipStream_t s);

@@ -69,14 +69,14 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
                const float* __restrict__ means3D, const float* __restrict__ scales,
                const float* __restrict__ rotations, const float* __restrict__ opacities,
                const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-               const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask,
+               const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask, const RawInputs& raw,
                float4* __restrict__ xydr, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_clamped,
                Counters* __restrict__ counters, int prefiltered, int& radius_i, int& x0, int& y0, int& x1, int& y1,
                float3& dir)
 {
     radius_i = 0;
     if (keep_mask && !keep_mask[idx]) return 0u;   // occlusion-culled by the caller: not part of this view
-    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 p = param_mean(means3D, raw, idx);
     const float4 p_hom = xform44(p, vmx.proj);
     const float3 p_view = xform43(p, vmx.view);
     const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -90,8 +90,8 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
 #pragma unroll
         for (int i = 0; i < 6; i++) cov[i] = cov3D_precomp[6 * idx + i];
     } else {
-        const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-        const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+        const float3 s = param_scale(scales, raw, idx);
+        const float4 q = param_rot(rotations, raw, idx);
         cov3d_from_scale_rot(s, vp.scale_modifier, q, cov);
     }
     const Ewa e = ewa_setup(p, vp.focal_x, vp.focal_y, vp.tan_fovx, vp.tan_fovy, vmx.view);
@@ -111,7 +111,7 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
     if (touched == 0) return 0u;
     radius_i = f2i(my_radius);
     xydr[idx] = make_float4(px, py, p_view.z, my_radius);
-    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, param_opacity(opacities, raw, idx));
     if (!colors_precomp) {  // unit view direction for the SH colour (forward.cu:25-27)
         float dx = p.x - vmx.campos[0], dy = p.y - vmx.campos[1], dz = p.z - vmx.campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -193,7 +193,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
-                      const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask,
+                      const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask, RawInputs raw,
                       int* __restrict__ radii, float4* __restrict__ xydr, float4* __restrict__ conic_opacity,
                       float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched,
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
@@ -224,7 +224,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         if (idx < P) {
             int radius_i, x0, y0, x1, y1;
             touched = preprocess_one(idx, vp, vmx, means3D, scales, rotations, opacities, shs, cov3D_precomp,
-                                     colors_precomp, keep_mask, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
+                                     colors_precomp, keep_mask, raw, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
                                      radius_i, x0, y0, x1, y1, dir);
             radii[idx] = radius_i;
             tiles_touched[idx] = touched;
@@ -649,7 +649,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
-                       in.cov3D_precomp, in.colors_precomp, in.keep_mask, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
+                       in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
     return hipGetLastError();
 }

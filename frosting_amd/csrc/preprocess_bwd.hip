@@ -50,7 +50,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const Counters* __restrict__ counters, const float* __restrict__ slots,
                       float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
-                      float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate)
+                      float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
+                      RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,15 +213,15 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float3 mean = make_float3(0.f, 0.f, 0.f);
     if (visible) {
-        mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        mean = param_mean(means3D, raw, idx);
         // ---- 2. computeCov2DCUDA (backward.cu:144-274) ----
         float cov[6];
         if (cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) cov[i] = cov3D_precomp[6 * idx + i];
         } else {
-            const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+            const float3 sc = param_scale(scales, raw, idx);
+            const float4 q = param_rot(rotations, raw, idx);
             cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov);  // recomputed, bit-identical to forward
         }
         const float dLc0 = part[5], dLc1 = part[6], dLc3 = part[7];
@@ -283,7 +284,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     if (valid) {
         dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
         if (dL_dconic) *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
-        dL_dopacity[idx] = part[8];
+        // raw mode: d sigmoid = o (1 - o)
+        dL_dopacity[idx] = (raw.raw_opacity && visible) ? part[8] * ((1.0f - conic_opacity[idx].w) * conic_opacity[idx].w) : part[8];
         // with shs given and dL_dsh == nullptr the caller wants the factor of the SH gradient instead
         // (the clamp-masked colour gradient, stored below): see frg_backward in the header
         if (!(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
@@ -429,13 +431,43 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
         for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
     }
+    // shell-bound centres (frosting_model.py:707-724): mean = sum_k w_k v_k, w = softmax(logits).
+    //   dL/dlogit_k = w_k (g_k - sum_j w_j g_j), g_k = v_k . dL/dmean          (softmax Jacobian)
+    //   dL/dv_k    += w_k dL/dmean                                              (learnable shell, learn_shell = True)
+    if (raw.shell_logits && valid) {
+        float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (visible) {
+            float w[6], gk[6];
+            raw_softmax6(raw.shell_logits + 6 * (size_t)idx, w);
+            const size_t cell = (size_t)raw.shell_cells[idx];
+            const float* v = raw.shell_verts + 18 * cell;
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                gk[k] = v[3 * k] * dmean[0] + v[3 * k + 1] * dmean[1] + v[3 * k + 2] * dmean[2];
+                dot += w[k] * gk[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) gl[k] = w[k] * (gk[k] - dot);
+            if (dL_dshell_verts) {
+                // several Gaussians share a cell: float atomics (the one place of this path whose summation order is
+                // not fixed; the reference's autograd index_add has the same property)
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) atomicAdd(dL_dshell_verts + 18 * cell + 3 * k + c, w[k] * dmean[c]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dshell_logits[6 * (size_t)idx + k] = gl[k];
+    }
 
     // ---- 5. cov3D -> scale, quaternion (backward.cu:278-341) ----
-    if (scales && valid) {
+    if ((scales || raw.raw_scale) && valid) {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
         if (visible) {
-            const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-            const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * idx);
+            const float3 sc = param_scale(scales, raw, idx);
+            const float4 q = param_rot(rotations, raw, idx);
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             const Rot3 R = quat_to_rot(q);
             const float s[3] = {vp.scale_modifier * sc.x, vp.scale_modifier * sc.y, vp.scale_modifier * sc.z};
@@ -464,6 +496,19 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             dq[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
             dq[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
         }
+        if (visible && raw.raw_scale) {          // d exp = exp
+            const float3 sc = param_scale(scales, raw, idx);
+            ds[0] *= sc.x; ds[1] *= sc.y; ds[2] *= sc.z;
+        }
+        if (visible && raw.raw_rot) {            // y = x / max(|x|, eps): dx = (g - y (y . g)) / max(|x|, eps)
+            const float4 x = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
+            const float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+            const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+            const float4 y = make_float4(x.x * inv, x.y * inv, x.z * inv, x.w * inv);
+            const float d = nrm > 1e-12f ? (y.x * dq[0] + y.y * dq[1] + y.z * dq[2] + y.w * dq[3]) : 0.0f;
+            dq[0] = (dq[0] - y.x * d) * inv; dq[1] = (dq[1] - y.y * d) * inv;
+            dq[2] = (dq[2] - y.z * d) * inv; dq[3] = (dq[3] - y.w * d) * inv;
+        }
         dL_dscale[3 * idx] = ds[0]; dL_dscale[3 * idx + 1] = ds[1]; dL_dscale[3 * idx + 2] = ds[2];
         *reinterpret_cast<float4*>(dL_drot + 4 * idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
@@ -480,7 +525,8 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
     hipLaunchKernelGGL((preprocess_bwd_kernel<S16>), grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,              \
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
-                       o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate)
+                       o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts)
     if (sh16) FRG_PBW(true); else FRG_PBW(false);
 #undef FRG_PBW
     return hipGetLastError();

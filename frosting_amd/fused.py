@@ -1,0 +1,119 @@
+"""Rasterization straight from the model's RAW parameters.
+
+Every iteration the reference turns its optimizer's parameters into rasterizer inputs with eager torch ops --
+``sigmoid(_opacities)``, ``exp(_scales)``, ``F.normalize(_quaternions)`` and, in Frosting,
+``(softmax(_bary_coords)[..., None] * shell_cells_verts[_point_cell_indices].reshape(-1, 6, 3)).sum(-2)`` for the
+shell-bound centres (frosting_scene/frosting_model.py:707-798, 1498-1520; gaussian_splatting/scene/gaussian_model.py:96-115)
+-- and autograd replays the chain backwards.  ``rasterize_raw`` hands the raw tensors to the rasterizer instead:
+the activations run inside the per-Gaussian kernels (csrc/raw_params.h), no activated tensor is ever written,
+and the backward returns gradients with respect to the raw parameters, the barycentric logits and -- when the
+cell vertices require grad (``learn_shell = True``) -- the shell itself.  GPU only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .parallel import _Arena
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class _RasterizeRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, settings, shs, raw_opacity, raw_scale, raw_rot, means3D, shell_logits, shell_cell_verts, shell_cells,
+                keep_mask):
+        L = _lib.lib()
+        s = settings
+        shelled = shell_logits is not None
+        ref = shell_logits if shelled else means3D
+        dev = ref.device
+        if dev.type != "cuda":
+            raise RuntimeError("frosting_amd.fused: parameters must live on a ROCm device (no CPU path)")
+        P, H, W = int(ref.shape[0]), int(s.image_height), int(s.image_width)
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        t = dict(shs=f32(shs), ro=f32(raw_opacity).reshape(-1), rs=f32(raw_scale), rr=f32(raw_rot), means=f32(means3D),
+                 lg=f32(shell_logits), cv=None if shell_cell_verts is None else f32(shell_cell_verts).reshape(-1, 6, 3),
+                 ci=None if shell_cells is None else shell_cells.to(torch.int64).contiguous(),
+                 bg=f32(s.bg), view=f32(s.viewmatrix), proj=f32(s.projmatrix), campos=f32(s.campos),
+                 mask=None if keep_mask is None else keep_mask.contiguous())
+        with torch.cuda.device(dev):
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            geom, binning, img = _Arena(dev, 1.0), _Arena(dev, 1.0), _Arena(dev, 1.0)
+            a = _lib.ForwardArgs(
+                struct_size=C.sizeof(_lib.ForwardArgs), geometry_alloc=geom.cb, binning_alloc=binning.cb, image_alloc=img.cb,
+                user=None, P=P, D=int(s.sh_degree), M=int(t["shs"].shape[1]), background=_p(t["bg"]), width=W, height=H,
+                means3D=_p(t["means"]), shs=_p(t["shs"]), colors_precomp=None, opacities=None, scales=None,
+                scale_modifier=float(s.scale_modifier), rotations=None, cov3D_precomp=None, viewmatrix=_p(t["view"]),
+                projmatrix=_p(t["proj"]), cam_pos=_p(t["campos"]), tan_fovx=float(s.tanfovx), tan_fovy=float(s.tanfovy),
+                prefiltered=int(bool(s.prefiltered)), out_color=color.data_ptr(), radii=radii.data_ptr(), debug=int(bool(s.debug)),
+                hip_stream=torch.cuda.current_stream(dev).cuda_stream, instance_capacity=0, keep_mask=_p(t["mask"]),
+                raw_opacities=_p(t["ro"]), raw_scales=_p(t["rs"]), raw_rotations=_p(t["rr"]), shell_logits=_p(t["lg"]),
+                shell_cell_verts=_p(t["cv"]), shell_cells=_p(t["ci"]))
+            R = L.frg_forward_ex(C.byref(a))
+        if R < 0:
+            raise RuntimeError(f"frg_forward_ex failed ({R}): {_lib.last_error()}")
+        ctx.t, ctx.settings, ctx.R, ctx.bufs, ctx.radii = t, s, R, (geom, binning, img), radii
+        ctx.learn_shell = shelled and shell_cell_verts is not None and shell_cell_verts.requires_grad
+        ctx.cv_shape = None if shell_cell_verts is None else tuple(shell_cell_verts.shape)
+        ctx.ro_shape = tuple(raw_opacity.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii):
+        L = _lib.lib()
+        t, s, R = ctx.t, ctx.settings, ctx.R
+        geom, binning, img = ctx.bufs
+        dev = g_color.device
+        shelled = t["lg"] is not None
+        P = int((t["lg"] if shelled else t["means"]).shape[0])
+        H, W = int(s.image_height), int(s.image_width)
+        M = int(t["shs"].shape[1])
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            g = dict(m2=e(P, 3), op=e(P), col=e(P, 3), m3=e(P, 3), cov=e(P, 6), sh=e(P, M, 3), sc=e(P, 3), rot=e(P, 4),
+                     lg=e(P, 6) if shelled else None,
+                     cv=torch.zeros_like(t["cv"]) if ctx.learn_shell else None)
+            out = g
+            if P:
+                ws = int(L.frg_backward_workspace_bytes(P, R))
+                work = torch.empty(ws, dtype=torch.uint8, device=dev)
+                gp = g_color.detach().to(torch.float32).contiguous()
+                a = _lib.BackwardArgs(
+                    struct_size=C.sizeof(_lib.BackwardArgs), P=P, D=int(s.sh_degree), M=M, R=R, background=_p(t["bg"]), width=W,
+                    height=H, means3D=_p(t["means"]), shs=_p(t["shs"]), colors_precomp=None, scales=None,
+                    scale_modifier=float(s.scale_modifier), rotations=None, cov3D_precomp=None, viewmatrix=_p(t["view"]),
+                    projmatrix=_p(t["proj"]), campos=_p(t["campos"]), tan_fovx=float(s.tanfovx), tan_fovy=float(s.tanfovy),
+                    radii=ctx.radii.data_ptr(), geom_buffer=geom.buf.data_ptr(), binning_buffer=binning.buf.data_ptr(),
+                    image_buffer=img.buf.data_ptr(), dL_dpix=gp.data_ptr(), dL_dmean2D=_p(g["m2"]), dL_dconic=None,
+                    dL_dopacity=_p(g["op"]), dL_dcolor=_p(g["col"]), dL_dmean3D=_p(g["m3"]), dL_dcov3D=_p(g["cov"]),
+                    dL_dsh=_p(g["sh"]), dL_dscale=_p(g["sc"]), dL_drot=_p(g["rot"]), workspace=work.data_ptr(), workspace_bytes=ws,
+                    debug=int(bool(s.debug)), hip_stream=torch.cuda.current_stream(dev).cuda_stream,
+                    raw_opacities=_p(t["ro"]), raw_scales=_p(t["rs"]), raw_rotations=_p(t["rr"]), shell_logits=_p(t["lg"]),
+                    shell_cell_verts=_p(t["cv"]), shell_cells=_p(t["ci"]), dL_dshell_logits=_p(g["lg"]),
+                    dL_dshell_cell_verts=_p(g["cv"]))
+                rc = L.frg_backward_ex(C.byref(a))
+                if rc < 0:
+                    raise RuntimeError(f"frg_backward_ex failed ({rc}): {_lib.last_error()}")
+                work.record_stream(torch.cuda.current_stream(dev))
+        g_cv = None if out["cv"] is None else out["cv"].reshape(ctx.cv_shape)
+        # settings, shs, raw_opacity, raw_scale, raw_rot, means3D, shell_logits, shell_cell_verts, shell_cells, keep_mask
+        return (None, out["sh"], out["op"].reshape(ctx.ro_shape), out["sc"], out["rot"],
+                None if shelled else out["m3"], out["lg"], g_cv, None, None)
+
+
+def rasterize_raw(settings, shs, raw_opacity, raw_scale, raw_rot, means3D=None, shell_logits=None, shell_cell_verts=None,
+                  shell_cells=None, keep_mask=None):
+    """-> (image [3,H,W], radii [P]).  settings: GaussianRasterizationSettings.  Exactly one of ``means3D`` [P,3]
+    and (``shell_logits`` [P,6], ``shell_cell_verts`` [F,2,3,3] or [F,6,3], ``shell_cells`` [P] int64).
+    raw_opacity [P] or [P,1]; raw_scale [P,3]; raw_rot [P,4]; shs [P,K,3]."""
+    if (means3D is None) == (shell_logits is None):
+        raise Exception("Please provide exactly one of either means3D or the shell parameterisation!")
+    return _RasterizeRaw.apply(settings, shs, raw_opacity, raw_scale, raw_rot, means3D, shell_logits, shell_cell_verts,
+                               shell_cells, keep_mask)

@@ -122,6 +122,21 @@ typedef struct frg_forward_args {
     void* hip_stream;
     int instance_capacity;
     const unsigned char* keep_mask;
+    /* ---- raw-parameter mode (optional; struct_size tells whether the caller knows these fields) ----------------
+     * The model's RAW parameters instead of activated tensors: the activations the reference applies with eager
+     * torch kernels every iteration run inside the per-Gaussian kernels and no activated tensor exists in memory.
+     *   raw_opacities [P]   opacity  = sigmoid(raw)        (frosting_model.py:726-727, gaussian_model.py:104-106);
+     *                       pass INSTEAD of opacities (which must then be NULL)
+     *   raw_scales [P,3]    scale    = exp(raw)            (frosting_model.py:763, gaussian_model.py:96-98)
+     *   raw_rotations [P,4] rotation = raw / max(|raw|, 1e-12)   (frosting_model.py:797-798); pass both INSTEAD of
+     *                       scales / rotations
+     *   shell_logits [P,6], shell_cell_verts [F,6,3], shell_cells [P] (int64): Frosting's shell-bound centres,
+     *                       mean = softmax(logits) . the six vertices of the Gaussian's prismatic cell
+     *                       (frosting_model.py:707-724); pass INSTEAD of means3D
+     * Each group is optional on its own.  frg_backward_ex takes the same pointers. */
+    const float *raw_opacities, *raw_scales, *raw_rotations;
+    const float *shell_logits, *shell_cell_verts;
+    const long long* shell_cells;
 } frg_forward_args;
 int frg_forward_ex(const frg_forward_args* args);
 
@@ -151,6 +166,37 @@ int frg_backward(int P, int D, int M, int R,
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  char* workspace, size_t workspace_bytes, int debug, void* hip_stream);
+
+/* frg_backward with every option, as a struct (set struct_size = sizeof(frg_backward_args)).  Fields up to
+ * hip_stream mean what the frg_backward parameters of the same name mean.  In raw-parameter mode (the raw_* /
+ * shell_* inputs of the forward, same pointers here) dL_dopacity, dL_dscale and dL_drot receive the gradients
+ * with respect to the RAW parameters (sigmoid', exp', normalisation Jacobian applied); with shell-bound centres
+ * dL_dshell_logits [P,6] is written (softmax Jacobian applied) and, when dL_dshell_cell_verts [F,6,3] is
+ * non-NULL, the gradient of the cell vertices -- the learnable shell of learn_shell = True -- is ACCUMULATED
+ * into it with float atomics (several Gaussians share a cell; the caller zeroes it).  dL_dmean3D is still written. */
+typedef struct frg_backward_args {
+    size_t struct_size;
+    int P, D, M, R;
+    const float* background;
+    int width, height;
+    const float *means3D, *shs, *colors_precomp, *scales;
+    float scale_modifier;
+    const float *rotations, *cov3D_precomp, *viewmatrix, *projmatrix, *campos;
+    float tan_fovx, tan_fovy;
+    const int* radii;
+    char *geom_buffer, *binning_buffer, *image_buffer;
+    const float* dL_dpix;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+    char* workspace;
+    size_t workspace_bytes;
+    int debug;
+    void* hip_stream;
+    const float *raw_opacities, *raw_scales, *raw_rotations;
+    const float *shell_logits, *shell_cell_verts;
+    const long long* shell_cells;
+    float *dL_dshell_logits, *dL_dshell_cell_verts;
+} frg_backward_args;
+int frg_backward_ex(const frg_backward_args* args);
 
 /* Runtime options.  "exact_blend": 1 = blend kernels use the reference's IEEE
  * operation order without FMA contraction and the accurate expf (bit-identical
