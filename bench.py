@@ -382,7 +382,7 @@ def main():
                 for t in leaves + [means2D]:
                     t.grad = None                # optimizer.zero_grad(set_to_none=True), as training loops do
                 img.backward(gpix)
-        for _ in range(5):
+        for _ in range(25):           # torch's caching allocator needs a few iterations to settle on its block sizes
             api_step()
         dt_a, ms_a = timed(args.steps, fn=api_step, with_drain=False)
         api_path = {"ms_per_step": 1e3 * dt_a / args.steps, "median_ms_per_step": statistics.median(ms_a),

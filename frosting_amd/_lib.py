@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libfrosting_rasterizer.so")
+# FROSTING_LIB: another build of the same library (A/B timing of kernel variants in one GPU session; tools/ab.py)
+LIB_PATH = os.environ.get("FROSTING_LIB") or os.path.join(_PKG, "lib", "libfrosting_rasterizer.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

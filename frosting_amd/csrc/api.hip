@@ -291,6 +291,7 @@ void frg_geometry_layout(int P, long long* out)
     frg::GeomState s = frg::GeomState::carve(nullptr, P);
     out[0] = (long long)(size_t)s.xydr; out[1] = (long long)(size_t)s.conic_opacity; out[2] = (long long)(size_t)s.rgb_clamped;
     out[3] = (long long)(size_t)s.tiles_touched; out[4] = (long long)(size_t)s.point_offsets;
+    out[5] = (long long)(16 * FRG_REC);   // byte stride between consecutive Gaussians' float4 of out[0..2]
 }
 void frg_image_layout(int width, int height, long long* out)
 {

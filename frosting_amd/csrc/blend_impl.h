@@ -130,9 +130,9 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
         if (lane < cnt) {
             const uint32_t id = point_list[rg.x + base + lane];
-            a = xydr[id];
-            co = conic_opacity[id];
-            col = rgb_clamped[id];
+            a = xydr[FRG_REC * id];
+            co = conic_opacity[FRG_REC * id];
+            col = rgb_clamped[FRG_REC * id];
             hit = quadrant_hit(a.x, a.y, co, qx0, qy0);
         }
         const uint64_t keep = wave_ballot(hit);
@@ -316,7 +316,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     }
     if (lane == 0) {
         const uint32_t id = point_list[rg.x + maxc - 1];
-        cutoff[tile] = make_uint2(__float_as_uint(xydr[id].z), id);
+        cutoff[tile] = make_uint2(__float_as_uint(xydr[FRG_REC * id].z), id);
     }
 
     // walk the processed prefix [0, maxc) back to front, 64 instances at a time
@@ -326,9 +326,9 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
         if (lane < cnt) {
             const uint32_t id = point_list[rg.x + hi - lane];
-            a = xydr[id];
-            co = conic_opacity[id];
-            col = rgb_clamped[id];
+            a = xydr[FRG_REC * id];
+            co = conic_opacity[FRG_REC * id];
+            col = rgb_clamped[FRG_REC * id];
             const uint32_t mypos = (uint32_t)(hi - lane);
             m = quadrant_mask(a.x, a.y, co, tx, ty) &
                 ((mypos < qmax[0] ? 1u : 0u) | (mypos < qmax[1] ? 2u : 0u) | (mypos < qmax[2] ? 4u : 0u) | (mypos < qmax[3] ? 8u : 0u));

@@ -23,13 +23,22 @@ struct Dims {
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// ---- geometry chunk (per Gaussian, SoA of 16-byte records so the blend kernels
-// gather with one global_load_dwordx4 each) ---------------------------------
+// ---- geometry chunk ---------------------------------------------------------
+// One 48-byte RECORD per Gaussian = three float4, contiguous: the blend kernels gather all three per list entry,
+// and as three separate arrays those were three L2 requests to three cache lines per entry (the L2 request rate of
+// 16-byte gathers, not bandwidth, bounded the forward blend's staging); side by side, three records out of four sit
+// inside one 128-byte line and the second and third load hit what the first one brought in.  48 bytes rather than a
+// padded 64: the per-Gaussian streaming kernels write and read every byte of the array either way.
+// xydr / conic_opacity / rgb_clamped point at float4 0..2 of record 0: element i of each lives at [FRG_REC * i].
+#define FRG_REC 3
 struct GeomState {
     float4* xydr;            // pixel x, pixel y, view depth, radius (as float, exact integer)
     float4* conic_opacity;   // conic a, b, c, opacity          (forward.cu:253)
     float4* rgb_clamped;     // r, g, b, clamp flags in the bit pattern of .w
     uint32_t* tiles_touched;
+    // what the scatter needs of a visible Gaussian, compact (12 bytes, streamed): depth bits, tile rectangle
+    // x0 | y0 << 16, x1 | y1 << 16 -- the records above are laid out for the blend kernels' gathers
+    uint32_t* depth_rect;
     uint32_t* point_offsets; // inclusive scan of tiles_touched (rasterizer_impl.cu:277)
     uint32_t* block_sums;    // per-256-Gaussian block totals -> exclusive prefix
     int* internal_radii;     // used when the caller passes radii == NULL (rasterizer_impl.cu:228-231)
@@ -39,10 +48,11 @@ struct GeomState {
         GeomState s;
         size_t o = 0;
         size_t Pp = (size_t)(P > 0 ? P : 1);
-        s.xydr = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
-        s.conic_opacity = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
-        s.rgb_clamped = (float4*)(base + o); o = align_up(o + Pp * 16, 256);
+        s.xydr = (float4*)(base + o);
+        s.conic_opacity = s.xydr + 1; s.rgb_clamped = s.xydr + 2;
+        o = align_up(o + Pp * 16 * FRG_REC, 256);
         s.tiles_touched = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
+        s.depth_rect = (uint32_t*)(base + o); o = align_up(o + Pp * 12, 256);
         s.point_offsets = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
         s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);  // per chunk
         s.internal_radii = (int*)(base + o); o = align_up(o + Pp * 4, 256);

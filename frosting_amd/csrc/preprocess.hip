@@ -70,9 +70,9 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
                const float* __restrict__ rotations, const float* __restrict__ opacities,
                const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask, const RawInputs& raw,
-               float4* __restrict__ xydr, float4* __restrict__ conic_opacity, float4* __restrict__ rgb_clamped,
+               float4* rec /* this Gaussian's record: [0] xydr, [1] conic + opacity */,
                Counters* __restrict__ counters, int prefiltered, int& radius_i, int& x0, int& y0, int& x1, int& y1,
-               float3& dir)
+               float3& dir, float& depth)
 {
     radius_i = 0;
     if (keep_mask && !keep_mask[idx]) return 0u;   // occlusion-culled by the caller: not part of this view
@@ -110,8 +110,9 @@ preprocess_one(int idx, const ViewParams& vp, const ViewMats& vmx,
     const uint32_t touched = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
     if (touched == 0) return 0u;
     radius_i = f2i(my_radius);
-    xydr[idx] = make_float4(px, py, p_view.z, my_radius);
-    conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, param_opacity(opacities, raw, idx));
+    depth = p_view.z;
+    rec[0] = make_float4(px, py, p_view.z, my_radius);
+    rec[1] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, param_opacity(opacities, raw, idx));
     if (!colors_precomp) {  // unit view direction for the SH colour (forward.cu:25-27)
         float dx = p.x - vmx.campos[0], dy = p.y - vmx.campos[1], dz = p.z - vmx.campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -195,7 +196,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ colors_precomp, const unsigned char* __restrict__ keep_mask, RawInputs raw,
                       int* __restrict__ radii, float4* __restrict__ xydr, float4* __restrict__ conic_opacity,
-                      float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched,
+                      float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_rect,
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered)
 {
@@ -206,6 +207,9 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     __shared__ int4 emit_info[FRG_BIN_THREADS];
     __shared__ float2 emit_xy[TIGHT ? FRG_BIN_THREADS : 1];   // tight binning: centre and conic/opacity of the lane's Gaussian
     __shared__ float4 emit_co[TIGHT ? FRG_BIN_THREADS : 1];
+    // the chunk's 48-byte records are assembled in LDS (centre / conic first, colour after the SH sum) and leave as
+    // one contiguous, fully written block per wave: piecewise 16-byte stores at a 48-byte stride cost 10 % of the kernel
+    __shared__ float4 rec_lds[FRG_BIN_THREADS * FRG_REC];
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
@@ -221,21 +225,29 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         uint32_t touched = 0;
         int rx0 = 0, ry0 = 0, rw = 1;
         float3 dir = make_float3(0.f, 0.f, 1.f);
+        float4* rec = rec_lds + threadIdx.x * FRG_REC;
+        rec[0] = rec[1] = rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < P) {
             int radius_i, x0, y0, x1, y1;
+            float depth = 0.f;
             touched = preprocess_one(idx, vp, vmx, means3D, scales, rotations, opacities, shs, cov3D_precomp,
-                                     colors_precomp, keep_mask, raw, xydr, conic_opacity, rgb_clamped, counters, prefiltered,
-                                     radius_i, x0, y0, x1, y1, dir);
+                                     colors_precomp, keep_mask, raw, rec, counters, prefiltered,
+                                     radius_i, x0, y0, x1, y1, dir, depth);
             radii[idx] = radius_i;
             tiles_touched[idx] = touched;
             rx0 = x0; ry0 = y0; rw = x1 - x0;
+            if (touched) {
+                depth_rect[3 * idx] = __float_as_uint(depth);
+                depth_rect[3 * idx + 1] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+                depth_rect[3 * idx + 2] = (uint32_t)x1 | ((uint32_t)y1 << 16);
+            }
         }
         {   // per-tile instance counts
             const int wave = threadIdx.x >> 6;
             if (TIGHT && touched) {
-                const float4 g4 = xydr[idx];
+                const float4 g4 = rec[0];
                 emit_xy[threadIdx.x] = make_float2(g4.x, g4.y);
-                emit_co[threadIdx.x] = conic_opacity[idx];
+                emit_co[threadIdx.x] = rec[1];
             }
             wave_for_each_instance(touched, rx0, ry0, rw, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
                                    [&](int owner, int t, int tx, int ty, uint32_t) {
@@ -250,7 +262,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         // ---- colour ----
         if (colors_precomp) {
             if (touched)
-                rgb_clamped[idx] = make_float4(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2],
+                rec[2] = make_float4(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2],
                                                __uint_as_float(0u));
         } else if (SHMODE != SH_DEFER) {
             float w[16];
@@ -320,7 +332,17 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                     if (i < ncoef) sa.add(i, ch, w[i], sh[e]);
                 }
             }
-            if (touched) rgb_clamped[idx] = sa.finish();
+            if (touched) rec[2] = sa.finish();
+        }
+        {   // the wave's 64 records leave as 3 x 64 consecutive float4
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const size_t first = (size_t)(c * FRG_BIN_THREADS + wave * 64) * FRG_REC;
+            const size_t limit = (size_t)P * FRG_REC;
+            wave_sync_lds();
+#pragma unroll
+            for (int j = 0; j < FRG_REC; j++)
+                if (first + j * 64 + lane < limit) xydr[first + j * 64 + lane] = rec_lds[wave * 64 * FRG_REC + j * 64 + lane];
+            wave_sync_lds();
         }
         // chunk total: one atomic per wave into this workgroup's own (pre-zeroed) entry.  No
         // workgroup barrier in the chunk loop: the 16 waves drift apart, so one wave's SH
@@ -416,7 +438,7 @@ sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const fl
             if (i < ncoef) sa.add(i, ch, w[i], sh[e]);
         }
     }
-    if (touched) rgb_clamped[idx] = sa.finish();
+    if (touched) rgb_clamped[FRG_REC * idx] = sa.finish();
 }
 
 // Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
@@ -555,7 +577,7 @@ colbase_kernel(int T, int nrows, uint32_t* __restrict__ bin_matrix, const uint32
 // (rasterizer_impl.cu:98-108, :303-308).
 template <bool LDS_BINS, bool TIGHT>
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
-scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float4* __restrict__ xydr,
+scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ depth_rect, const float4* __restrict__ xydr,
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ chunk_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ bin_matrix,
                const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs,
@@ -588,10 +610,10 @@ scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii, const float
         int x0 = 0, y0 = 0, x1 = 1, y1 = 0;
         uint32_t dbits = 0;
         if (touched) {
-            const float4 g = xydr[idx];
-            tile_rect(g.x, g.y, radii[idx], gx, gy, x0, y0, x1, y1);
-            dbits = __float_as_uint(g.z);
-            if (TIGHT) { emit_xy[threadIdx.x] = make_float2(g.x, g.y); emit_co[threadIdx.x] = conic_opacity[idx]; }
+            dbits = depth_rect[3 * idx];
+            const uint32_t lo = depth_rect[3 * idx + 1], hi = depth_rect[3 * idx + 2];
+            x0 = (int)(lo & 0xFFFFu); y0 = (int)(lo >> 16); x1 = (int)(hi & 0xFFFFu); y1 = (int)(hi >> 16);
+            if (TIGHT) { const float4 g = xydr[FRG_REC * idx]; emit_xy[threadIdx.x] = make_float2(g.x, g.y); emit_co[threadIdx.x] = conic_opacity[FRG_REC * idx]; }
         }
         const int wave = threadIdx.x >> 6;
         const uint32_t idx0 = (uint32_t)(c * FRG_BIN_THREADS + wave * 64);
@@ -650,7 +672,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
     hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
-                       g.tiles_touched, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
+                       g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
     return hipGetLastError();
 }
 
@@ -702,7 +724,7 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
 #define FRG_SCATTER(L, TI, LDS)                                                                                          \
-    hipLaunchKernelGGL((scatter_kernel<L, TI>), dim3(nb), dim3(FRG_BIN_THREADS), LDS, s, P, vp.gx, vp.gy, radii, g.xydr,    \
+    hipLaunchKernelGGL((scatter_kernel<L, TI>), dim3(nb), dim3(FRG_BIN_THREADS), LDS, s, P, vp.gx, vp.gy, g.depth_rect, g.xydr,    \
                        g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs,  \
                        img.counters, g.conic_opacity)
     if (img.lds_bins) {

@@ -73,8 +73,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     uint32_t clamp_bits = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (visible) {
-        g = xydr[idx];
-        clamp_bits = __float_as_uint(rgb_clamped[idx].w);
+        g = xydr[FRG_REC * idx];
+        clamp_bits = __float_as_uint(rgb_clamped[FRG_REC * idx].w);
         tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
     }
     // SH rows (192 B per Gaussian, the largest stream of this kernel): the first sub-batch is requested NOW, so
@@ -108,7 +108,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     float4* own_co = shbuf;                                         // [64]
     float2* own_xy = reinterpret_cast<float2*>(shbuf + 64);         // [64]
     if (TIGHT) {
-        own_co[lane] = visible ? conic_opacity[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        own_co[lane] = visible ? conic_opacity[FRG_REC * idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         own_xy[lane] = make_float2(g.x, g.y);
     }
 #pragma unroll
@@ -200,7 +200,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // coefficients, so it is applied here, once per Gaussian after the sum over its tiles, instead of once per
     // (tile, Gaussian) instance in the blend kernel.
     if (visible) {
-        const float4 kc = conic_opacity[idx];
+        const float4 kc = conic_opacity[FRG_REC * idx];
         const float o = kc.w, m3 = part[3], m4 = part[4];
         part[3] = -o * (kc.x * m3 + kc.y * m4) * (0.5f * vp.W);
         part[4] = -o * (kc.z * m4 + kc.y * m3) * (0.5f * vp.H);
@@ -285,7 +285,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
         if (dL_dconic) *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
         // raw mode: d sigmoid = o (1 - o)
-        dL_dopacity[idx] = (raw.raw_opacity && visible) ? part[8] * ((1.0f - conic_opacity[idx].w) * conic_opacity[idx].w) : part[8];
+        dL_dopacity[idx] = (raw.raw_opacity && visible) ? part[8] * ((1.0f - conic_opacity[FRG_REC * idx].w) * conic_opacity[FRG_REC * idx].w) : part[8];
         // with shs given and dL_dsh == nullptr the caller wants the factor of the SH gradient instead
         // (the clamp-masked colour gradient, stored below): see frg_backward in the header
         if (!(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }

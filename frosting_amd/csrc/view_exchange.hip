@@ -40,7 +40,7 @@ sh_color_grad_kernel(int P, const float4* __restrict__ rgb_clamped, const int* _
     if (idx >= P) return;
     float r = 0.f, g = 0.f, b = 0.f;
     if (radii[idx] > 0) {
-        const uint32_t bits = __float_as_uint(rgb_clamped[idx].w);
+        const uint32_t bits = __float_as_uint(rgb_clamped[FRG_REC * idx].w);
         r = dL_dcolor[3 * idx] * ((bits & 1u) ? 0.f : 1.f);
         g = dL_dcolor[3 * idx + 1] * ((bits & 2u) ? 0.f : 1.f);
         b = dL_dcolor[3 * idx + 2] * ((bits & 4u) ? 0.f : 1.f);

@@ -22,9 +22,11 @@ class State:
         T = ((W + 15) // 16) * ((H + 15) // 16)
         N = W * H
         L.frg_geometry_layout(P, off)
-        self.xydr = _view(geom, off[0], torch.float32, 4 * P).view(P, 4)
-        self.conic_opacity = _view(geom, off[1], torch.float32, 4 * P).view(P, 4)
-        rgbc = _view(geom, off[2], torch.float32, 4 * P).view(P, 4)
+        stride = int(off[5]) // 4                      # floats between consecutive Gaussians (64-byte records)
+        rec = _view(geom, off[0], torch.float32, stride * P).view(P, stride)
+        self.xydr = rec[:, 0:4]
+        self.conic_opacity = rec[:, 4:8]
+        rgbc = rec[:, 8:12]
         self.rgb = rgbc[:, :3]
         self.clamp_bits = rgbc[:, 3].contiguous().view(torch.int32)
         self.tiles_touched = _view(geom, off[3], torch.int32, P)

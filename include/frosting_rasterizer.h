@@ -234,6 +234,8 @@ size_t frg_binning_bytes(int R, int max_tile_count);
  * geometry: out[0]=xy_depth_radius (float4[P]: pixel x, pixel y, view depth, radius)
  *           out[1]=conic_opacity (float4[P]) out[2]=rgb_clamped (float4[P]: r,g,b, clamp bits)
  *           out[3]=tiles_touched (u32[P])    out[4]=point_offsets (u32[P], inclusive scan)
+ *           out[5]=byte stride between consecutive Gaussians' float4 of out[0..2] (they are interleaved in one
+ *           48-byte record per Gaussian); `out` needs room for 6 values
  * image:    out[0]=final_T (f32[H*W]) out[1]=n_contrib (u32[H*W]) out[2]=ranges (uint2[tiles])
  *           out[3]=tile_count (u32[tiles])
  * binning:  out[0]=point_list (u32[R], sorted by (tile, depth, index))
