@@ -319,16 +319,28 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         cutoff[tile] = make_uint2(__float_as_uint(xydr[FRG_REC * id].z), id);
     }
 
-    // walk the processed prefix [0, maxc) back to front, 64 instances at a time
+    // walk the processed prefix [0, maxc) back to front, 64 instances at a time.  The walk is known in advance (no
+    // early termination), so the records of round r + 1 -- id, three 16-byte gathers, the instance offset: a ~4 us
+    // dependent chain -- are requested before round r is processed.  The loads are unconditional (clamped
+    // positions): a conditional load into a loop-carried register makes the compiler copy it, and wait, at once.
+    uint32_t id_n = 0, off_n = 0;
+    float4 a_n, co_n, col_n;
+    auto fetch = [&](int hi) {
+        id_n = point_list[rg.x + max(hi - lane, 0)];
+        a_n = xydr[FRG_REC * id_n];
+        co_n = conic_opacity[FRG_REC * id_n];
+        col_n = rgb_clamped[FRG_REC * id_n];
+        off_n = point_offsets[max(id_n, 1u) - 1u];
+    };
+    fetch((int)maxc - 1);
     for (int hi = (int)maxc - 1; hi >= 0; hi -= 64) {
         const int cnt = min(64, hi + 1);
         uint32_t m = 0, my_slot = 0;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
+        const uint32_t id = id_n;
+        const float4 a = a_n, co = co_n, col = col_n;
+        const uint32_t off = id == 0 ? 0u : off_n;
+        if (hi >= 64) fetch(hi - 64);             // wave-uniform
         if (lane < cnt) {
-            const uint32_t id = point_list[rg.x + hi - lane];
-            a = xydr[FRG_REC * id];
-            co = conic_opacity[FRG_REC * id];
-            col = rgb_clamped[FRG_REC * id];
             const uint32_t mypos = (uint32_t)(hi - lane);
             m = quadrant_mask(a.x, a.y, co, tx, ty) &
                 ((mypos < qmax[0] ? 1u : 0u) | (mypos < qmax[1] ? 2u : 0u) | (mypos < qmax[2] ? 4u : 0u) | (mypos < qmax[3] ? 8u : 0u));
@@ -336,7 +348,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             // reference's duplicateWithKeys emission order (rasterizer_impl.cu:98-108)
             int x0, y0, x1, y1;
             tile_rect(a.x, a.y, (int)a.w, gx, gy, x0, y0, x1, y1);
-            const uint32_t off = id == 0 ? 0u : point_offsets[id - 1];
             my_slot = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
             if (m == 0) {  // provably no contribution in this tile: the slot is still owed a value
                 float* dst = slots + (size_t)my_slot * FRG_SLOT_FLOATS;
