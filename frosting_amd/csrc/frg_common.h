@@ -13,7 +13,7 @@
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
 #define FRG_BIN_SEGS 8           // row segments of the column scan
-#define FRG_BIN_MAX_LDS_TILES 20480  // T*4 bytes of LDS bins beside 53 KiB of SH staging and the scan scratch (160 KiB/CU)
+#define FRG_BIN_MAX_LDS_TILES 9216   // T*4 bytes of LDS bins beside 53 KiB of SH staging, 48 KiB of record assembly and the scan scratch (160 KiB/CU)
 
 namespace frg {
 

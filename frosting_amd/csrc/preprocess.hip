@@ -205,8 +205,6 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
-    __shared__ float2 emit_xy[TIGHT ? FRG_BIN_THREADS : 1];   // tight binning: centre and conic/opacity of the lane's Gaussian
-    __shared__ float4 emit_co[TIGHT ? FRG_BIN_THREADS : 1];
     // the chunk's 48-byte records are assembled in LDS (centre / conic first, colour after the SH sum) and leave as
     // one contiguous, fully written block per wave: piecewise 16-byte stores at a 48-byte stride cost 10 % of the kernel
     __shared__ float4 rec_lds[FRG_BIN_THREADS * FRG_REC];
@@ -244,16 +242,12 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
         {   // per-tile instance counts
             const int wave = threadIdx.x >> 6;
-            if (TIGHT && touched) {
-                const float4 g4 = rec[0];
-                emit_xy[threadIdx.x] = make_float2(g4.x, g4.y);
-                emit_co[threadIdx.x] = rec[1];
-            }
             wave_for_each_instance(touched, rx0, ry0, rw, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
                                    [&](int owner, int t, int tx, int ty, uint32_t) {
-                                       if (TIGHT) {
-                                           const float2 c2 = emit_xy[wave * 64 + owner];
-                                           if (!tile_hit(c2.x, c2.y, emit_co[wave * 64 + owner], tx, ty)) return;
+                                       if (TIGHT) {   // centre and conic of the owner: its record, still in LDS
+                                           const float4* orec = rec_lds + (wave * 64 + owner) * FRG_REC;
+                                           const float4 c2 = orec[0];
+                                           if (!tile_hit(c2.x, c2.y, orec[1], tx, ty)) return;
                                        }
                                        if (LDS_BINS) atomicAdd(&lds_bins[t], 1u);   // ds_add_u32
                                        else atomicAdd(&tile_count[t], 1u);

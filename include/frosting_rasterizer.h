@@ -205,7 +205,7 @@ int frg_backward_ex(const frg_backward_args* args);
  * tile counts and sort keys never depend on this switch.  "profile": see
  * frg_stage_times; "profile_stage": k in 0..6 restricts the events to stage k (each event
  * record costs a few microseconds of stream time), -1 (default) = every stage.  "global_bins": 1 forces the binning path used for images with
- * more than 20480 tiles (global atomics instead of LDS histograms; test hook).
+ * more than 9216 tiles (global atomics instead of LDS histograms; test hook).
  * "tight_binning": 1 = a (Gaussian, tile) instance is only put on the tile's list if the Gaussian can
  * reach alpha >= 1/255 somewhere in the tile (the closed-form bound the blend kernels use per 8x8
  * quadrant, taken over the 16x16 tile); the reference lists every tile of the 3-sigma square

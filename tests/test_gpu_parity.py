@@ -515,3 +515,18 @@ def test_deferred_forward_overflow_then_backward_before_finish(gpu_device):
     vpr.backward(gpix)
     assert vpr.finish() is True
     assert torch.equal(img2, img_b) and torch.equal(vpr.exchange.flat, flat_b)
+
+
+@pytest.mark.parametrize("tight", [0, 1])
+def test_full_size_image_every_binning_mode_fits_the_lds(gpu_device, tight):
+    """The LDS budget of the binning kernels depends on the number of tiles: run the full 1600x1056 grid (6600 tiles)
+    and the largest grid that still uses the LDS histograms, in both binning modes, against the C oracle."""
+    scene, _, bg = scenes.config_scene("c2", 0, P=20_000)
+    _lib.set_option("tight_binning", tight)
+    for (w, h) in [(1600, 1056), (1536, 1536)]:           # 6600 and 9216 tiles
+        cam = scenes.ring_camera(2, w, h, 1334.0, 1334.0)
+        out, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+        assert out[0] == o["num_rendered"]
+        np.testing.assert_array_equal(out[2].cpu().numpy(), o["radii"])
+        assert np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= L1_BAR
