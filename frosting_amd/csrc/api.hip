@@ -38,6 +38,10 @@ std::atomic<int> g_ablate{0};         // TIMING EXPERIMENTS ONLY: kernels skip p
 std::atomic<int> g_async_sh{0};       // SH colours on a side stream beside the binning stages (0: inside preprocess)
 std::atomic<int> g_bwd_batch{3};      // tuning: instances per reduction step of the backward blend (2 | 3)
 std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
+// TIMING EXPERIMENTS ONLY (results are those of the previous frame's lists / slots): bit 0 launches the forward blend
+// beside the sort, bit 1 the per-Gaussian backward beside the backward blend -- an upper bound on what overlapping
+// a VALU-bound with an LDS- or HBM-bound stage can give before any dependency-respecting pipeline is built
+std::atomic<int> g_probe{0};
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
 // recorded on the caller's stream between the kernels of one forward / backward;
@@ -187,6 +191,20 @@ struct ShSide {
 };
 thread_local ShSide g_sh_side;
 
+struct ProbeSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ensure()
+    {
+        if (stream) return true;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }
+};
+thread_local ProbeSide g_probe_side;
+
 #define FRG_HIP(call)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
@@ -237,6 +255,8 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
+    if (name && strcmp(name, "probe") == 0) return g_probe.exchange(value);
+    if (name && strcmp(name, "rows_grid") == 0) { const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old; }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -423,7 +443,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         char* bin_chunk = binning_alloc(user, frg_binning_bytes(capacity, FRG_SORT_LDS_CAP + 1));
         if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
         const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1);
-        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
+        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
         { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, 0, index_bits, b.point_list, stream), "sort"); }
         if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
@@ -451,10 +471,18 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
     const frg::BinningState b = frg::BinningState::carve(bin_chunk, R, max_tile);
 
+    const bool probe_fwd = (g_probe.load() & 1) && R > 0 && !exact_blend() && g_probe_side.ensure();
     if (R > 0) {
-        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter"); }
+        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
+        if (probe_fwd) {
+            FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
+            FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
+            FRG_HIP(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, g_probe_side.stream));
+            FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
+        }
         { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, max_tile, index_bits, b.point_list, stream), "sort"); }
+        if (probe_fwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return R; }
     } else {
         // point_offsets must still be defined for backward
         FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream), "scatter");
@@ -579,6 +607,18 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     float* slots = reinterpret_cast<float*>(workspace);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
+    frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
+    in.raw = rw;
+    frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
+    out.dL_dshell_logits = dL_dshell_logits;
+    out.dL_dshell_verts = dL_dshell_verts;
+    const bool probe_bwd = (g_probe.load() & 2) && g_probe_side.ensure();
+    if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
+        FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
+        FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), g_probe_side.stream));
+        FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
+    }
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact_blend())
@@ -586,12 +626,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         else
             FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
     }
-
-    frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
-    in.raw = rw;
-    frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
-    out.dL_dshell_logits = dL_dshell_logits;
-    out.dL_dshell_verts = dL_dshell_verts;
+    if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
     { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), stream), "preprocess_bwd"); }
     return FRG_OK;
 }

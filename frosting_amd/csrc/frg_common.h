@@ -13,7 +13,8 @@
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
 #define FRG_BIN_SEGS 8           // row segments of the column scan
-#define FRG_BIN_MAX_LDS_TILES 9216   // T*4 bytes of LDS bins beside 53 KiB of SH staging, 48 KiB of record assembly and the scan scratch (160 KiB/CU)
+#define FRG_BIN_MAX_LDS_TILES 10176  // LDS bins of the preprocess (tiles + record cells): 4 bytes each beside 53 KiB of SH staging, 48 KiB of record assembly and the scan scratch (160 KiB per CU)
+#define FRG_MAX_TILE_ROWS 1024       // cells (tile row x band of tile columns) of the scatter's record order; also the largest number of tile rows it handles
 
 namespace frg {
 
@@ -42,6 +43,12 @@ struct GeomState {
     uint32_t* point_offsets; // inclusive scan of tiles_touched (rasterizer_impl.cu:277)
     uint32_t* block_sums;    // per-256-Gaussian block totals -> exclusive prefix
     int* internal_radii;     // used when the caller passes radii == NULL (rasterizer_impl.cu:228-231)
+    // the visible Gaussians' scatter records {depth bits, index, x0 | y0 << 16, x1 | y1 << 16}, grouped by the cell
+    // (tile row, band of tile columns) of the rectangle's first tile (reorder_kernel): consecutive records touch the
+    // same few dozen tiles, so the scatter's 8-byte stores into a tile's segment land within microseconds of each
+    // other and leave the L2 as full lines.  In the caller's (arbitrary) order every 128-byte line of the pairs array was open for the whole
+    // kernel and went to HBM as 32-byte sectors: 0.49 GB written for 0.13 GB of pairs.
+    uint4* row_records;
     size_t bytes;
     __host__ static GeomState carve(char* base, int P)
     {
@@ -56,6 +63,7 @@ struct GeomState {
         s.point_offsets = (uint32_t*)(base + o); o = align_up(o + Pp * 4, 256);
         s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);  // per chunk
         s.internal_radii = (int*)(base + o); o = align_up(o + Pp * 4, 256);
+        s.row_records = (uint4*)(base + o); o = align_up(o + Pp * 16, 256);
         s.bytes = o;
         return s;
     }
@@ -72,7 +80,8 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
     // modes of the forward that filled this image chunk, stamped by scan_kernel: the backward follows
     // THESE, not the process-wide options at the time it is called
     uint32_t tight_binning;
-    uint32_t pad2[2];
+    uint32_t num_visible;    // Gaussians with at least one tile (records in GeomState::row_records)
+    uint32_t pad2[1];
 };
 __host__ __device__ inline int sort_class_of(uint32_t n)
 {
@@ -100,9 +109,14 @@ struct ImageState {
     uint32_t* bwd_order;     // [xcd_grid_blocks(T)] workgroup -> tile map of the backward blend (longest tiles first)
     Counters* counters;      // zeroed every forward
     uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
-    uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts -> scatter bases
+    uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts (-> scatter bases when !row_order)
     uint32_t* seg_sums;      // [FRG_BIN_SEGS][T]
+    uint32_t* row_matrix;    // [FRG_BIN_MAX_BLOCKS][ncells] per-workgroup counts of visible Gaussians by the cell of their rectangle's first tile -> bases of reorder_kernel
+    uint32_t* row_start;     // [ncells] visible Gaussians per cell (reorder_kernel scans them)
     bool lds_bins;           // false: image too large for LDS histograms -> global-atomic binning
+    bool row_order;          // scatter over cell-ordered records (needs lds_bins)
+    // cells of the record order: tile row x band of band_w tile columns (nbands per row, at most FRG_MAX_TILE_ROWS cells)
+    int band_w, nbands, ncells;
     uint32_t* class_tiles;   // [FRG_SORT_CLASSES][T] tile ids per sort size class (non-empty tiles only)
     size_t zero_begin, zero_bytes;  // region [tile_count .. counters] cleared with one memset
     size_t bytes;
@@ -124,11 +138,24 @@ struct ImageState {
         s.zero_bytes = o - s.zero_begin;
         s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
         s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
+        const size_t gy = (size_t)((H + FRG_TILE - 1) / FRG_TILE);
         s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;
-        s.bin_matrix = nullptr; s.seg_sums = nullptr;
+        s.bin_matrix = nullptr; s.seg_sums = nullptr; s.row_matrix = nullptr; s.row_start = nullptr;
         if (s.lds_bins) {
             s.seg_sums = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_BIN_SEGS * T * 4, 256);
             s.bin_matrix = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_BIN_MAX_BLOCKS * T * 4, 256);
+        }
+        const size_t gx = (size_t)((W + FRG_TILE - 1) / FRG_TILE);
+        s.nbands = (int)(gy ? FRG_MAX_TILE_ROWS / gy : 1);
+        if (s.nbands < 1) s.nbands = 1;
+        if ((size_t)s.nbands > gx) s.nbands = (int)gx;
+        s.band_w = (int)((gx + s.nbands - 1) / s.nbands);
+        s.nbands = (int)((gx + s.band_w - 1) / s.band_w);
+        s.ncells = (int)gy * s.nbands;
+        s.row_order = s.lds_bins && gy <= FRG_MAX_TILE_ROWS && T + (size_t)s.ncells <= FRG_BIN_MAX_LDS_TILES;
+        if (s.row_order) {
+            s.row_matrix = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_BIN_MAX_BLOCKS * s.ncells * 4, 256);
+            s.row_start = (uint32_t*)(base + o); o = align_up(o + ((size_t)s.ncells + 1) * 4, 256);
         }
         s.bytes = o;
         return s;
@@ -264,10 +291,13 @@ __device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, i
     const float a = co.x, b = co.y, c = co.z;
     // not a proper positive-definite conic (or not finite): no bound, keep
     if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f) || !(a < 3.0e38f) || !(c < 3.0e38f)) return true;
-    const float thr = __logf(255.0f * o) + 0.02f;
+    // 255 o lies in [1, 255]: the raw v_log_f32 (log2, 1 ulp) needs none of the denormal scaling __logf carries
+    const float thr = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) + 0.02f;
     const float xlo = (float)qx0 - x, ylo = (float)qy0 - y, xhi = xlo + (float)EXTENT, yhi = ylo + (float)EXTENT;
     if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return true;  // centre inside: Q = 0
-    const float ia = 1.0f / a, ic = 1.0f / c;
+    // v_rcp_f32 (1 ulp) instead of two IEEE divisions (~11 instructions each): an error of the clamped vertex
+    // position enters Q at second order, far below the margins
+    const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);
     float best = 3.0e38f;
 #pragma unroll
     for (int e = 0; e < 2; e++) {

@@ -19,7 +19,8 @@ hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& i
 hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g, hipStream_t s);
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s);
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
-                          const BinningState& b, hipStream_t s);
+                          const BinningState& b, hipStream_t s, int ablate = 0);
+extern int g_rows_grid;   // workgroups of the row-ordered scatter (tuning)
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
 
 // class_count: host copy of the per-class tile counts, or nullptr when they are only known on the

@@ -11,6 +11,8 @@
 #include "gauss_math.h"
 #include "kernels.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace frg {
@@ -27,10 +29,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 // rectangles (owner found by binary search over the per-lane starts in LDS).  A per-lane
 // `for y, for x` loop instead runs for as long as the LARGEST rectangle in the wave
 // (heavy-tailed: ~50 iterations against an average of 6.5 instances per Gaussian).
-// lds_start: 65 words, lds_info: 64 int4, both private to the wave.
+// lds_start: 65 words, lds_info: 64 int4, both private to the wave.  f(owner lane, tile, tx, ty, payload, payload2).
 template <typename F>
 __device__ __forceinline__ void wave_for_each_instance(uint32_t touched, int x0, int y0, int rect_w, uint32_t payload,
-                                                        uint32_t* lds_start, int4* lds_info, int gx, F&& f)
+                                                        uint32_t payload2, uint32_t* lds_start, int4* lds_info, int gx, F&& f)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t incl = wave_incl_scan(touched, lane);
@@ -40,7 +42,7 @@ __device__ __forceinline__ void wave_for_each_instance(uint32_t touched, int x0,
     __builtin_amdgcn_wave_barrier();
     lds_start[lane] = incl - touched;
     if (lane == 0) lds_start[64] = S;
-    lds_info[lane] = make_int4(x0, y0, rect_w, (int)payload);
+    lds_info[lane] = make_int4(x0 | (y0 << 16), rect_w, (int)payload, (int)payload2);   // tile coordinates < 2^16
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -56,8 +58,9 @@ __device__ __forceinline__ void wave_for_each_instance(uint32_t touched, int x0,
             const int4 info = lds_info[owner];
             const uint32_t k = s - lds_start[owner];
             uint32_t ry, rx;
-            rect_divmod(k, (uint32_t)info.z, ry, rx);
-            f(owner, (info.y + (int)ry) * gx + info.x + (int)rx, info.x + (int)rx, info.y + (int)ry, (uint32_t)info.w);
+            rect_divmod(k, (uint32_t)info.y, ry, rx);
+            const int tx = (info.x & 0xFFFF) + (int)rx, ty = (int)((uint32_t)info.x >> 16) + (int)ry;
+            f(owner, ty * gx + tx, tx, ty, (uint32_t)info.z, (uint32_t)info.w);
         }
     }
 }
@@ -198,7 +201,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       int* __restrict__ radii, float4* __restrict__ xydr, float4* __restrict__ conic_opacity,
                       float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_rect,
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
-                      uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered)
+                      uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered,
+                      uint32_t* __restrict__ row_matrix, int band_w, int nbands)
 {
     constexpr bool SH16 = SHMODE == SH_STREAM;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
@@ -212,8 +216,12 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    // bins [T, T + ncells): visible Gaussians by the cell (tile row, band of band_w tile columns) of their rectangle's
+    // first tile (reorder_kernel's counts)
+    const int ncells = row_matrix ? vp.gy * nbands : 0;
+    const int nbins = T + ncells;
     if (LDS_BINS)
-        for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = 0;
+        for (int t = threadIdx.x; t < nbins; t += FRG_BIN_THREADS) lds_bins[t] = 0;
     // the chunk totals of this workgroup's chunks are accumulated with atomics below
     for (int c = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; c < nchunks; c += FRG_BIN_THREADS * (int)gridDim.x) block_sums[c] = 0;
     __threadfence_block();
@@ -235,6 +243,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             tiles_touched[idx] = touched;
             rx0 = x0; ry0 = y0; rw = x1 - x0;
             if (touched) {
+                if (LDS_BINS && row_matrix) atomicAdd(&lds_bins[T + y0 * nbands + x0 / band_w], 1u);
                 depth_rect[3 * idx] = __float_as_uint(depth);
                 depth_rect[3 * idx + 1] = (uint32_t)x0 | ((uint32_t)y0 << 16);
                 depth_rect[3 * idx + 2] = (uint32_t)x1 | ((uint32_t)y1 << 16);
@@ -242,8 +251,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
         {   // per-tile instance counts
             const int wave = threadIdx.x >> 6;
-            wave_for_each_instance(touched, rx0, ry0, rw, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
-                                   [&](int owner, int t, int tx, int ty, uint32_t) {
+            wave_for_each_instance(touched, rx0, ry0, rw, 0u, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
+                                   [&](int owner, int t, int tx, int ty, uint32_t, uint32_t) {
                                        if (TIGHT) {   // centre and conic of the owner: its record, still in LDS
                                            const float4* orec = rec_lds + (wave * 64 + owner) * FRG_REC;
                                            const float4 c2 = orec[0];
@@ -348,6 +357,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         __syncthreads();
         uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
         for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) row[t] = lds_bins[t];
+        if (row_matrix)
+            for (int r = threadIdx.x; r < ncells; r += FRG_BIN_THREADS) row_matrix[(size_t)blockIdx.x * ncells + r] = lds_bins[T + r];
     }
 }
 
@@ -435,11 +446,209 @@ sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const fl
     if (touched) rgb_clamped[FRG_REC * idx] = sa.finish();
 }
 
+// The two single-workgroup scans of the binning stage.  Both are latency-bound: every thread owns SCAN_K CONSECUTIVE
+// elements, loads them in one batch of independent requests, and the workgroup runs one scan over the thread sums.
+//   scan_chunks  exclusive scan of the per-chunk sums (in place), total -> counters.num_rendered, overflow flag
+//   scan_tiles   per-tile totals -> ranges [start,end), empty tiles (0,0) exactly as the reference's memset +
+//                identifyTileRanges leave them (rasterizer_impl.cu:310-317); max -> counters.max_tile_count; the sort's
+//                work lists; with use_segs == 1 the per-segment sums become per-segment start offsets for colbase_kernel
+// scan_kernel runs both; with cell-ordered records they ride as extra workgroups of colsum_kernel and reorder_kernel
+// (the tile scan then runs beside the reorder instead of in front of it).
+struct ScanShared {
+    uint32_t ovf, carry, maxc;
+    uint32_t wtot[16];
+    uint32_t cls[FRG_SORT_CLASSES];
+    uint32_t sub[FRG_SORT_CLASSES * 8], cur[FRG_SORT_CLASSES * 8];
+};
+#define SCAN_K 10
+
+template <int NT>
+__device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_t* __restrict__ block_sums,
+                                            Counters* __restrict__ counters, uint32_t capacity)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { sh.carry = 0; sh.ovf = 0; }
+    __syncthreads();
+    for (int base = 0; base < nchunks; base += NT * SCAN_K) {
+        const int per = min(SCAN_K, (min(nchunks - base, NT * SCAN_K) + NT - 1) / NT);   // elements per thread in this round
+        const int lo = base + tid * per;
+        uint32_t v[SCAN_K], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; k++) {
+            v[k] = (k < per && lo + k < nchunks) ? block_sums[lo + k] : 0u;
+            sum += v[k];
+        }
+        const uint32_t inc = wave_incl_scan(sum, lane);
+        if (lane == 63) sh.wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0, all = 0;
+        for (int w = 0; w < NT / 64; w++) { const uint32_t x = sh.wtot[w]; if (w < wave) woff += x; all += x; }
+        const uint32_t carry = sh.carry;
+        uint32_t run = carry + woff + inc - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; k++)
+            if (k < per && lo + k < nchunks) { block_sums[lo + k] = run; run += v[k]; }
+        __syncthreads();
+        if (tid == 0) sh.carry = carry + all;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counters->num_rendered = sh.carry;
+        // more instances than the caller's binning buffer holds (deferred-counters forward):
+        // every tile list is left empty, the frame renders as background and is redone
+        if (capacity && sh.carry > capacity) { sh.ovf = 1; counters->overflow = 1; }
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void scan_tiles(ScanShared& sh, bool ovf, int T, uint32_t* __restrict__ tile_count,
+                                           uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges,
+                                           uint32_t* __restrict__ class_tiles, Counters* __restrict__ counters, uint32_t tight)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { sh.carry = 0; sh.maxc = 0; }
+    if (tid < FRG_SORT_CLASSES) sh.cls[tid] = 0;
+    if (tid < FRG_SORT_CLASSES * 8) { sh.sub[tid] = 0; sh.cur[tid] = 0; }
+    __syncthreads();
+    uint32_t local_max = 0;
+    const bool single = T <= NT * SCAN_K;     // one round: the totals stay in registers for the work lists below
+    uint32_t v[SCAN_K];
+    int lo = 0, per = 0;
+    for (int base = 0; base < T; base += NT * SCAN_K) {
+        per = min(SCAN_K, (min(T - base, NT * SCAN_K) + NT - 1) / NT);
+        lo = base + tid * per;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; k++) {
+            const int i = lo + k;
+            v[k] = 0;
+            if (k < per && i < T) {
+                if (use_segs) {
+#pragma unroll
+                    for (int sg = 0; sg < FRG_BIN_SEGS; sg++) v[k] += seg_sums[(size_t)sg * T + i];
+                } else v[k] = tile_count[i];
+            }
+            if (ovf) v[k] = 0;
+            sum += v[k];
+            local_max = max(local_max, v[k]);
+        }
+        const uint32_t inc = wave_incl_scan(sum, lane);
+        if (lane == 63) sh.wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0, all = 0;
+        for (int w = 0; w < NT / 64; w++) { const uint32_t x = sh.wtot[w]; if (w < wave) woff += x; all += x; }
+        const uint32_t carry = sh.carry;
+        uint32_t run = carry + woff + inc - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; k++) {
+            const int i = lo + k;
+            if (k < per && i < T) {
+                const uint32_t excl = run;
+                run += v[k];
+                if (use_segs || ovf) tile_count[i] = v[k];
+                ranges[i] = v[k] ? make_uint2(excl, excl + v[k]) : make_uint2(0u, 0u);
+                if (v[k]) atomicAdd(&sh.sub[sort_subclass_of(v[k])], 1u);
+                if (use_segs == 1) {  // segment s of tile i starts at excl + sum of earlier segments (colbase_kernel)
+                    uint32_t r2 = excl;
+#pragma unroll
+                    for (int sg = 0; sg < FRG_BIN_SEGS; sg++) {
+                        const uint32_t c = seg_sums[(size_t)sg * T + i];
+                        seg_sums[(size_t)sg * T + i] = r2;
+                        r2 += c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) sh.carry = carry + all;
+        __syncthreads();
+    }
+    atomicMax(&sh.maxc, local_max);
+    __syncthreads();
+    // work lists of the sort: only non-empty tiles, grouped by size class and, inside a class,
+    // by size in eight descending buckets (longest tiles are dispatched first: the last round of
+    // workgroups then holds the short ones instead of a straggler)
+    if (tid < FRG_SORT_CLASSES) {
+        uint32_t run = 0;
+        for (int k = 0; k < 8; k++) { const uint32_t c = sh.sub[tid * 8 + k]; sh.sub[tid * 8 + k] = run; run += c; }
+        sh.cls[tid] = run;
+    }
+    __syncthreads();
+    if (single) {
+#pragma unroll
+        for (int k = 0; k < SCAN_K; k++) {
+            if (k < per && lo + k < T && v[k]) {
+                const int key = sort_subclass_of(v[k]);
+                class_tiles[(size_t)(key >> 3) * T + sh.sub[key] + atomicAdd(&sh.cur[key], 1u)] = (uint32_t)(lo + k);
+            }
+        }
+    } else {
+        for (int i = tid; i < T; i += NT) {
+            const uint32_t c = tile_count[i];
+            if (!c) continue;
+            const int key = sort_subclass_of(c);
+            class_tiles[(size_t)(key >> 3) * T + sh.sub[key] + atomicAdd(&sh.cur[key], 1u)] = (uint32_t)i;
+        }
+    }
+    if (tid == 0) { counters->max_tile_count = sh.maxc; counters->tight_binning = tight; }
+    if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = sh.cls[tid];
+}
+
+__global__ void __launch_bounds__(1024)
+scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
+            uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
+            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight)
+{
+    __shared__ ScanShared sh;
+    scan_chunks<1024>(sh, nchunks, block_sums, counters, capacity);
+    scan_tiles<1024>(sh, sh.ovf != 0, T, tile_count, seg_sums, use_segs, ranges, class_tiles, counters, tight);
+}
+
 // Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
 // seg_sums[s][t] = sum over the rows of segment s.  grid (ceil(T/256), FRG_BIN_SEGS).
+// With cell-ordered records (row_matrix given) two more rows of workgroups ride along:
+//   blockIdx.y == FRG_BIN_SEGS      one wave per cell turns the counts of visible Gaussians per (workgroup, cell) into
+//                                   each workgroup's offset inside the cell's block of records (the workgroups of one
+//                                   XCD next to each other) and leaves the cell's total in row_total (reorder_kernel
+//                                   scans the totals);
+//   blockIdx.y == FRG_BIN_SEGS + 1  one workgroup scans the chunk totals (scan_chunks).
 __global__ void __launch_bounds__(256)
-colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums)
+colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums,
+              uint32_t* __restrict__ row_matrix, uint32_t* __restrict__ row_total, int gy,
+              int nchunks, uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, uint32_t capacity)
 {
+    if (blockIdx.y == FRG_BIN_SEGS + 1) {
+        if (blockIdx.x != 0) return;
+        __shared__ ScanShared sh;
+        scan_chunks<256>(sh, nchunks, block_sums, counters, capacity);
+        return;
+    }
+    if (blockIdx.y == FRG_BIN_SEGS) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int r = blockIdx.x * 4 + wave;
+        if (r >= gy) return;
+        // four workgroups per lane (nrows <= FRG_BIN_MAX_BLOCKS = 256), XCD-major when nrows is a multiple of 8
+        const int per = (nrows % FRG_NUM_XCD == 0) ? nrows / FRG_NUM_XCD : 0;
+        uint32_t c[4], s4 = 0;
+        int w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = 4 * lane + i;
+            w[i] = per ? (k / per) + FRG_NUM_XCD * (k % per) : k;
+            c[i] = k < nrows ? row_matrix[(size_t)w[i] * gy + r] : 0u;
+            s4 += c[i];
+        }
+        const uint32_t inc = wave_incl_scan(s4, lane);
+        uint32_t run = inc - s4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (4 * lane + i < nrows) row_matrix[(size_t)w[i] * gy + r] = run;
+            run += c[i];
+        }
+        if (lane == 63) row_total[r] = inc;
+        return;
+    }
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
     // segment s = the workgroups the dispatcher places on XCD s (round robin, FRG_BIN_SEGS == 8):
@@ -449,102 +658,6 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
 #pragma unroll 8
     for (int r = blockIdx.y; r < nrows; r += FRG_BIN_SEGS) s += bin_matrix[(size_t)r * T + t];
     seg_sums[(size_t)blockIdx.y * T + t] = s;
-}
-
-// Single workgroup: (a) exclusive scan of the per-chunk sums (in place), total ->
-// counters.num_rendered; (b) per-tile totals -> ranges [start,end), empty tiles (0,0)
-// exactly as the reference's memset + identifyTileRanges leave them
-// (rasterizer_impl.cu:310-317); max -> counters.max_tile_count; with LDS_BINS the
-// per-segment sums become per-segment start offsets for colbase_kernel.
-__global__ void __launch_bounds__(1024)
-scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
-            uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
-            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight)
-{
-    __shared__ uint32_t ovf_s;
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    __shared__ uint32_t maxc_s;
-    __shared__ uint32_t cls_s[FRG_SORT_CLASSES];
-    __shared__ uint32_t sub_s[FRG_SORT_CLASSES * 8], sub_cur[FRG_SORT_CLASSES * 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry_s = 0; maxc_s = 0; ovf_s = 0; }
-    if (tid < FRG_SORT_CLASSES) cls_s[tid] = 0;
-    if (tid < FRG_SORT_CLASSES * 8) { sub_s[tid] = 0; sub_cur[tid] = 0; }
-    __syncthreads();
-    for (int pass = 0; pass < 2; pass++) {
-        const int n = pass == 0 ? nchunks : T;
-        uint32_t local_max = 0;
-        for (int base = 0; base < n; base += 1024) {
-            const int i = base + tid;
-            uint32_t v = 0;
-            if (i < n) {
-                if (pass == 0) v = block_sums[i];
-                else if (use_segs) {
-#pragma unroll
-                    for (int s = 0; s < FRG_BIN_SEGS; s++) v += seg_sums[(size_t)s * T + i];
-                    tile_count[i] = v;
-                } else v = tile_count[i];
-                // more instances than the caller's binning buffer holds (deferred-counters forward):
-                // every tile list is left empty, the frame renders as background and is redone
-                if (pass == 1 && ovf_s) { v = 0; tile_count[i] = 0; }
-            }
-            local_max = max(local_max, v);
-            uint32_t inc = wave_incl_scan(v, lane);
-            if (lane == 63) wtot[wave] = inc;
-            __syncthreads();
-            uint32_t woff = 0;
-            for (int w = 0; w < wave; w++) woff += wtot[w];
-            const uint32_t carry = carry_s;
-            const uint32_t excl = carry + woff + inc - v;
-            if (i < n) {
-                if (pass == 0) block_sums[i] = excl;
-                else {
-                    ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
-                    if (v) atomicAdd(&sub_s[sort_subclass_of(v)], 1u);
-                    if (use_segs) {  // segment s of tile i starts at excl + sum of earlier segments
-                        uint32_t run = excl;
-#pragma unroll
-                        for (int s = 0; s < FRG_BIN_SEGS; s++) {
-                            const uint32_t c = seg_sums[(size_t)s * T + i];
-                            seg_sums[(size_t)s * T + i] = run;
-                            run += c;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 1023) carry_s = carry + woff + inc;
-            __syncthreads();
-        }
-        if (pass == 0) {
-            if (tid == 0) {
-                counters->num_rendered = carry_s;
-                if (capacity && carry_s > capacity) { ovf_s = 1; counters->overflow = 1; }
-                carry_s = 0;
-            }
-        } else {
-            atomicMax(&maxc_s, local_max);
-        }
-        __syncthreads();
-    }
-    // work lists of the sort: only non-empty tiles, grouped by size class and, inside a class,
-    // by size in eight descending buckets (longest tiles are dispatched first: the last round of
-    // workgroups then holds the short ones instead of a straggler)
-    if (tid < FRG_SORT_CLASSES) {
-        uint32_t run = 0;
-        for (int k = 0; k < 8; k++) { const uint32_t c = sub_s[tid * 8 + k]; sub_s[tid * 8 + k] = run; run += c; }
-        cls_s[tid] = run;
-    }
-    __syncthreads();
-    for (int i = tid; i < T; i += 1024) {
-        const uint32_t v = tile_count[i];
-        if (!v) continue;
-        const int key = sort_subclass_of(v);
-        class_tiles[(size_t)(key >> 3) * T + sub_s[key] + atomicAdd(&sub_cur[key], 1u)] = (uint32_t)i;
-    }
-    if (tid == 0) { counters->max_tile_count = maxc_s; counters->tight_binning = tight; }
-    if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = cls_s[tid];
 }
 
 // Turns the count matrix into the base matrix in place: base[b][t] = first position
@@ -611,8 +724,8 @@ scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ depth_rect, c
         }
         const int wave = threadIdx.x >> 6;
         const uint32_t idx0 = (uint32_t)(c * FRG_BIN_THREADS + wave * 64);
-        wave_for_each_instance(touched, x0, y0, x1 - x0, dbits, emit_start + wave * 68, emit_info + wave * 64, gx,
-                               [&](int owner, int t, int tx, int ty, uint32_t depth_bits) {
+        wave_for_each_instance(touched, x0, y0, x1 - x0, dbits, 0u, emit_start + wave * 68, emit_info + wave * 64, gx,
+                               [&](int owner, int t, int tx, int ty, uint32_t depth_bits, uint32_t) {
                                    if (TIGHT) {
                                        const float2 c2 = emit_xy[wave * 64 + owner];
                                        if (!tile_hit(c2.x, c2.y, emit_co[wave * 64 + owner], tx, ty)) return;
@@ -621,6 +734,156 @@ scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ depth_rect, c
                                    if (LDS_BINS) pos = atomicAdd(&lds_bins[t], 1u);             // ds_add_rtn_u32
                                    else pos = ranges[t].x + atomicAdd(&tile_fill[t], 1u);
                                    pairs[pos] = make_uint2(depth_bits, idx0 + (uint32_t)owner);
+                               });
+    }
+}
+
+// ---- scatter over cell-ordered records ---------------------------------------------------------
+// In the caller's order a chunk of 1024 Gaussians hits ~6500 different tiles all over the image: every 128-byte line
+// of the pairs array is written 16 times over the whole duration of the scatter, no cache can hold 131 MB of open
+// lines, and they reach HBM as 32-byte sectors (3.8x write amplification, the stage ran at 15 % of its roofline).
+// With the Gaussians of the C3 scene handed over sorted by screen row the very same kernel took 0.085 instead of
+// 0.222 ms -- so the library orders its own 16-byte scatter records first, by the CELL (tile row, band of a few tile
+// columns) of the rectangle's first tile:
+//   reorder_kernel       same chunk -> workgroup map as preprocess (whose per-workgroup cell counts, scanned by the
+//                        extra workgroups of colsum_kernel, are its write positions: no atomics on global memory);
+//                        also finishes point_offsets; one extra workgroup scans the tile totals beside it
+//   scatter_rows_kernel  every workgroup takes one contiguous share of the records (a few cells: some dozens of
+//                        tiles): counts its instances per tile in LDS, reserves one run per touched tile with a single
+//                        atomic on the tile's fill cursor, emits.  The shares of one XCD are consecutive (dealt like
+//                        the tile bands of the blend), so the lines of a tile segment are completed inside one L2.
+// The order of the pairs inside a tile segment is arbitrary (and, with the run reservations, not the same from run to
+// run); the sort orders them by (depth, index), a total order: point_list is deterministic.
+__global__ void __launch_bounds__(FRG_BIN_THREADS, 8)   // 8 waves per SIMD = two workgroups per CU: the scan workgroup must fit beside a reorder workgroup
+reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uint32_t* __restrict__ depth_rect, const uint32_t* __restrict__ tiles_touched,
+               const uint32_t* __restrict__ chunk_prefix, uint32_t* __restrict__ point_offsets,
+               const uint32_t* __restrict__ row_matrix, const uint32_t* __restrict__ row_total, uint4* __restrict__ row_records,
+               Counters* __restrict__ counters,
+               int T, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
+               uint32_t* __restrict__ class_tiles, uint32_t tight)
+{
+    if ((int)blockIdx.x == nblocks) {
+        // one more workgroup than the reorder needs: the scan of the tile totals (ranges, the sort's work lists,
+        // the counters the host reads back) -- a single workgroup's latency chain, beside the reorder instead of in
+        // front of it.  Nothing in the reorder depends on it.
+        __shared__ ScanShared sh;
+        scan_tiles<FRG_BIN_THREADS>(sh, counters->overflow != 0, T, tile_count, seg_sums, 2, ranges, class_tiles, counters, tight);
+        return;
+    }
+    __shared__ uint32_t cursor[FRG_MAX_TILE_ROWS];
+    __shared__ uint32_t wsum[FRG_BIN_THREADS / 64];
+    {   // first record of every cell = exclusive scan of the cell totals (at most FRG_MAX_TILE_ROWS = the workgroup
+        // size; every workgroup repeats these few hundred additions rather than wait for another launch)
+        const uint32_t v = (int)threadIdx.x < ncells ? row_total[threadIdx.x] : 0u;
+        uint32_t all;
+        const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(v, wsum, &all);
+        if ((int)threadIdx.x < ncells) cursor[threadIdx.x] = inc - v + row_matrix[(size_t)blockIdx.x * ncells + threadIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x == 0) counters->num_visible = all;
+        __syncthreads();
+    }
+    const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
+    for (int c = blockIdx.x; c < nchunks; c += nblocks) {
+        const int idx = c * FRG_BIN_THREADS + threadIdx.x;
+        const uint32_t touched = idx < P ? tiles_touched[idx] : 0u;
+        uint3 dr = make_uint3(0u, 0u, 0u);
+        if (touched) dr = make_uint3(depth_rect[3 * idx], depth_rect[3 * idx + 1], depth_rect[3 * idx + 2]);
+        uint32_t total;
+        const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
+        if (idx < P) point_offsets[idx] = chunk_prefix[c] + inc;
+        if (touched) {
+            const uint32_t pos = atomicAdd(&cursor[(dr.y >> 16) * nbands + (dr.y & 0xFFFFu) / band_w], 1u);     // ds_add_rtn_u32
+            row_records[pos] = make_uint4(dr.x, (uint32_t)idx, dr.y, dr.z);
+        }
+    }
+}
+
+// Records of one workgroup = FRG_ROWS_SUB sub-slices of 1024 at most (launch_scatter sizes the grid accordingly).
+#define FRG_ROWS_SUB 8
+__global__ void __launch_bounds__(FRG_BIN_THREADS)
+scatter_rows_kernel(int T, int gx, int gy, const uint4* __restrict__ row_records, const uint2* __restrict__ ranges,
+                    uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs, const Counters* __restrict__ counters, int ablate)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
+    __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
+    __shared__ int4 emit_info[FRG_BIN_THREADS];
+    __shared__ int row_lo, row_hi;
+    // the binning buffer is too small for this frame (deferred-counters forward): every tile list was left empty
+    if (counters->overflow != 0) return;
+    // Every workgroup takes one contiguous share of the records, a multiple of 1024 (a few cells: some dozens of
+    // tiles), and reserves ONE run per touched tile.  Workgroup b runs on XCD b % 8: XCD x takes the shares
+    // [x * per_xcd, (x + 1) * per_xcd), so that a tile's pairs are written through one L2.
+    const uint32_t nvis = counters->num_visible;
+    const uint32_t per_xcd = gridDim.x / FRG_NUM_XCD;
+    const uint32_t share = ((nvis + gridDim.x - 1) / gridDim.x + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS * FRG_BIN_THREADS;
+    const uint32_t first = ((blockIdx.x % FRG_NUM_XCD) * per_xcd + blockIdx.x / FRG_NUM_XCD) * share;
+    if (first >= nvis) return;                       // workgroup-uniform
+    const uint32_t last = min(nvis, first + share);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) lds_bins[t] = 0;
+    if (threadIdx.x == 0) { row_lo = gy; row_hi = 0; }
+    __syncthreads();
+    struct Rec { int x0, y0, x1, y1; uint32_t depth, index, touched; bool valid; };
+    auto load = [&](uint32_t base) -> Rec {
+        Rec r;
+        const uint32_t i = base + threadIdx.x;
+        r.valid = i < last;
+        const uint4 rec = r.valid ? row_records[i] : make_uint4(0u, 0u, 0u, 0u);
+        r.x0 = (int)(rec.z & 0xFFFFu); r.y0 = (int)(rec.z >> 16); r.x1 = (int)(rec.w & 0xFFFFu); r.y1 = (int)(rec.w >> 16);
+        r.depth = rec.x; r.index = rec.y;
+        r.touched = r.valid ? (uint32_t)((r.x1 - r.x0) * (r.y1 - r.y0)) : 0u;
+        return r;
+    };
+    // ---- counts per tile ----
+    // Every tile of a rectangle counts: the per-tile counts are the 2-D prefix sum of a difference array with four
+    // entries per Gaussian (+1 top-left, -1 right of the top-right, -1 below the bottom-left, +1 diagonal; entries
+    // beyond the end of a tile row or below the last row are not needed) -- 4 LDS atomics per Gaussian and two short
+    // scans instead of a walk over its 6.5 instances.  Unsigned wrap-around is harmless.
+    int lo = gy, hi = 0;
+    for (uint32_t base = first; base < last; base += FRG_BIN_THREADS) {
+        const Rec r = load(base);
+        if (!r.valid) continue;
+        lo = min(lo, r.y0); hi = max(hi, r.y1);
+        atomicAdd(&lds_bins[r.y0 * gx + r.x0], 1u);
+        if (r.x1 < gx) atomicAdd(&lds_bins[r.y0 * gx + r.x1], 0xFFFFFFFFu);
+        if (r.y1 < gy) {
+            atomicAdd(&lds_bins[r.y1 * gx + r.x0], 0xFFFFFFFFu);
+            if (r.x1 < gx) atomicAdd(&lds_bins[r.y1 * gx + r.x1], 1u);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); }
+    if (lane == 0) { atomicMin(&row_lo, lo); atomicMax(&row_hi, hi); }
+    __syncthreads();
+    const int rlo = row_lo, rhi = max(row_hi, row_lo);   // tile rows this workgroup's records touch
+    for (int row = rlo + wave; row < rhi; row += FRG_BIN_THREADS / 64) {      // along x: one wave per row
+        uint32_t carry = 0;
+        for (int xb = 0; xb < gx; xb += 64) {
+            const int x = xb + lane;
+            const uint32_t v = x < gx ? lds_bins[row * gx + x] : 0u;
+            const uint32_t inc = wave_incl_scan(v, lane) + carry;
+            if (x < gx) lds_bins[row * gx + x] = inc;
+            carry = (uint32_t)__shfl((int)inc, 63, 64);
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < gx; x += FRG_BIN_THREADS) {                   // along y: one thread per column
+        uint32_t run = lds_bins[rlo * gx + x];
+        for (int row = rlo + 1; row < rhi; row++) { run += lds_bins[row * gx + x]; lds_bins[row * gx + x] = run; }
+    }
+    __syncthreads();
+    // ---- one run per touched tile: the bin becomes the position of the run's first pair ----
+    for (int t = rlo * gx + (int)threadIdx.x; t < rhi * gx; t += FRG_BIN_THREADS) {
+        const uint32_t c = lds_bins[t];
+        if (c) lds_bins[t] = ranges[t].x + atomicAdd(&tile_fill[t], c);
+    }
+    __syncthreads();
+    // ---- emit ----
+    for (uint32_t base = first; base < last; base += FRG_BIN_THREADS) {
+        const Rec r = load(base);                    // (second read of the records: they come from the L2)
+        wave_for_each_instance(r.touched, r.x0, r.y0, r.x1 - r.x0, r.depth, r.index, emit_start + wave * 68, emit_info + wave * 64, gx,
+                               [&](int, int t, int, int, uint32_t depth_bits, uint32_t index) {
+                                   const uint32_t pos = atomicAdd(&lds_bins[t], 1u);            // ds_add_rtn_u32
+                                   if (!(ablate & 4) || pos == 0xFFFFFFFFu) pairs[pos] = make_uint2(depth_bits, index);   // (ablate: timing experiments)
                                });
     }
 }
@@ -641,6 +904,14 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 }
 
 // ---- host launchers -----------------------------------------------------------
+// workgroups of the cell-ordered scatter (tuning knob: frg_set_option("rows_grid")), 2 per CU by default
+int g_rows_grid = 512;
+
+// The scatter runs over cell-ordered records (reorder_kernel + scatter_rows_kernel) in the reference-identical
+// binning mode; tight binning keeps the scatter in the caller's order (it would evaluate the per-instance tile test in
+// both passes of the new kernel and gather the centre / conic of every record: measured slower).
+static bool cell_order(const ImageState& img, const ViewParams& vp) { return img.row_order && !vp.tight; }
+
 static int bin_blocks(int P)
 {
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
@@ -660,13 +931,14 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
-    const size_t lds = LDS_BINS ? (size_t)T * 4 : 0;
+    const size_t lds = LDS_BINS ? (size_t)(T + (cell_order(img, vp) ? img.ncells : 0)) * 4 : 0;
     hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
-                       g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered);
+                       g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
+                       LDS_BINS && cell_order(img, vp) ? img.row_matrix : nullptr, img.band_w, img.nbands);
     return hipGetLastError();
 }
 
@@ -703,20 +975,43 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     const int T = vp.gx * vp.gy;
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
     const int nb = bin_blocks(P);
+    const bool cells = cell_order(img, vp);
     if (img.lds_bins)
-        hipLaunchKernelGGL(colsum_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
+        hipLaunchKernelGGL(colsum_kernel, dim3(std::max((T + 255) / 256, cells ? (img.ncells + 3) / 4 : 0), FRG_BIN_SEGS + (cells ? 2 : 0)),
+                           dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums, img.row_matrix, img.row_start, img.ncells,
+                           nchunks, g.block_sums, img.counters, capacity);
+    if (cells) {
+        // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
+        hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), 0, s, P, nb, img.ncells, img.band_w, img.nbands,
+                           g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
+                           img.counters, T, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
                        img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity, (uint32_t)vp.tight);
+    // per-workgroup scatter bases of the scatter in the caller's order
     if (img.lds_bins)
         hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
     return hipGetLastError();
 }
 
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
-                          const BinningState& b, hipStream_t s)
+                          const BinningState& b, hipStream_t s, int ablate)
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
+    if (cell_order(img, vp)) {   // (launch_scan has reordered the records)
+        const size_t lds = (size_t)T * 4;
+        // two workgroups per CU, each with one contiguous share of the records (their number is only known on the
+        // device: at most P); more workgroups only when a share would exceed FRG_ROWS_SUB sub-slices
+        const int need = (P + FRG_ROWS_SUB * FRG_BIN_THREADS - 1) / (FRG_ROWS_SUB * FRG_BIN_THREADS);
+        const int grid = ((std::max(need, g_rows_grid) + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD;
+        hipError_t e = allow_big_lds(scatter_rows_kernel, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(FRG_BIN_THREADS), lds, s, T, vp.gx, vp.gy, g.row_records,
+                           img.ranges, img.tile_fill, b.pairs, img.counters, ablate);
+        return hipGetLastError();
+    }
 #define FRG_SCATTER(L, TI, LDS)                                                                                          \
     hipLaunchKernelGGL((scatter_kernel<L, TI>), dim3(nb), dim3(FRG_BIN_THREADS), LDS, s, P, vp.gx, vp.gy, g.depth_rect, g.xydr,    \
                        g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs,  \

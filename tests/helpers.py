@@ -65,6 +65,24 @@ def grad_bar(name, noise=0.0, fast=False):
     return max(5.0 * noise, (GRAD_FLOOR_FAST if fast else GRAD_FLOOR)[name])
 
 
+def reference_runs(backward_fn, n=4):
+    """n runs of the reference's backward on the same state.  Its float atomics land in scheduling order, and on
+    strongly cancelling sums (means3D / scales / quaternions of thin or anisotropic Gaussians) the run-to-run
+    spread itself varies by an order of magnitude between pairs of runs (C4 means3D: 3e-5 .. 6e-4 measured), so
+    ONE pair is not an estimate of it: a comparison that used one pair failed about one time in ten."""
+    return [backward_fn() for _ in range(n)]
+
+
+def reference_noise(runs, name):
+    """largest pairwise rel. L2 difference between the reference's own runs"""
+    return max((rel_l2(runs[i][name], runs[j][name]) for i in range(len(runs)) for j in range(i)), default=0.0)
+
+
+def distance_to_reference(g, runs, name):
+    """rel. L2 distance to the closest of the reference's runs"""
+    return min(rel_l2(g, r[name]) for r in runs)
+
+
 def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False, ops=None):
     """Call the native entry points directly (what _RasterizeGaussians.forward does)."""
     sc = scene.to(device)

@@ -236,11 +236,13 @@ def test_c4_refine_step_vs_reference_on_compacted_tensors(gpu_device, P):
         b = (args[0], args[1], radii, args[2], args[4], args[5], args[6], args[7], args[8], args[9], args[10], args[11],
              gpix, args[14], args[15], args[16], geom, R, binning, img, False)
         grads = D._C.rasterize_gaussians_backward(*b)
-        rg, rg2 = REF.backward(rst, gpix), REF.backward(rst, gpix)
+        runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
         names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
         for name, g in zip(names, grads):
             assert not g[~keep].any(), name                    # culled Gaussians: zero rows
-            noise = Hh.rel_l2(rg2[name], rg[name])
-            assert Hh.rel_l2(g[keep], rg[name]) < Hh.grad_bar(name, noise), name
+            noise = Hh.reference_noise(runs, name)
+            d = Hh.distance_to_reference(g[keep], runs, name)
+            print(f"c4 {name}: ours vs reference {d:.3e}, reference vs itself {noise:.3e}, bar {Hh.grad_bar(name, noise):.3e}")
+            assert d < Hh.grad_bar(name, noise), name
     finally:
         _lib.set_option("exact_blend", 0)

@@ -167,12 +167,11 @@ def test_bit_exact_vs_reference_rasterizer(gpu_device, cfg, P, view, binding):
     del st
     gpix, _ = scenes.l1_target_grad(color.cpu(), 9)
     gpix = gpix.to(gpu_device)
-    rg = REF.backward(rst, gpix)
-    rg2 = REF.backward(rst, gpix)
-    noise = {name: Hh.rel_l2(rg2[name], rg[name]) for name in GRAD_NAMES}   # the reference's own run-to-run spread
+    runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
+    noise = {name: Hh.reference_noise(runs, name) for name in GRAD_NAMES}   # the reference's own run-to-run spread
 
     def check(grads, fast, label):
-        report = {name: Hh.rel_l2(g, rg[name]) for name, g in zip(GRAD_NAMES, grads)}
+        report = {name: Hh.distance_to_reference(g, runs, name) for name, g in zip(GRAD_NAMES, grads)}
         print(f"\n[{cfg} P={P} {label}] gradient rel-L2 vs reference (reference vs itself): " +
               ", ".join(f"{k[3:]} {v:.1e} ({noise[k]:.1e})" for k, v in report.items()))
         for name, err in report.items():

@@ -14,11 +14,31 @@ ap.add_argument("--config", default="c3")
 ap.add_argument("--points", type=int, default=0)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--view", type=int, default=0)
+ap.add_argument("--order", default="input", choices=["input", "yrow", "morton"],
+                help="memory order of the Gaussians: as generated | by the 16-pixel screen row of the projected centre | Morton order of the pixel")
 ap.add_argument("settings", nargs="*", default=[""])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = scenes.CONFIGS[a.config]
 scene, cam, bg = scenes.config_scene(a.config, a.view, P=a.points or cfg["P"])
+if a.order != "input":
+    # what spatial coherence of the caller's array would be worth to the binning stages (timing experiment)
+    ph = torch.cat([scene.means3D.double(), torch.ones(scene.P, 1, dtype=torch.float64)], 1) @ cam.projmatrix.double()
+    w = ph[:, 3:4].clamp_min(1e-6)
+    px = ((ph[:, 0:1] / w + 1) * cam.image_width - 1) * 0.5
+    py = ((ph[:, 1:2] / w + 1) * cam.image_height - 1) * 0.5
+    tx = (px[:, 0] / 16).floor().clamp(-4, 4095).long() + 4
+    ty = (py[:, 0] / 16).floor().clamp(-4, 4095).long() + 4
+    if a.order == "yrow":
+        key = ty * 8192 + tx
+    else:
+        key = torch.zeros_like(tx)
+        for bit in range(12):
+            key |= ((tx >> bit) & 1) << (2 * bit)
+            key |= ((ty >> bit) & 1) << (2 * bit + 1)
+    perm = torch.argsort(key, stable=True)
+    scene = scenes.Scene(scene.means3D[perm].contiguous(), scene.scales[perm].contiguous(), scene.rotations[perm].contiguous(),
+                         scene.opacities[perm].contiguous(), scene.shs[perm].contiguous(), scene.sh_degree)
 vpr = ViewParallelRasterizer(scene.to(dev), dev)
 cam_d, bg_d = cam.to(dev), bg.to(dev)
 img, radii = vpr.forward(cam_d, bg_d)
