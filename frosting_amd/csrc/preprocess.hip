@@ -760,9 +760,11 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
                const uint32_t* __restrict__ row_matrix, const uint32_t* __restrict__ row_total, uint4* __restrict__ row_records,
                Counters* __restrict__ counters,
                int T, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
-               uint32_t* __restrict__ class_tiles, uint32_t tight)
+               uint32_t* __restrict__ class_tiles, uint32_t tight, int scan_first)
 {
-    if ((int)blockIdx.x == nblocks) {
+    const int scan_block = scan_first ? 0 : nblocks;
+    const int my_block = (int)blockIdx.x - (scan_first ? 1 : 0);     // this workgroup's row of the count matrices
+    if ((int)blockIdx.x == scan_block) {
         // one more workgroup than the reorder needs: the scan of the tile totals (ranges, the sort's work lists,
         // the counters the host reads back) -- a single workgroup's latency chain, beside the reorder instead of in
         // front of it.  Nothing in the reorder depends on it.
@@ -777,12 +779,12 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
         const uint32_t v = (int)threadIdx.x < ncells ? row_total[threadIdx.x] : 0u;
         uint32_t all;
         const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(v, wsum, &all);
-        if ((int)threadIdx.x < ncells) cursor[threadIdx.x] = inc - v + row_matrix[(size_t)blockIdx.x * ncells + threadIdx.x];
-        if (blockIdx.x == 0 && threadIdx.x == 0) counters->num_visible = all;
+        if ((int)threadIdx.x < ncells) cursor[threadIdx.x] = inc - v + row_matrix[(size_t)my_block * ncells + threadIdx.x];
+        if (my_block == 0 && threadIdx.x == 0) counters->num_visible = all;
         __syncthreads();
     }
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
-    for (int c = blockIdx.x; c < nchunks; c += nblocks) {
+    for (int c = my_block; c < nchunks; c += nblocks) {
         const int idx = c * FRG_BIN_THREADS + threadIdx.x;
         const uint32_t touched = idx < P ? tiles_touched[idx] : 0u;
         uint3 dr = make_uint3(0u, 0u, 0u);
@@ -906,6 +908,7 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 // ---- host launchers -----------------------------------------------------------
 // workgroups of the cell-ordered scatter (tuning knob: frg_set_option("rows_grid")), 2 per CU by default
 int g_rows_grid = 512;
+int g_scan_first = 0;   // (experiment) the tile-scan workgroup is dispatched first instead of last
 
 // The scatter runs over cell-ordered records (reorder_kernel + scatter_rows_kernel) in the reference-identical
 // binning mode; tight binning keeps the scatter in the caller's order (it would evaluate the per-instance tile test in
@@ -984,7 +987,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), 0, s, P, nb, img.ncells, img.band_w, img.nbands,
                            g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
-                           img.counters, T, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight);
+                           img.counters, T, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g_scan_first);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
