@@ -501,95 +501,91 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
     __syncthreads();
 }
 
-template <int NT>
-__device__ __forceinline__ void scan_tiles(ScanShared& sh, bool ovf, int T, uint32_t* __restrict__ tile_count,
-                                           uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges,
+// The tile scan is ONE workgroup executing its code once: the time goes to instruction fetch (straight-line unrolled
+// code ran at an instruction-cache miss per 64 bytes, ~30 us at C3, twice that beside a streaming kernel), not to
+// data.  So only the load batch is unrolled; the totals then sit in LDS (tot, T words) and everything else is a
+// rolled loop of a few dozen instructions.  USE_SEGS: 0 totals in tile_count | 1 sum the segments and turn them into
+// start offsets for colbase_kernel | 2 sum the segments only.
+template <int NT, int USE_SEGS>
+__device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool ovf, int T, uint32_t* __restrict__ tile_count,
+                                           uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
                                            uint32_t* __restrict__ class_tiles, Counters* __restrict__ counters, uint32_t tight)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { sh.carry = 0; sh.maxc = 0; }
     if (tid < FRG_SORT_CLASSES) sh.cls[tid] = 0;
     if (tid < FRG_SORT_CLASSES * 8) { sh.sub[tid] = 0; sh.cur[tid] = 0; }
-    __syncthreads();
-    uint32_t local_max = 0;
-    const bool single = T <= NT * SCAN_K;     // one round: the totals stay in registers for the work lists below
-    uint32_t v[SCAN_K];
-    int lo = 0, per = 0;
+    // totals -> LDS: coalesced, all requests of a round in flight together.  (Images of more tiles than the LDS holds
+    // have their totals in tile_count already -- USE_SEGS == 0 -- and are scanned from there: tot == tile_count.)
+    if (tot == tile_count) {
+        if (ovf) for (int i = tid; i < T; i += NT) tile_count[i] = 0;
+    } else
     for (int base = 0; base < T; base += NT * SCAN_K) {
-        per = min(SCAN_K, (min(T - base, NT * SCAN_K) + NT - 1) / NT);
-        lo = base + tid * per;
-        uint32_t sum = 0;
+        uint32_t v[SCAN_K];
 #pragma unroll
         for (int k = 0; k < SCAN_K; k++) {
-            const int i = lo + k;
+            const int i = base + k * NT + tid;
             v[k] = 0;
-            if (k < per && i < T) {
-                if (use_segs) {
+            if (i < T) {
+                if (USE_SEGS) {
 #pragma unroll
                     for (int sg = 0; sg < FRG_BIN_SEGS; sg++) v[k] += seg_sums[(size_t)sg * T + i];
                 } else v[k] = tile_count[i];
             }
-            if (ovf) v[k] = 0;
-            sum += v[k];
-            local_max = max(local_max, v[k]);
         }
-        const uint32_t inc = wave_incl_scan(sum, lane);
-        if (lane == 63) sh.wtot[wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0, all = 0;
-        for (int w = 0; w < NT / 64; w++) { const uint32_t x = sh.wtot[w]; if (w < wave) woff += x; all += x; }
-        const uint32_t carry = sh.carry;
-        uint32_t run = carry + woff + inc - sum;
 #pragma unroll
         for (int k = 0; k < SCAN_K; k++) {
-            const int i = lo + k;
-            if (k < per && i < T) {
-                const uint32_t excl = run;
-                run += v[k];
-                if (use_segs || ovf) tile_count[i] = v[k];
-                ranges[i] = v[k] ? make_uint2(excl, excl + v[k]) : make_uint2(0u, 0u);
-                if (v[k]) atomicAdd(&sh.sub[sort_subclass_of(v[k])], 1u);
-                if (use_segs == 1) {  // segment s of tile i starts at excl + sum of earlier segments (colbase_kernel)
-                    uint32_t r2 = excl;
+            const int i = base + k * NT + tid;
+            if (i < T) tot[i] = ovf ? 0u : v[k];
+        }
+    }
+    __syncthreads();
+    // every thread owns `per` consecutive tiles
+    const int per = (T + NT - 1) / NT, lo = tid * per, hi = min(T, lo + per);
+    uint32_t sum = 0, local_max = 0;
+#pragma unroll 1
+    for (int i = lo; i < hi; i++) { const uint32_t c = tot[i]; sum += c; local_max = max(local_max, c); }
+    const uint32_t inc = wave_incl_scan(sum, lane);
+    if (lane == 63) sh.wtot[wave] = inc;
 #pragma unroll
-                    for (int sg = 0; sg < FRG_BIN_SEGS; sg++) {
-                        const uint32_t c = seg_sums[(size_t)sg * T + i];
-                        seg_sums[(size_t)sg * T + i] = r2;
-                        r2 += c;
-                    }
-                }
+    for (int d = 32; d >= 1; d >>= 1) local_max = max(local_max, (uint32_t)__shfl_xor((int)local_max, d, 64));
+    if (lane == 0) atomicMax(&sh.maxc, local_max);
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; w++) run += sh.wtot[w];
+#pragma unroll 1
+    for (int i = lo; i < hi; i++) {
+        const uint32_t c = tot[i], excl = run;
+        run += c;
+        if (USE_SEGS || ovf) tile_count[i] = c;
+        ranges[i] = c ? make_uint2(excl, excl + c) : make_uint2(0u, 0u);
+        if (c) atomicAdd(&sh.sub[sort_subclass_of(c)], 1u);
+        if (USE_SEGS == 1) {  // segment s of tile i starts at excl + sum of earlier segments (colbase_kernel)
+            uint32_t r2 = excl;
+#pragma unroll 1
+            for (int sg = 0; sg < FRG_BIN_SEGS; sg++) {
+                const uint32_t c2 = seg_sums[(size_t)sg * T + i];
+                seg_sums[(size_t)sg * T + i] = r2;
+                r2 += c2;
             }
         }
-        __syncthreads();
-        if (tid == 0) sh.carry = carry + all;
-        __syncthreads();
     }
-    atomicMax(&sh.maxc, local_max);
     __syncthreads();
     // work lists of the sort: only non-empty tiles, grouped by size class and, inside a class,
     // by size in eight descending buckets (longest tiles are dispatched first: the last round of
     // workgroups then holds the short ones instead of a straggler)
     if (tid < FRG_SORT_CLASSES) {
-        uint32_t run = 0;
-        for (int k = 0; k < 8; k++) { const uint32_t c = sh.sub[tid * 8 + k]; sh.sub[tid * 8 + k] = run; run += c; }
-        sh.cls[tid] = run;
+        uint32_t r3 = 0;
+        for (int k = 0; k < 8; k++) { const uint32_t c = sh.sub[tid * 8 + k]; sh.sub[tid * 8 + k] = r3; r3 += c; }
+        sh.cls[tid] = r3;
     }
     __syncthreads();
-    if (single) {
-#pragma unroll
-        for (int k = 0; k < SCAN_K; k++) {
-            if (k < per && lo + k < T && v[k]) {
-                const int key = sort_subclass_of(v[k]);
-                class_tiles[(size_t)(key >> 3) * T + sh.sub[key] + atomicAdd(&sh.cur[key], 1u)] = (uint32_t)(lo + k);
-            }
-        }
-    } else {
-        for (int i = tid; i < T; i += NT) {
-            const uint32_t c = tile_count[i];
-            if (!c) continue;
-            const int key = sort_subclass_of(c);
-            class_tiles[(size_t)(key >> 3) * T + sh.sub[key] + atomicAdd(&sh.cur[key], 1u)] = (uint32_t)i;
-        }
+#pragma unroll 1
+    for (int i = tid; i < T; i += NT) {
+        const uint32_t c = tot[i];
+        if (!c) continue;
+        const int key = sort_subclass_of(c);
+        class_tiles[(size_t)(key >> 3) * T + sh.sub[key] + atomicAdd(&sh.cur[key], 1u)] = (uint32_t)i;
     }
     if (tid == 0) { counters->max_tile_count = sh.maxc; counters->tight_binning = tight; }
     if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = sh.cls[tid];
@@ -598,11 +594,13 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, bool ovf, int T, uint
 __global__ void __launch_bounds__(1024)
 scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
             uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
-            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight)
+            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight, int lds_tot)
 {
     __shared__ ScanShared sh;
+    extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (lds_tot)
     scan_chunks<1024>(sh, nchunks, block_sums, counters, capacity);
-    scan_tiles<1024>(sh, sh.ovf != 0, T, tile_count, seg_sums, use_segs, ranges, class_tiles, counters, tight);
+    if (use_segs) scan_tiles<1024, 1>(sh, scan_tot, sh.ovf != 0, T, tile_count, seg_sums, ranges, class_tiles, counters, tight);
+    else scan_tiles<1024, 0>(sh, lds_tot ? scan_tot : tile_count, sh.ovf != 0, T, tile_count, seg_sums, ranges, class_tiles, counters, tight);
 }
 
 // Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
@@ -769,7 +767,8 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
         // the counters the host reads back) -- a single workgroup's latency chain, beside the reorder instead of in
         // front of it.  Nothing in the reorder depends on it.
         __shared__ ScanShared sh;
-        scan_tiles<FRG_BIN_THREADS>(sh, counters->overflow != 0, T, tile_count, seg_sums, 2, ranges, class_tiles, counters, tight);
+        extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (dynamic LDS of this launch)
+        scan_tiles<FRG_BIN_THREADS, 2>(sh, scan_tot, counters->overflow != 0, T, tile_count, seg_sums, ranges, class_tiles, counters, tight);
         return;
     }
     __shared__ uint32_t cursor[FRG_MAX_TILE_ROWS];
@@ -985,13 +984,19 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
                            nchunks, g.block_sums, img.counters, capacity);
     if (cells) {
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
-        hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), 0, s, P, nb, img.ncells, img.band_w, img.nbands,
+        hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,
                            g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
                            img.counters, T, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g_scan_first);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
-                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity, (uint32_t)vp.tight);
+    // the tile totals sit in LDS (T words) when they fit
+    const bool lds_tot = (size_t)T * 4 <= 128 * 1024;
+    if (lds_tot) {
+        hipError_t e = allow_big_lds(scan_kernel, (size_t)T * 4);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), lds_tot ? (size_t)T * 4 : 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
+                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity, (uint32_t)vp.tight, lds_tot ? 1 : 0);
     // per-workgroup scatter bases of the scatter in the caller's order
     if (img.lds_bins)
         hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);
