@@ -190,7 +190,15 @@ __device__ __forceinline__ void wave_sync_lds()
 //   SH_DEFER   not here: sh_color_kernel computes it on a side stream while the binning stages (scan, scatter,
 //              sort -- LDS / latency bound, HBM nearly idle) run on the caller's; the blend waits for both
 enum { SH_INLINE = 0, SH_STREAM = 1, SH_DEFER = 2 };
-template <bool LDS_BINS, int SHMODE, bool TIGHT>
+// BINMODE: how the per-tile instance counts are formed.
+//   BIN_WALK   every (Gaussian, tile) instance bumps its tile's bin (walk over the wave's concatenated rectangles)
+//   BIN_TIGHT  the same walk, instances that provably touch no pixel of their tile dropped
+//   BIN_CELLS  (cell-ordered scatter) every tile of the rectangle counts, so the counts are the 2-D prefix sum of a
+//              DIFFERENCE array with four entries per Gaussian (+1 top-left, -1 right of the top-right, -1 below the
+//              bottom-left, +1 diagonal): 4 LDS atomics per Gaussian, no walk; the prefix sum is linear, so it is
+//              taken once, over the sum of all workgroups' arrays (scan_tiles).  Plus one bin per record cell.
+enum { BIN_WALK = 0, BIN_TIGHT = 1, BIN_CELLS = 2 };
+template <bool LDS_BINS, int SHMODE, int BINMODE>
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
 preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
@@ -205,6 +213,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       uint32_t* __restrict__ row_matrix, int band_w, int nbands)
 {
     constexpr bool SH16 = SHMODE == SH_STREAM;
+    constexpr bool TIGHT = BINMODE == BIN_TIGHT, CELLS = BINMODE == BIN_CELLS;
+    static_assert(!CELLS || LDS_BINS, "the cell-ordered scatter needs the LDS bins");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     __shared__ float4 sh_lds[SH16 ? (FRG_BIN_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
@@ -218,7 +228,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
     // bins [T, T + ncells): visible Gaussians by the cell (tile row, band of band_w tile columns) of their rectangle's
     // first tile (reorder_kernel's counts)
-    const int ncells = row_matrix ? vp.gy * nbands : 0;
+    const int ncells = CELLS ? vp.gy * nbands : 0;
     const int nbins = T + ncells;
     if (LDS_BINS)
         for (int t = threadIdx.x; t < nbins; t += FRG_BIN_THREADS) lds_bins[t] = 0;
@@ -243,13 +253,21 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             tiles_touched[idx] = touched;
             rx0 = x0; ry0 = y0; rw = x1 - x0;
             if (touched) {
-                if (LDS_BINS && row_matrix) atomicAdd(&lds_bins[T + y0 * nbands + x0 / band_w], 1u);
+                if (CELLS) {
+                    atomicAdd(&lds_bins[T + y0 * nbands + x0 / band_w], 1u);
+                    atomicAdd(&lds_bins[y0 * vp.gx + x0], 1u);         // unsigned wrap-around is harmless
+                    if (x1 < vp.gx) atomicAdd(&lds_bins[y0 * vp.gx + x1], 0xFFFFFFFFu);
+                    if (y1 < vp.gy) {
+                        atomicAdd(&lds_bins[y1 * vp.gx + x0], 0xFFFFFFFFu);
+                        if (x1 < vp.gx) atomicAdd(&lds_bins[y1 * vp.gx + x1], 1u);
+                    }
+                }
                 depth_rect[3 * idx] = __float_as_uint(depth);
                 depth_rect[3 * idx + 1] = (uint32_t)x0 | ((uint32_t)y0 << 16);
                 depth_rect[3 * idx + 2] = (uint32_t)x1 | ((uint32_t)y1 << 16);
             }
         }
-        {   // per-tile instance counts
+        if (!CELLS) {   // per-tile instance counts
             const int wave = threadIdx.x >> 6;
             wave_for_each_instance(touched, rx0, ry0, rw, 0u, 0u, emit_start + wave * 68, emit_info + wave * 64, vp.gx,
                                    [&](int owner, int t, int tx, int ty, uint32_t, uint32_t) {
@@ -357,7 +375,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         __syncthreads();
         uint32_t* row = bin_matrix + (size_t)blockIdx.x * T;
         for (int t = threadIdx.x; t < T; t += FRG_BIN_THREADS) row[t] = lds_bins[t];
-        if (row_matrix)
+        if (CELLS)
             for (int r = threadIdx.x; r < ncells; r += FRG_BIN_THREADS) row_matrix[(size_t)blockIdx.x * ncells + r] = lds_bins[T + r];
     }
 }
@@ -507,7 +525,7 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
 // rolled loop of a few dozen instructions.  USE_SEGS: 0 totals in tile_count | 1 sum the segments and turn them into
 // start offsets for colbase_kernel | 2 sum the segments only.
 template <int NT, int USE_SEGS>
-__device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool ovf, int T, uint32_t* __restrict__ tile_count,
+__device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool ovf, int T, int gx, uint32_t* __restrict__ tile_count,
                                            uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
                                            uint32_t* __restrict__ class_tiles, Counters* __restrict__ counters, uint32_t tight)
 {
@@ -540,6 +558,28 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
         }
     }
     __syncthreads();
+    if (USE_SEGS == 2) {
+        // the staged totals are the summed DIFFERENCE arrays of the preprocess (BIN_CELLS): instances per tile = their
+        // 2-D prefix sum, along x (one wave per tile row) and then along y (one thread per tile column)
+        const int gy = T / gx;
+        for (int row = wave; row < gy; row += NT / 64) {
+            uint32_t carry = 0;
+            for (int xb = 0; xb < gx; xb += 64) {
+                const int x = xb + lane;
+                const uint32_t v = x < gx ? tot[row * gx + x] : 0u;
+                const uint32_t inc = wave_incl_scan(v, lane) + carry;
+                if (x < gx) tot[row * gx + x] = inc;
+                carry = (uint32_t)__shfl((int)inc, 63, 64);
+            }
+        }
+        __syncthreads();
+        for (int x = tid; x < gx; x += NT) {
+            uint32_t run = tot[x];
+#pragma unroll 1
+            for (int row = 1; row < gy; row++) { run += tot[row * gx + x]; tot[row * gx + x] = run; }
+        }
+        __syncthreads();
+    }
     // every thread owns `per` consecutive tiles
     const int per = (T + NT - 1) / NT, lo = tid * per, hi = min(T, lo + per);
     uint32_t sum = 0, local_max = 0;
@@ -599,8 +639,8 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
     __shared__ ScanShared sh;
     extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (lds_tot)
     scan_chunks<1024>(sh, nchunks, block_sums, counters, capacity);
-    if (use_segs) scan_tiles<1024, 1>(sh, scan_tot, sh.ovf != 0, T, tile_count, seg_sums, ranges, class_tiles, counters, tight);
-    else scan_tiles<1024, 0>(sh, lds_tot ? scan_tot : tile_count, sh.ovf != 0, T, tile_count, seg_sums, ranges, class_tiles, counters, tight);
+    if (use_segs) scan_tiles<1024, 1>(sh, scan_tot, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight);
+    else scan_tiles<1024, 0>(sh, lds_tot ? scan_tot : tile_count, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight);
 }
 
 // Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
@@ -757,7 +797,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
                const uint32_t* __restrict__ chunk_prefix, uint32_t* __restrict__ point_offsets,
                const uint32_t* __restrict__ row_matrix, const uint32_t* __restrict__ row_total, uint4* __restrict__ row_records,
                Counters* __restrict__ counters,
-               int T, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
+               int T, int gx, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
                uint32_t* __restrict__ class_tiles, uint32_t tight, int scan_first)
 {
     const int scan_block = scan_first ? 0 : nblocks;
@@ -768,7 +808,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
         // front of it.  Nothing in the reorder depends on it.
         __shared__ ScanShared sh;
         extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (dynamic LDS of this launch)
-        scan_tiles<FRG_BIN_THREADS, 2>(sh, scan_tot, counters->overflow != 0, T, tile_count, seg_sums, ranges, class_tiles, counters, tight);
+        scan_tiles<FRG_BIN_THREADS, 2>(sh, scan_tot, counters->overflow != 0, T, gx, tile_count, seg_sums, ranges, class_tiles, counters, tight);
         return;
     }
     __shared__ uint32_t cursor[FRG_MAX_TILE_ROWS];
@@ -927,20 +967,20 @@ static hipError_t allow_big_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDS_BINS, int SHMODE, bool TIGHT>
+template <bool LDS_BINS, int SHMODE, int BINMODE>
 static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
                                      const ImageState& img, int prefiltered, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
-    const size_t lds = LDS_BINS ? (size_t)(T + (cell_order(img, vp) ? img.ncells : 0)) * 4 : 0;
-    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>, lds);
+    const size_t lds = LDS_BINS ? (size_t)(T + (BINMODE == BIN_CELLS ? img.ncells : 0)) * 4 : 0;
+    hipError_t e = allow_big_lds(preprocess_fwd_kernel<LDS_BINS, SHMODE, BINMODE>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SHMODE, TIGHT>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
+    hipLaunchKernelGGL((preprocess_fwd_kernel<LDS_BINS, SHMODE, BINMODE>), dim3(nb), dim3(FRG_BIN_THREADS), lds, s, P, vp, in.viewmatrix,
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
-                       LDS_BINS && cell_order(img, vp) ? img.row_matrix : nullptr, img.band_w, img.nbands);
+                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands);
     return hipGetLastError();
 }
 
@@ -954,11 +994,14 @@ hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& i
                                  const ImageState& img, int prefiltered, bool defer_sh, hipStream_t s)
 {
     const int mode = (defer_sh && in.shs) ? SH_DEFER : sh_streamable(in, vp) ? SH_STREAM : SH_INLINE;
-#define FRG_PRE(L, S) (vp.tight ? launch_pre_variant<L, S, true>(P, vp, in, radii, g, img, prefiltered, s) \
-                                : launch_pre_variant<L, S, false>(P, vp, in, radii, g, img, prefiltered, s))
+#define FRG_PRE(L, S) (vp.tight ? launch_pre_variant<L, S, BIN_TIGHT>(P, vp, in, radii, g, img, prefiltered, s) \
+                                : launch_pre_variant<L, S, BIN_WALK>(P, vp, in, radii, g, img, prefiltered, s))
+#define FRG_PRE_CELLS(S) launch_pre_variant<true, S, BIN_CELLS>(P, vp, in, radii, g, img, prefiltered, s)
+    if (cell_order(img, vp)) return mode == SH_DEFER ? FRG_PRE_CELLS(SH_DEFER) : mode == SH_STREAM ? FRG_PRE_CELLS(SH_STREAM) : FRG_PRE_CELLS(SH_INLINE);
     if (img.lds_bins) return mode == SH_DEFER ? FRG_PRE(true, SH_DEFER) : mode == SH_STREAM ? FRG_PRE(true, SH_STREAM) : FRG_PRE(true, SH_INLINE);
     return mode == SH_DEFER ? FRG_PRE(false, SH_DEFER) : mode == SH_STREAM ? FRG_PRE(false, SH_STREAM) : FRG_PRE(false, SH_INLINE);
 #undef FRG_PRE
+#undef FRG_PRE_CELLS
 }
 
 hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g, hipStream_t s)
@@ -986,7 +1029,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,
                            g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
-                           img.counters, T, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g_scan_first);
+                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g_scan_first);
         return hipGetLastError();
     }
     // the tile totals sit in LDS (T words) when they fit
