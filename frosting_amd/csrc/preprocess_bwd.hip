@@ -114,82 +114,116 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
     for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
     wave_fence();
-    // one batch = 64 consecutive slots of the wave's run, one per lane: owner by binary search
-    // (own_start / own_info do not change inside the loop), cutoff test, then the 36-byte row
-    auto fetch = [&](uint32_t s0, int& owner, bool& in_run, float (&part)[FRG_SLOT_FLOATS]) {
-        const uint32_t s = s0 + lane;
-        in_run = s < S;
-        owner = 0;
+    // Only a quarter of the slots were processed by the blend backward (the tiles stop at saturation); the rest hold
+    // nothing.  Two passes over windows of BWD_WIN slots of the wave's run:
+    //   A  per slot: owner by binary search over the lane offsets in LDS (own_start / own_info do not change), its
+    //      tile, the tile's cutoff key -> processed or not; the processed ones are compacted (ballot) into a list of
+    //      16-bit entries {position in the window, owner};
+    //   B  64 list entries at a time: the 36-byte rows, the segmented sum per owner, the accumulators.
+    // The nine loads and the ~130-instruction segmented scan run on a quarter of the batches instead of all of them.
+    constexpr uint32_t BWD_WIN = 896;                                   // 10 bits of position, 6 bits of owner
+    uint16_t* live = reinterpret_cast<uint16_t*>(shbuf + 96);           // [BWD_WIN] behind own_co / own_xy
+    if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
+    for (uint32_t w0 = 0; w0 < S; w0 += BWD_WIN) {
+        const uint32_t wend = min(S, w0 + BWD_WIN);
+        uint32_t nlive = 0;                                              // wave-uniform
+        // ---- A: two batches per step, so that their cutoff loads are in flight together ----
+        for (uint32_t s0 = w0; s0 < wend; s0 += 128) {
+            bool ok[2];
+            int own[2];
+            uint2 cut[2];
+            uint32_t dbits[2], gid[2];
+            bool live_lane[2], binned[2];
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const int mid = owner + step;
-            if (mid < 64 && own_start[mid] <= s) owner = mid;
+            for (int u = 0; u < 2; u++) {
+                const uint32_t sl = s0 + 64 * u + lane;
+                live_lane[u] = sl < wend;
+                int owner = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int mid = owner + step;
+                    if (mid < 64 && own_start[mid] <= sl) owner = mid;
+                }
+                own[u] = owner;
+                cut[u] = make_uint2(0u, 0u); dbits[u] = 0xFFFFFFFFu; gid[u] = 0; binned[u] = true;
+                if (live_lane[u]) {
+                    const int4 info = own_info[owner];
+                    const uint32_t k = sl - own_start[owner];
+                    uint32_t ry, rx;
+                    rect_divmod(k, (uint32_t)info.z, ry, rx);
+                    const int tx = info.x + (int)rx, ty = info.y + (int)ry;
+                    cut[u] = cutoff[ty * vp.gx + tx];
+                    dbits[u] = (uint32_t)info.w; gid[u] = (uint32_t)(idx0 + owner);
+                    if (TIGHT) { const float2 c2 = own_xy[owner]; binned[u] = tile_hit(c2.x, c2.y, own_co[owner], tx, ty); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                // processed by the blend backward iff (depth, index) <= the tile's cutoff key
+                ok[u] = live_lane[u] && binned[u] && (dbits[u] < cut[u].x || (dbits[u] == cut[u].x && gid[u] <= cut[u].y));
+                const uint64_t m = __builtin_amdgcn_ballot_w64(ok[u]);
+                if (ok[u]) live[nlive + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((s0 + 64 * u + lane - w0) | ((uint32_t)own[u] << 10));
+                nlive += (uint32_t)__popcll(m);
+            }
         }
+        wave_fence();
+        // ---- B ----
+        auto fetch = [&](uint32_t b0, int& owner, bool& in_run, float (&part)[FRG_SLOT_FLOATS]) {
+            in_run = b0 + lane < nlive;
+            owner = 64 + lane;  // unique: never merges with a neighbour
 #pragma unroll
-        for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
-        if (in_run) {
-            const int4 info = own_info[owner];
-            const uint32_t k = s - own_start[owner];
-            uint32_t ry, rx;
-            rect_divmod(k, (uint32_t)info.z, ry, rx);
-            const int tx = info.x + (int)rx, ty = info.y + (int)ry;
-            const uint2 cut = cutoff[ty * vp.gx + tx];
-            const uint32_t dbits = (uint32_t)info.w, gid = (uint32_t)(idx0 + owner);
-            bool binned = true;
-            if (TIGHT) { const float2 c2 = own_xy[owner]; binned = tile_hit(c2.x, c2.y, own_co[owner], tx, ty); }
-            // processed by the blend backward iff (depth, index) <= the tile's cutoff key
-            if (binned && (dbits < cut.x || (dbits == cut.x && gid <= cut.y))) {
-                const float* sp = slots + (size_t)(wave_base + s) * FRG_SLOT_FLOATS;
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
+            if (in_run) {
+                const uint32_t e = live[b0 + lane];
+                owner = (int)(e >> 10);
+                const float* sp = slots + (size_t)(wave_base + w0 + (e & 1023u)) * FRG_SLOT_FLOATS;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
             }
-        } else {
-            owner = 64 + lane;  // unique: never merges with a neighbour
-        }
-    };
-    // software pipeline: the next batch's cutoff and slot loads are in flight during the scan
-    int owner_n = 0;
-    bool in_run_n = false;
-    float part_n[FRG_SLOT_FLOATS];
-    if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
-    if (S > 0) fetch(0, owner_n, in_run_n, part_n);
-    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
-        int owner = owner_n;
-        const bool in_run = in_run_n;
-        float part[FRG_SLOT_FLOATS];
+        };
+        // software pipeline: the next batch's rows are in flight during the scan
+        int owner_n = 0;
+        bool in_run_n = false;
+        float part_n[FRG_SLOT_FLOATS];
+        if (nlive > 0) fetch(0, owner_n, in_run_n, part_n);
+        for (uint32_t b0 = 0; b0 < nlive; b0 += 64) {
+            int owner = owner_n;
+            const bool in_run = in_run_n;
+            float part[FRG_SLOT_FLOATS];
 #pragma unroll
-        for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = part_n[c];
-        if (s0 + 64 < S) fetch(s0 + 64, owner_n, in_run_n, part_n);
-        // Segmented inclusive scan over the lanes (owners are non-decreasing with the lane), on DPP moves:
-        // four row_shr steps inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the last lane of a
-        // row (of the lower half) into the lanes above that continue its owner's run.  A ds_bpermute shuffle
-        // costs ~24 cycles per wave on gfx950, a DPP move ~7 (tools/micro/pk_rate.hip): 60 shuffles per batch
-        // of 64 slots were the largest single item of this kernel.  A lane whose source does not exist (start
-        // of the row) or belongs to another owner multiplies what it receives by 0: fma(v, 1, p) == v + p.
-        float tk[6];
-        {
-            const int own_i = owner;
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = part_n[c];
+            if (b0 + 64 < nlive) fetch(b0 + 64, owner_n, in_run_n, part_n);
+            // Segmented inclusive scan over the lanes (owners are non-decreasing with the lane), on DPP moves:
+            // four row_shr steps inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the last lane of a
+            // row (of the lower half) into the lanes above that continue its owner's run.  A ds_bpermute shuffle
+            // costs ~24 cycles per wave on gfx950, a DPP move ~7 (tools/micro/pk_rate.hip): 60 shuffles per batch
+            // of 64 slots were the largest single item of this kernel.  A lane whose source does not exist (start
+            // of the row) or belongs to another owner multiplies what it receives by 0: fma(v, 1, p) == v + p.
+            float tk[6];
+            {
+                const int own_i = owner;
 #define FRG_SEG_STEP(I, CTRL, ROWMASK)                                                                              \
-            { const int o_up = __builtin_amdgcn_update_dpp(-1, own_i, CTRL, ROWMASK, 0xf, false);                   \
-              tk[I] = (o_up == own_i) ? 1.0f : 0.0f; }
-            FRG_SEG_STEP(0, 0x111, 0xf) FRG_SEG_STEP(1, 0x112, 0xf) FRG_SEG_STEP(2, 0x114, 0xf) FRG_SEG_STEP(3, 0x118, 0xf)
-            FRG_SEG_STEP(4, 0x142, 0xa) FRG_SEG_STEP(5, 0x143, 0xc)
+                { const int o_up = __builtin_amdgcn_update_dpp(-1, own_i, CTRL, ROWMASK, 0xf, false);                   \
+                  tk[I] = (o_up == own_i) ? 1.0f : 0.0f; }
+                FRG_SEG_STEP(0, 0x111, 0xf) FRG_SEG_STEP(1, 0x112, 0xf) FRG_SEG_STEP(2, 0x114, 0xf) FRG_SEG_STEP(3, 0x118, 0xf)
+                FRG_SEG_STEP(4, 0x142, 0xa) FRG_SEG_STEP(5, 0x143, 0xc)
 #undef FRG_SEG_STEP
-        }
+            }
 #define FRG_SEG_ADD(I, CTRL, ROWMASK)                                                                               \
-        _Pragma("unroll") for (int c = 0; c < FRG_SLOT_FLOATS; c++) {                                               \
-            const float v_up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part[c]), CTRL, ROWMASK, 0xf, false)); \
-            part[c] = __builtin_fmaf(v_up, tk[I], part[c]);                                                         \
-        }
-        FRG_SEG_ADD(0, 0x111, 0xf) FRG_SEG_ADD(1, 0x112, 0xf) FRG_SEG_ADD(2, 0x114, 0xf) FRG_SEG_ADD(3, 0x118, 0xf)
-        FRG_SEG_ADD(4, 0x142, 0xa) FRG_SEG_ADD(5, 0x143, 0xc)
+            _Pragma("unroll") for (int c = 0; c < FRG_SLOT_FLOATS; c++) {                                               \
+                const float v_up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part[c]), CTRL, ROWMASK, 0xf, false)); \
+                part[c] = __builtin_fmaf(v_up, tk[I], part[c]);                                                         \
+            }
+            FRG_SEG_ADD(0, 0x111, 0xf) FRG_SEG_ADD(1, 0x112, 0xf) FRG_SEG_ADD(2, 0x114, 0xf) FRG_SEG_ADD(3, 0x118, 0xf)
+            FRG_SEG_ADD(4, 0x142, 0xa) FRG_SEG_ADD(5, 0x143, 0xc)
 #undef FRG_SEG_ADD
-        const int o_next = __shfl_down(owner, 1, 64);
-        if (in_run && (lane == 63 || o_next != owner)) {
+            const int o_next = __shfl_down(owner, 1, 64);
+            if (in_run && (lane == 63 || o_next != owner)) {
 #pragma unroll
-            for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[owner * FRG_SLOT_FLOATS + c] += part[c];
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[owner * FRG_SLOT_FLOATS + c] += part[c];
+            }
+            wave_fence();
         }
-        wave_fence();
     }
     float part[FRG_SLOT_FLOATS];
 #pragma unroll
