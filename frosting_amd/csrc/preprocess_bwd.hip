@@ -100,17 +100,15 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     own_start[lane] = valid ? base - wave_base : S;
     if (lane == 0) own_start[64] = S;
     own_info[lane] = make_int4(x0, y0, x1 - x0, (int)__float_as_uint(g.z));
-    // tight binning: slots of instances that were never binned (tile_hit false) hold nothing; the
-    // owner's centre and conic sit in the (still unused) SH transpose buffer during this phase.
-    // The mode is the one the FORWARD that filled these buffers ran in (stamped into its counters by
-    // scan_kernel), not the process-wide option at the time of the backward: wave-uniform scalar load.
-    const bool TIGHT = __builtin_amdgcn_readfirstlane((int)counters->tight_binning) != 0;
+    // Slots of instances that provably touch no pixel of their tile (tile_hit false) hold nothing: with tight binning
+    // they were never binned, otherwise the blend backward found their quadrant mask empty and wrote zeros.  They are
+    // skipped in BOTH modes -- half of the processed slots, and the list of slots that ARE read is then the same
+    // list in both modes, so the order of the additions, hence every gradient bit, does not depend on the mode.
+    // The owner's centre and conic sit in the (still unused) SH transpose buffer during this phase.
     float4* own_co = shbuf;                                         // [64]
     float2* own_xy = reinterpret_cast<float2*>(shbuf + 64);         // [64]
-    if (TIGHT) {
-        own_co[lane] = visible ? conic_opacity[FRG_REC * idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        own_xy[lane] = make_float2(g.x, g.y);
-    }
+    own_co[lane] = visible ? conic_opacity[FRG_REC * idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    own_xy[lane] = make_float2(g.x, g.y);
 #pragma unroll
     for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
     wave_fence();
@@ -154,7 +152,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                     const int tx = info.x + (int)rx, ty = info.y + (int)ry;
                     cut[u] = cutoff[ty * vp.gx + tx];
                     dbits[u] = (uint32_t)info.w; gid[u] = (uint32_t)(idx0 + owner);
-                    if (TIGHT) { const float2 c2 = own_xy[owner]; binned[u] = tile_hit(c2.x, c2.y, own_co[owner], tx, ty); }
+                    const float2 c2 = own_xy[owner];
+                    binned[u] = tile_hit(c2.x, c2.y, own_co[owner], tx, ty);
                 }
             }
 #pragma unroll
