@@ -49,6 +49,9 @@ struct GeomState {
     // other and leave the L2 as full lines.  In the caller's (arbitrary) order every 128-byte line of the pairs array was open for the whole
     // kernel and went to HBM as 32-byte sectors: 0.49 GB written for 0.13 GB of pairs.
     uint4* row_records;
+    // d(colour)/d(view direction) of every visible Gaussian, 9 floats {ddx[3], ddy[3], ddz[3]} (ShDir, gauss_math.h):
+    // written by the forward's SH pass, read by the per-Gaussian backward instead of the SH rows
+    float* sh_dir;
     size_t bytes;
     __host__ static GeomState carve(char* base, int P)
     {
@@ -64,6 +67,7 @@ struct GeomState {
         s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);  // per chunk
         s.internal_radii = (int*)(base + o); o = align_up(o + Pp * 4, 256);
         s.row_records = (uint4*)(base + o); o = align_up(o + Pp * 16, 256);
+        s.sh_dir = (float*)(base + o); o = align_up(o + Pp * 36, 256);
         s.bytes = o;
         return s;
     }

@@ -123,4 +123,40 @@ __device__ __forceinline__ int sh_weights(int deg, float x, float y, float z, fl
     return 16;
 }
 
+// d(colour_ch)/d(dir): the share of one coefficient (basis i, value sv of the channel) in
+//   ddx = sum_i dbasis_i/dx * sh[i][ch], ddy, ddz                       (backward.cu:47-137).
+// Evaluated by the FORWARD while the coefficients pass through LDS anyway, and stored (9 floats per Gaussian,
+// GeomState::sh_dir): the backward then never reads the 192-byte SH rows again.  i is a compile-time constant at
+// every call site (unrolled), so only one case survives.
+struct ShDir {
+    float x, y, z, xx, yy, zz, xy, yz, xz;
+    int deg;
+    __device__ __forceinline__ ShDir(int deg_, float x_, float y_, float z_)
+        : x(x_), y(y_), z(z_), xx(x_ * x_), yy(y_ * y_), zz(z_ * z_), xy(x_ * y_), yz(y_ * z_), xz(x_ * z_), deg(deg_) {}
+    __device__ __forceinline__ void feed(int i, float sv, float& ddx, float& ddy, float& ddz) const
+    {
+        if (i >= 1 && i <= 3 && deg < 1) return;
+        if (i >= 4 && i <= 8 && deg < 2) return;
+        if (i >= 9 && deg < 3) return;
+        switch (i) {
+        case 1: ddy += -kSH1 * sv; break;
+        case 2: ddz += kSH1 * sv; break;
+        case 3: ddx += -kSH1 * sv; break;
+        case 4: ddx += kSH2[0] * y * sv; ddy += kSH2[0] * x * sv; break;
+        case 5: ddy += kSH2[1] * z * sv; ddz += kSH2[1] * y * sv; break;
+        case 6: ddx += kSH2[2] * 2.f * -x * sv; ddy += kSH2[2] * 2.f * -y * sv; ddz += kSH2[2] * 2.f * 2.f * z * sv; break;
+        case 7: ddx += kSH2[3] * z * sv; ddz += kSH2[3] * x * sv; break;
+        case 8: ddx += kSH2[4] * 2.f * x * sv; ddy += kSH2[4] * 2.f * -y * sv; break;
+        case 9: ddx += kSH3[0] * sv * 3.f * 2.f * xy; ddy += kSH3[0] * sv * 3.f * (xx - yy); break;
+        case 10: ddx += kSH3[1] * sv * yz; ddy += kSH3[1] * sv * xz; ddz += kSH3[1] * sv * xy; break;
+        case 11: ddx += kSH3[2] * sv * -2.f * xy; ddy += kSH3[2] * sv * (-3.f * yy + 4.f * zz - xx); ddz += kSH3[2] * sv * 4.f * 2.f * yz; break;
+        case 12: ddx += kSH3[3] * sv * -3.f * 2.f * xz; ddy += kSH3[3] * sv * -3.f * 2.f * yz; ddz += kSH3[3] * sv * 3.f * (2.f * zz - xx - yy); break;
+        case 13: ddx += kSH3[4] * sv * (-3.f * xx + 4.f * zz - yy); ddy += kSH3[4] * sv * -2.f * xy; ddz += kSH3[4] * sv * 4.f * 2.f * xz; break;
+        case 14: ddx += kSH3[5] * sv * 2.f * xz; ddy += kSH3[5] * sv * -2.f * yz; ddz += kSH3[5] * sv * (xx - yy); break;
+        case 15: ddx += kSH3[6] * sv * 3.f * (xx - yy); ddy += kSH3[6] * sv * -3.f * 2.f * xy; break;
+        default: break;
+        }
+    }
+};
+
 }  // namespace frg

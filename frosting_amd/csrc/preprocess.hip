@@ -184,6 +184,85 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// SH colour AND d(colour)/d(direction) of the wave's 64 Gaussians from the float4-streamed coefficient rows
+// (M == 16).  The wave's 64 x 48 coefficients are one contiguous stream of 768 float4: read coalesced, 16 Gaussians at
+// a time through the wave's LDS buffer (software pipeline: the next needed sub-batch is in flight while the current
+// one is consumed; sub-batches without a visible Gaussian are skipped).  A sub-batch is consumed by
+// lane = (Gaussian g of 16, channel ch): 48 of the 64 lanes work, each sums its channel's 16 coefficients in the
+// reference's left-to-right order (forward.cu:28-70: colours bit-identical) and, on the way, the three direction
+// derivatives of its channel (ShDir::feed) -- the per-Gaussian backward needs those, and with them in sh_dir it never
+// reads the 192-byte rows again.  (One Gaussian per lane used 16 of 64 lanes per sub-batch.)
+//   dirs[k * dir_stride]  a float4 per Gaussian k of the wave in LDS, written here: unit direction + visible flag
+//   sh_dir_out            global, this wave's first Gaussian: [64][9]
+// Returns this lane's own colour record (only meaningful for a visible Gaussian).
+__device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restrict__ src, int nvalid, bool touched, float3 dir,
+                                                 float4* shbuf, float4* dirs, int dir_stride, float* __restrict__ sh_dir_out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t vis = __ballot(touched);
+    if (vis == 0ull) return make_float4(0.f, 0.f, 0.f, 0.f);
+    dirs[lane * dir_stride] = make_float4(dir.x, dir.y, dir.z, touched ? 1.0f : 0.0f);
+    uint32_t need = 0;
+#pragma unroll
+    for (int h = 0; h < 64 / PRE_SUB; h++)
+        if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
+    float4 pre[PRE_SUB * 12 / 64];
+    auto issue = [&](int h) {
+#pragma unroll
+        for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
+            const int f = k * 64 + lane, gl = f / 12;
+            pre[k] = (h * PRE_SUB + gl < nvalid) ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int h = __builtin_ctz(need);
+    issue(h);
+    float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int g = lane >> 2, ch = lane & 3;
+    const float* shw = reinterpret_cast<const float*>(shbuf) + g * (PRE_ROW_F4 * 4) + ch;   // coefficient i of (g, ch) at shw[3 i]
+#pragma unroll 1
+    while (h < 64 / PRE_SUB) {
+#pragma unroll
+        for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
+            const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
+            shbuf[gl * PRE_ROW_F4 + j] = pre[k];
+        }
+        const uint32_t rest = need >> (h + 1);
+        const int hn = rest ? h + 1 + __builtin_ctz(rest) : 64 / PRE_SUB;
+        if (hn < 64 / PRE_SUB) issue(hn);
+        wave_sync_lds();
+        const float4 dv = dirs[(h * PRE_SUB + g) * dir_stride];
+        if (ch < 3 && dv.w != 0.0f) {
+            float w[16];
+            const int ncoef = sh_weights(deg, dv.x, dv.y, dv.z, w);
+            const ShDir sd(deg, dv.x, dv.y, dv.z);
+            float acc = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (i < ncoef) {
+                    const float sv = shw[3 * i];
+                    if (i == 0) acc = w[0] * sv;
+                    else if (i == 1 || i == 3) acc = acc - w[i] * sv;
+                    else acc = acc + w[i] * sv;
+                    sd.feed(i, sv, ddx, ddy, ddz);
+                }
+            }
+            reinterpret_cast<float*>(shbuf + g * PRE_ROW_F4 + 12)[ch] = acc;    // the row's pad float4: raw colour sums
+            float* o = sh_dir_out + (size_t)(h * PRE_SUB + g) * 9 + ch;
+            o[0] = ddx; o[3] = ddy; o[6] = ddz;
+        }
+        wave_sync_lds();
+        if ((lane / PRE_SUB) == h && touched) {
+            const float4 c = shbuf[(lane % PRE_SUB) * PRE_ROW_F4 + 12];
+            ShAccum sa;
+            sa.acc[0] = c.x; sa.acc[1] = c.y; sa.acc[2] = c.z;
+            mine = sa.finish();
+        }
+        wave_sync_lds();
+        h = hn;
+    }
+    return mine;
+}
+
 // SHMODE: how the SH colour of a visible Gaussian is produced.
 //   SH_INLINE  in this kernel, one strided read per coefficient (any layout)
 //   SH_STREAM  in this kernel, coefficients streamed as float4 and transposed through LDS (M == 16)
@@ -210,7 +289,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_rect,
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered,
-                      uint32_t* __restrict__ row_matrix, int band_w, int nbands)
+                      uint32_t* __restrict__ row_matrix, int band_w, int nbands, float* __restrict__ sh_dir)
 {
     constexpr bool SH16 = SHMODE == SH_STREAM;
     constexpr bool TIGHT = BINMODE == BIN_TIGHT, CELLS = BINMODE == BIN_CELLS;
@@ -286,74 +365,32 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 rec[2] = make_float4(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2],
                                                __uint_as_float(0u));
         } else if (SHMODE != SH_DEFER) {
-            float w[16];
-            const int ncoef = sh_weights(vp.D, dir.x, dir.y, dir.z, w);
-            ShAccum sa;
-            sa.acc[0] = sa.acc[1] = sa.acc[2] = 0.f;
             if (SH16) {
-                // the wave's 64 x 48 coefficients are one contiguous stream of 768 float4: read it
-                // coalesced and transpose through LDS, 16 Gaussians at a time
                 const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-                float4* shbuf = sh_lds + wave * (PRE_SUB * PRE_ROW_F4);
                 const int idx0 = c * FRG_BIN_THREADS + wave * 64;
-                const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
-                const int nvalid = min(64, P - idx0);
-                const bool wave_needs = __ballot(touched != 0) != 0ull;
-                if (wave_needs) {
-                    // sub-batches that hold a visible Gaussian (wave-uniform 4-bit mask)
-                    const uint64_t vis = __ballot(touched != 0);
-                    uint32_t need = 0;
-#pragma unroll
-                    for (int h = 0; h < 64 / PRE_SUB; h++)
-                        if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
-                    // software pipeline: the loads of the next needed sub-batch are in flight while
-                    // the current one is consumed (registers pre[] -> LDS -> per-lane rows)
-                    float4 pre[PRE_SUB * 12 / 64];
-                    auto issue = [&](int h) {
-#pragma unroll
-                        for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
-                            const int f = k * 64 + lane, gl = f / 12;
-                            pre[k] = (h * PRE_SUB + gl < nvalid) ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    };
-                    int h = __builtin_ctz(need);
-                    issue(h);
-#pragma unroll 1
-                    while (h < 64 / PRE_SUB) {
-#pragma unroll
-                        for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
-                            const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                            shbuf[gl * PRE_ROW_F4 + j] = pre[k];
-                        }
-                        const uint32_t rest = need >> (h + 1);
-                        const int hn = rest ? h + 1 + __builtin_ctz(rest) : 64 / PRE_SUB;
-                        if (hn < 64 / PRE_SUB) issue(hn);
-                        wave_sync_lds();
-                        if ((lane / PRE_SUB) == h && touched) {
-#pragma unroll
-                            for (int j = 0; j < 12; j++) {
-                                const float4 v = shbuf[(lane % PRE_SUB) * PRE_ROW_F4 + j];
-                                const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                                for (int t = 0; t < 4; t++) {
-                                    const int e = 4 * j + t, i = e / 3, ch = e % 3;
-                                    if (i < ncoef) sa.add(i, ch, w[i], vv[t]);
-                                }
-                            }
-                        }
-                        wave_sync_lds();
-                        h = hn;
-                    }
-                }
+                // the direction of every Gaussian of the wave waits in the (still empty) colour slot of its record
+                const float4 col = sh_stream_wave(vp.D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0),
+                                                  touched != 0, dir, sh_lds + wave * (PRE_SUB * PRE_ROW_F4),
+                                                  rec_lds + (wave * 64) * FRG_REC + 2, FRG_REC, sh_dir + (size_t)idx0 * 9);
+                (void)lane;
+                rec[2] = touched ? col : make_float4(0.f, 0.f, 0.f, 0.f);
             } else if (touched) {
+                float w[16];
+                const int ncoef = sh_weights(vp.D, dir.x, dir.y, dir.z, w);
+                const ShDir sd(vp.D, dir.x, dir.y, dir.z);
+                ShAccum sa;
+                sa.acc[0] = sa.acc[1] = sa.acc[2] = 0.f;
+                float dd[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // [x|y|z][channel]
                 const float* sh = shs + (size_t)idx * vp.M * 3;
 #pragma unroll
                 for (int e = 0; e < 48; e++) {
                     const int i = e / 3, ch = e % 3;
-                    if (i < ncoef) sa.add(i, ch, w[i], sh[e]);
+                    if (i < ncoef) { const float sv = sh[e]; sa.add(i, ch, w[i], sv); sd.feed(i, sv, dd[0][ch], dd[1][ch], dd[2][ch]); }
                 }
+                rec[2] = sa.finish();
+#pragma unroll
+                for (int k = 0; k < 9; k++) sh_dir[(size_t)idx * 9 + k] = dd[k / 3][k % 3];
             }
-            if (touched) rec[2] = sa.finish();
         }
         {   // the wave's 64 records leave as 3 x 64 consecutive float4
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,9 +425,11 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 template <bool SH16>
 __global__ void __launch_bounds__(SHC_THREADS)
 sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const float* __restrict__ means3D,
-                const int* __restrict__ radii, const float* __restrict__ shs, float4* __restrict__ rgb_clamped)
+                const int* __restrict__ radii, const float* __restrict__ shs, float4* __restrict__ rgb_clamped,
+                float* __restrict__ sh_dir)
 {
     __shared__ float4 sh_lds[SH16 ? (SHC_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
+    __shared__ float4 dir_lds[SH16 ? SHC_THREADS : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx0 = blockIdx.x * SHC_THREADS + wave * 64;
     const int idx = idx0 + lane;
@@ -404,64 +443,27 @@ sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const fl
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         dir = make_float3(dx / len, dy / len, dz / len);
     }
-    float w[16];
-    const int ncoef = sh_weights(D, dir.x, dir.y, dir.z, w);
-    ShAccum sa;
-    sa.acc[0] = sa.acc[1] = sa.acc[2] = 0.f;
     if (SH16) {
-        float4* shbuf = sh_lds + wave * (PRE_SUB * PRE_ROW_F4);
-        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
-        const int nvalid = min(64, P - idx0);
-        const uint64_t vis = __ballot(touched);
-        uint32_t need = 0;
-#pragma unroll
-        for (int h = 0; h < 64 / PRE_SUB; h++)
-            if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
-        float4 pre[PRE_SUB * 12 / 64];
-        auto issue = [&](int h) {
-#pragma unroll
-            for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
-                const int f = k * 64 + lane, gl = f / 12;
-                pre[k] = (h * PRE_SUB + gl < nvalid) ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        int h = __builtin_ctz(need);
-        issue(h);
-#pragma unroll 1
-        while (h < 64 / PRE_SUB) {
-#pragma unroll
-            for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
-                const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                shbuf[gl * PRE_ROW_F4 + j] = pre[k];
-            }
-            const uint32_t rest = need >> (h + 1);
-            const int hn = rest ? h + 1 + __builtin_ctz(rest) : 64 / PRE_SUB;
-            if (hn < 64 / PRE_SUB) issue(hn);
-            wave_sync_lds();
-            if ((lane / PRE_SUB) == h && touched) {
-#pragma unroll
-                for (int j = 0; j < 12; j++) {
-                    const float4 v = shbuf[(lane % PRE_SUB) * PRE_ROW_F4 + j];
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int e = 4 * j + t, i = e / 3, ch = e % 3;
-                        if (i < ncoef) sa.add(i, ch, w[i], vv[t]);
-                    }
-                }
-            }
-            wave_sync_lds();
-            h = hn;
-        }
+        const float4 col = sh_stream_wave(D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0), touched, dir,
+                                          sh_lds + wave * (PRE_SUB * PRE_ROW_F4), dir_lds + wave * 64, 1, sh_dir + (size_t)idx0 * 9);
+        if (touched) rgb_clamped[FRG_REC * idx] = col;
     } else if (touched) {
+        float w[16];
+        const int ncoef = sh_weights(D, dir.x, dir.y, dir.z, w);
+        const ShDir sd(D, dir.x, dir.y, dir.z);
+        ShAccum sa;
+        sa.acc[0] = sa.acc[1] = sa.acc[2] = 0.f;
+        float dd[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         const float* sh = shs + (size_t)idx * M * 3;
 #pragma unroll
         for (int e = 0; e < 48; e++) {
             const int i = e / 3, ch = e % 3;
-            if (i < ncoef) sa.add(i, ch, w[i], sh[e]);
+            if (i < ncoef) { const float sv = sh[e]; sa.add(i, ch, w[i], sv); sd.feed(i, sv, dd[0][ch], dd[1][ch], dd[2][ch]); }
         }
+        rgb_clamped[FRG_REC * idx] = sa.finish();
+#pragma unroll
+        for (int k = 0; k < 9; k++) sh_dir[(size_t)idx * 9 + k] = dd[k / 3][k % 3];
     }
-    if (touched) rgb_clamped[FRG_REC * idx] = sa.finish();
 }
 
 // The two single-workgroup scans of the binning stage.  Both are latency-bound: every thread owns SCAN_K CONSECUTIVE
@@ -980,7 +982,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
-                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands);
+                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir);
     return hipGetLastError();
 }
 
@@ -1009,9 +1011,9 @@ hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, con
     if (!in.shs || P <= 0) return hipSuccess;
     const dim3 grid((P + SHC_THREADS - 1) / SHC_THREADS), block(SHC_THREADS);
     if (sh_streamable(in, vp))
-        hipLaunchKernelGGL((sh_color_kernel<true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped);
+        hipLaunchKernelGGL((sh_color_kernel<true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir);
     else
-        hipLaunchKernelGGL((sh_color_kernel<false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped);
+        hipLaunchKernelGGL((sh_color_kernel<false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir);
     return hipGetLastError();
 }
 

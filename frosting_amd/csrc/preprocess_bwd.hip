@@ -51,7 +51,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
-                      RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts)
+                      RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
+                      const float* __restrict__ sh_dir)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -77,19 +78,11 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         clamp_bits = __float_as_uint(rgb_clamped[FRG_REC * idx].w);
         tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
     }
-    // SH rows (192 B per Gaussian, the largest stream of this kernel): the first sub-batch is requested NOW, so
-    // that it is in flight during the whole slot reduction instead of starting after it
-    float4 sh_pre[BWD_SUB * 12 / 64];
-    const int sh_nvalid = min(64, P - idx0);
-    auto sh_issue = [&](int h) {
-        const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12;
+    // d(colour)/d(direction) of this Gaussian, left by the forward's SH pass (GeomState::sh_dir): requested now, used
+    // after the slot reduction.  The backward does not read the 192-byte SH rows at all.
+    float shd[9];
 #pragma unroll
-        for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
-            const int f = k * 64 + lane, gl = f / 12;
-            sh_pre[k] = (h * BWD_SUB + gl < sh_nvalid) ? src[(size_t)h * BWD_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    if (SH16 && shs) sh_issue(0);
+    for (int k = 0; k < 9; k++) shd[k] = (visible && shs) ? sh_dir[(size_t)idx * 9 + k] : 0.0f;
     // ---- 1. slot reduction ------------------------------------------------------
     const uint32_t incl = valid ? point_offsets[idx] : 0u;
     const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
@@ -327,9 +320,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // ---- 4. SH path (backward.cu:20-139) ----
     if (shs && !(ablate & 2)) {
         // dL/dsh[i][ch] = wgt[i] * dRGB[ch]; the view-direction gradient needs
-        // d(colour)/d(dir) = sum_i dbasis_i/d(dir) * sh[i], accumulated per channel in ddx/ddy/ddz
+        // d(colour)/d(dir) = sum_i dbasis_i/d(dir) * sh[i]: the forward left it in sh_dir (shd)
         float wgt[16], dRGB[3] = {0.f, 0.f, 0.f};
-        float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
         const int M = vp.M;
@@ -358,67 +350,10 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
             }
         }
-        // one coefficient (basis i, channel ch, value sv) -> its share of d(colour_ch)/d(dir);
-        // i is a compile-time constant at every call site (unrolled), so only one case survives
-        auto feed = [&](int i, int ch, float sv) {
-            if (i >= 1 && i <= 3 && deg < 1) return;
-            if (i >= 4 && i <= 8 && deg < 2) return;
-            if (i >= 9 && deg < 3) return;
-            switch (i) {
-            case 1: ddy[ch] += -kSH1 * sv; break;
-            case 2: ddz[ch] += kSH1 * sv; break;
-            case 3: ddx[ch] += -kSH1 * sv; break;
-            case 4: ddx[ch] += kSH2[0] * y * sv; ddy[ch] += kSH2[0] * x * sv; break;
-            case 5: ddy[ch] += kSH2[1] * z * sv; ddz[ch] += kSH2[1] * y * sv; break;
-            case 6: ddx[ch] += kSH2[2] * 2.f * -x * sv; ddy[ch] += kSH2[2] * 2.f * -y * sv; ddz[ch] += kSH2[2] * 2.f * 2.f * z * sv; break;
-            case 7: ddx[ch] += kSH2[3] * z * sv; ddz[ch] += kSH2[3] * x * sv; break;
-            case 8: ddx[ch] += kSH2[4] * 2.f * x * sv; ddy[ch] += kSH2[4] * 2.f * -y * sv; break;
-            case 9: ddx[ch] += kSH3[0] * sv * 3.f * 2.f * xy; ddy[ch] += kSH3[0] * sv * 3.f * (xx - yy); break;
-            case 10: ddx[ch] += kSH3[1] * sv * yz; ddy[ch] += kSH3[1] * sv * xz; ddz[ch] += kSH3[1] * sv * xy; break;
-            case 11: ddx[ch] += kSH3[2] * sv * -2.f * xy; ddy[ch] += kSH3[2] * sv * (-3.f * yy + 4.f * zz - xx); ddz[ch] += kSH3[2] * sv * 4.f * 2.f * yz; break;
-            case 12: ddx[ch] += kSH3[3] * sv * -3.f * 2.f * xz; ddy[ch] += kSH3[3] * sv * -3.f * 2.f * yz; ddz[ch] += kSH3[3] * sv * 3.f * (2.f * zz - xx - yy); break;
-            case 13: ddx[ch] += kSH3[4] * sv * (-3.f * xx + 4.f * zz - yy); ddy[ch] += kSH3[4] * sv * -2.f * xy; ddz[ch] += kSH3[4] * sv * 4.f * 2.f * xz; break;
-            case 14: ddx[ch] += kSH3[5] * sv * 2.f * xz; ddy[ch] += kSH3[5] * sv * -2.f * yz; ddz[ch] += kSH3[5] * sv * (xx - yy); break;
-            case 15: ddx[ch] += kSH3[6] * sv * 3.f * (xx - yy); ddy[ch] += kSH3[6] * sv * -3.f * 2.f * xy; break;
-            default: break;
-            }
-        };
-        if (SH16) {
-            // coalesced read: the wave's 64 x 48 floats are one contiguous stream of 768 float4,
-            // transposed through LDS 16 Gaussians at a time and consumed as they arrive
-            // software pipeline: sub-batch h + 1 is in flight while sub-batch h is consumed (sub-batch 0 was
-            // requested at the top of the kernel)
-#pragma unroll 1
-            for (int h = 0; h < 64 / BWD_SUB; h++) {
-#pragma unroll
-                for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
-                    const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                    shbuf[gl * BWD_ROW_F4 + j] = sh_pre[k];
-                }
-                if (h + 1 < 64 / BWD_SUB) sh_issue(h + 1);
-                wave_fence();
-                if ((lane / BWD_SUB) == h && visible) {
-#pragma unroll
-                    for (int j = 0; j < 12; j++) {
-                        const float4 v = shbuf[(lane % BWD_SUB) * BWD_ROW_F4 + j];
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int t = 0; t < 4; t++) feed((4 * j + t) / 3, (4 * j + t) % 3, vv[t]);
-                    }
-                }
-                wave_fence();
-            }
-        } else if (visible) {
-            const float* sp = shs + (size_t)idx * M * 3;
-            const int n = min(M, 16) * 3;
-#pragma unroll
-            for (int e = 0; e < 48; e++)
-                if (e < n) feed(e / 3, e % 3, sp[e]);
-        }
         if (visible) {
-            const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
-            const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
-            const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+            const float dd0 = shd[0] * dRGB[0] + shd[1] * dRGB[1] + shd[2] * dRGB[2];
+            const float dd1 = shd[3] * dRGB[0] + shd[4] * dRGB[1] + shd[5] * dRGB[2];
+            const float dd2 = shd[6] * dRGB[0] + shd[7] * dRGB[1] + shd[8] * dRGB[2];
             // auxiliary.h:107-117 dnormvdv
             const float sum2 = dox * dox + doy * doy + doz * doz;
             const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
@@ -559,7 +494,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir)
     if (sh16) FRG_PBW(true); else FRG_PBW(false);
 #undef FRG_PBW
     return hipGetLastError();

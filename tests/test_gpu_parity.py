@@ -518,11 +518,13 @@ def test_deferred_forward_overflow_then_backward_before_finish(gpu_device):
 
 @pytest.mark.parametrize("tight", [0, 1])
 def test_full_size_image_every_binning_mode_fits_the_lds(gpu_device, tight):
-    """The LDS budget of the binning kernels depends on the number of tiles: run the full 1600x1056 grid (6600 tiles)
-    and the largest grid that still uses the LDS histograms, in both binning modes, against the C oracle."""
+    """The LDS budget of the binning kernels depends on the number of tiles: run the full 1600x1056 grid (6600 tiles),
+    the largest square grid whose tile bins AND record cells fit the LDS (1536^2: 9216 tiles + 960 cells = the limit,
+    cell-ordered scatter), one whose tile bins alone fit (1600^2: 10000 tiles, scatter in the caller's order) and one
+    beyond the LDS (1664^2: 10816 tiles, global-atomic binning), in both binning modes, against the C oracle."""
     scene, _, bg = scenes.config_scene("c2", 0, P=20_000)
     _lib.set_option("tight_binning", tight)
-    for (w, h) in [(1600, 1056), (1536, 1536)]:           # 6600 and 9216 tiles
+    for (w, h) in [(1600, 1056), (1536, 1536), (1600, 1600), (1664, 1664)]:
         cam = scenes.ring_camera(2, w, h, 1334.0, 1334.0)
         out, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
         o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 STAGE_OF = {"preprocess_fwd_kernel": "preprocess", "scan_kernel": "scan", "colsum_kernel": "scan", "colbase_kernel": "scan",
-            "scatter_kernel": "scatter", "sort_tiles": "sort", "blend_fwd_kernel": "blend_fwd",
+            "scatter_kernel": "scatter", "scatter_rows_kernel": "scatter", "reorder_kernel": "scan", "sort_tiles": "sort", "blend_fwd_kernel": "blend_fwd",
             "blend_bwd_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd"}
 
 def load(name, counter):
