@@ -304,7 +304,7 @@ size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::
 size_t frg_backward_workspace_bytes(int P, int R)
 {
     (void)P;
-    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_FLOATS * sizeof(float), 256);
+    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256);
 }
 
 void frg_geometry_layout(int P, long long* out)

@@ -366,7 +366,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             tile_rect(a.x, a.y, (int)a.w, gx, gy, x0, y0, x1, y1);
             my_slot = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
             if (m == 0) {  // provably no contribution in this tile: the slot is still owed a value
-                float* dst = slots + (size_t)my_slot * FRG_SLOT_FLOATS;
+                float* dst = slots + (size_t)my_slot * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) dst[c] = 0.0f;
             }
@@ -453,7 +453,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             // the lane that ends up with (instance, component) stores it straight into the instance's slot:
             // the nine lanes of an instance write 36 consecutive bytes
             const bool writer = half == 0 && row < BWD_BATCH * FRG_SLOT_FLOATS && k + inst < nkeep;
-            float* dst = writer ? slots + (size_t)__float_as_uint(s_rgb[k + inst].w) * FRG_SLOT_FLOATS + comp : nullptr;
+            float* dst = writer ? slots + (size_t)__float_as_uint(s_rgb[k + inst].w) * FRG_SLOT_STRIDE + comp : nullptr;
             if (!any) {              // nothing blended in this batch: its slots are still owed their zeros
                 if (writer) *dst = 0.0f;
                 continue;

@@ -10,6 +10,9 @@
 #define FRG_WAVE 64
 #define FRG_NUM_XCD 8
 #define FRG_SLOT_FLOATS 9   // per-instance backward partial: rgb(3) mean2D(2) conic(3) opacity(1)
+#ifndef FRG_SLOT_STRIDE
+#define FRG_SLOT_STRIDE 9   // floats from one instance's slot to the next in the backward workspace
+#endif
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
 #define FRG_BIN_SEGS 8           // row segments of the column scan

@@ -168,7 +168,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             if (in_run) {
                 const uint32_t e = live[b0 + lane];
                 owner = (int)(e >> 10);
-                const float* sp = slots + (size_t)(wave_base + w0 + (e & 1023u)) * FRG_SLOT_FLOATS;
+                const float* sp = slots + (size_t)(wave_base + w0 + (e & 1023u)) * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
             }
