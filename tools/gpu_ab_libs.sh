@@ -8,4 +8,4 @@ for l in ${LIBS}; do
   echo "== $l (pass $rep)"
   FROSTING_LIB=$PWD/$l timeout 600 python tools/ab.py "" ${AB_EXTRA:-} 2>&1 | grep "^\[" | cut -c1-220
 done
-done | tee gpurun_out/s5_ab.log
+done | tee gpurun_out/abl_ab.log
