@@ -196,6 +196,27 @@ def test_backward_is_bit_reproducible(gpu_device):
     assert all(torch.equal(a, c) for a, c in zip(g1, g2))
 
 
+def test_forward_is_bit_reproducible_whatever_the_scatter_order(gpu_device):
+    """The cell-ordered scatter reserves one run per (workgroup share, tile) with an atomic on the tile's fill
+    cursor: the order of the (depth, index) pairs inside a tile segment differs from run to run.  The sort's order is
+    total, so every output must not: tile lists, image, per-pixel bookkeeping and gradients of two independent runs
+    are identical bit for bit (and, in the comparisons with the reference above, identical to the reference's)."""
+    scene, cam, bg = scenes.config_scene("c3", 0, P=500_000)
+    runs = []
+    for _ in range(3):
+        out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        st = State(scene.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 11)
+        grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+        runs.append((out[0], out[1].clone(), out[2].clone(), st.point_list.clone(), st.ranges.clone(), st.n_contrib.clone(),
+                     st.final_T.clone(), [g.clone() for g in grads]))
+        del st
+    for r in runs[1:]:
+        assert r[0] == runs[0][0]
+        assert all(torch.equal(a, b) for a, b in zip(r[1:7], runs[0][1:7]))
+        assert all(torch.equal(a, b) for a, b in zip(r[7], runs[0][7]))
+
+
 def test_ragged_image_and_edge_sizes(gpu_device):
     scene, _, bg = scenes.config_scene("mini", 0, P=700)
     _lib.set_option("exact_blend", 1)
