@@ -13,17 +13,22 @@
 
 namespace frg {
 
-// Lanes of the wave holding the same 8-bit digit as this lane (invalid lanes excluded).
+// Lanes of the wave holding the same 8-bit digit as this lane (invalid lanes excluded).  Per bit: the lane's bit
+// sign-extended to a mask sb (v_bfe_i32), one ballot, and peers &= ~(ballot ^ sb) per 32-bit half (v_xnor + v_and):
+// six vector instructions.  (`peers &= bit ? m : ~m` on 64-bit values compiled to nine: the ranking is the sort's
+// instruction-bound inner loop.)
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
 {
-    uint64_t peers = __ballot(valid);
+    const uint64_t v = __builtin_amdgcn_ballot_w64(valid);
+    uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
+        const uint32_t sb = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);   // 0 or 0xFFFFFFFF
+        const uint64_t m = __builtin_amdgcn_ballot_w64(sb != 0u);
+        plo &= ~((uint32_t)m ^ sb);
+        phi &= ~((uint32_t)(m >> 32) ^ sb);
     }
-    return peers;
+    return ((uint64_t)phi << 32) | plo;
 }
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane)
