@@ -44,13 +44,13 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane)
 template <typename PtrT>
 __device__ __forceinline__ int count_ties(PtrT a, int n, int nthreads, uint32_t* scratch)
 {
-    if (threadIdx.x == 0) scratch[257] = 0;
+    if (threadIdx.x == 0) scratch[260] = 0;
     __syncthreads();
     uint32_t c = 0;
     for (int i = threadIdx.x; i < n - 1; i += nthreads) c += (a[i].x == a[i + 1].x) ? 1u : 0u;
-    if (c) atomicAdd(&scratch[257], c);
+    if (c) atomicAdd(&scratch[260], c);
     __syncthreads();
-    const int r = (int)scratch[257];
+    const int r = (int)scratch[260];
     __syncthreads();
     return r;
 }
@@ -111,35 +111,23 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
             run += c;
         }
         scratch[dg] = run;
-        if (run == (uint32_t)n) scratch[256] = 1;   // one digit holds everything: nothing to move
+        // one digit holds everything: nothing to move.  One flag per pass position (reset once per group of
+        // passes by the caller), so no barrier is spent on clearing it
+        if (run == (uint32_t)n) scratch[256 + (shift >> 3)] = 1;
     }
-    __syncthreads();
-    const bool uniform = scratch[256] != 0;
-    __syncthreads();
-    if (uniform) {
-        if (tid == 0) scratch[256] = 0;
-        __syncthreads();
-        return false;
+    __syncthreads();   // (every thread also holds its elements in registers by now: the buffer may be overwritten)
+    if (scratch[256 + (shift >> 3)] != 0) return false;
+    {   // EVERY wave scans the 256 digit totals itself (4 per lane, DPP) and adds the digit bases to its own cursor
+        // row: no single-wave scan with a barrier on either side, three workgroup barriers per pass instead of six
+        const uint32_t v0 = scratch[4 * lane], v1 = scratch[4 * lane + 1], v2 = scratch[4 * lane + 2], v3 = scratch[4 * lane + 3];
+        const uint32_t s4 = v0 + v1 + v2 + v3;
+        const uint32_t ex = wave_incl_scan_dpp(s4) - s4;
+        myhist[4 * lane] += ex; myhist[4 * lane + 1] += ex + v0;
+        myhist[4 * lane + 2] += ex + v0 + v1; myhist[4 * lane + 3] += ex + v0 + v1 + v2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (tid < 64) {  // exclusive scan of the 256 totals by one wave, 4 per lane
-        uint32_t v0 = scratch[4 * lane], v1 = scratch[4 * lane + 1], v2 = scratch[4 * lane + 2], v3 = scratch[4 * lane + 3];
-        uint32_t s = v0 + v1 + v2 + v3, inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        uint32_t ex = inc - s;
-        scratch[4 * lane] = ex; scratch[4 * lane + 1] = ex + v0;
-        scratch[4 * lane + 2] = ex + v0 + v1; scratch[4 * lane + 3] = ex + v0 + v1 + v2;
-    }
-    __syncthreads();
-    for (int dg = tid; dg < 256; dg += NT) {
-        const uint32_t base = scratch[dg];
-#pragma unroll
-        for (int w = 0; w < NWAVES; w++) whist[w * 256 + dg] += base;
-    }
-    __syncthreads();   // every thread holds its elements in registers: the buffer may be overwritten
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; it++) {
         if (begin + it * 64 >= end) break;        // wave-uniform
@@ -172,7 +160,7 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* buf = reinterpret_cast<uint2*>(smem);
     uint32_t* whist = reinterpret_cast<uint32_t*>(buf + CAP);
-    uint32_t* scratch = whist + NWAVES * 256;  // 260 words
+    uint32_t* scratch = whist + NWAVES * 256;  // 264 words: 256 digit totals, 4 uniform-pass flags, tie counter
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the grid normally covers exactly the tiles of this size class (one pass of this loop); when the
@@ -193,7 +181,7 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __
             const int i = begin + it * 64 + lane;
             e[it] = i < end ? pairs[rg.x + i] : make_uint2(0u, 0u);
         }
-        if (tid == 0) scratch[256] = 0;
+        if (tid < 4) scratch[256 + tid] = 0;
         __syncthreads();
         bool in_lds = false;
         if (n > 1) {
@@ -214,8 +202,10 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __
             if (ties > 32) {
                 // many equal depths (coplanar scenes): order by index, then by depth again -- LSD
                 // stability turns that into (depth, index)
+                if (tid < 4) scratch[256 + tid] = 0;      // (count_ties ended with a barrier; the first pass has one before the flags are used)
 #pragma unroll 1
                 for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
+                if (tid < 4) scratch[256 + tid] = 0;      // (every thread is past the last pass's flag; the next read is two barriers away)
 #pragma unroll 1
                 for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
             } else if (ties > 0) {
@@ -343,7 +333,7 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
                                    const uint2* pairs, uint32_t* point_list, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
-    const size_t lds = (size_t)CAP * 8 + NW * 1024 + 260 * 4;
+    const size_t lds = (size_t)CAP * 8 + NW * 1024 + 264 * 4;
     if (lds > 48 * 1024) {
         // the attribute is per device: remember it per device, not per process
         static std::atomic<unsigned long long> attr_set{0};
