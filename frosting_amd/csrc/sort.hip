@@ -97,7 +97,7 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
         const uint64_t peers = match_digit(d, valid);
         const uint32_t rank = lanes_below(peers, lane), cnt = (uint32_t)__popcll(peers);
         meta[it] = rank | (cnt << 8) | (d << 16);
-        if (valid && rank == 0) myhist[d] += cnt;
+        if (valid && rank == 0) atomicAdd(&myhist[d], cnt);    // ds_add_u32: no read / wait / write-back round trip
     }
     __syncthreads();
     // digit totals, exclusive over waves then over digits
@@ -136,7 +136,7 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
         uint32_t pos = 0;
         if (valid) pos = myhist[d] + rank;
         __builtin_amdgcn_wave_barrier();          // all lanes read the cursor before a leader bumps it
-        if (valid && rank == 0) myhist[d] += cnt;
+        if (valid && rank == 0) atomicAdd(&myhist[d], cnt);
         if (valid) buf[pos] = e[it];
     }
     __syncthreads();
