@@ -282,7 +282,7 @@ __device__ __forceinline__ void tile_rect(float px, float py, int max_radius, in
 // alpha < 1/255 on the whole quadrant whenever 1/2 min_rect Q > ln(255 o), the minimum taken
 // over the continuous rectangle spanned by the quadrant's pixel centres (a superset of the
 // pixels, hence conservative).  Q is convex: if the centre lies inside the rectangle the
-// minimum is 0, otherwise it sits on one of the four edges, where Q restricted to the edge is
+// minimum is 0, otherwise it sits on an edge facing the centre, where Q restricted to the edge is
 // a 1-D parabola whose clamped vertex gives the edge minimum in closed form.  Margins (0.1 %
 // relative, 0.02 absolute on a threshold <= 5.6) dominate the rounding of the per-pixel
 // evaluation (|error| <= ~1e-6 * lambda_max * d^2, lambda_max <= 1/0.3 by the low-pass,
@@ -305,16 +305,13 @@ __device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, i
     // v_rcp_f32 (1 ulp) instead of two IEEE divisions (~11 instructions each): an error of the clamped vertex
     // position enters Q at second order, far below the margins
     const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const float ex = e ? xhi : xlo;                           // vertical edge dx = ex
-        const float dy = fminf(fmaxf(-b * ex * ic, ylo), yhi);
-        best = fminf(best, a * ex * ex + 2.f * b * ex * dy + c * dy * dy);
-        const float ey = e ? yhi : ylo;                           // horizontal edge dy = ey
-        const float dx = fminf(fmaxf(-b * ey * ia, xlo), xhi);
-        best = fminf(best, a * dx * dx + 2.f * b * dx * ey + c * ey * ey);
-    }
+    // The minimiser lies on the line dx = ex or on the line dy = ey, ex / ey the rectangle's x / y closest to the
+    // centre (0 clamped into the range): from any other point of the rectangle a small step towards the centre stays
+    // inside and lowers Q.  Two clamped 1-D parabola vertices instead of the four edges.
+    const float ex = fminf(fmaxf(0.f, xlo), xhi), ey = fminf(fmaxf(0.f, ylo), yhi);
+    const float dy = fminf(fmaxf(-b * ex * ic, ylo), yhi);
+    const float dx = fminf(fmaxf(-b * ey * ia, xlo), xhi);
+    const float best = fminf(a * ex * ex + 2.f * b * ex * dy + c * dy * dy, a * dx * dx + 2.f * b * dx * ey + c * ey * ey);
     return !(0.5f * 0.999f * best > thr);
 }
 __device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx0, int qy0) { return rect_hit<7>(x, y, co, qx0, qy0); }
