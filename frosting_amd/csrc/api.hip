@@ -256,7 +256,6 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
     if (name && strcmp(name, "probe") == 0) return g_probe.exchange(value);
-    if (name && strcmp(name, "scan_first") == 0) { const int old = frg::g_scan_first; frg::g_scan_first = value ? 1 : 0; return old; }
     if (name && strcmp(name, "rows_grid") == 0) { const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old; }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");

@@ -800,11 +800,10 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
                const uint32_t* __restrict__ row_matrix, const uint32_t* __restrict__ row_total, uint4* __restrict__ row_records,
                Counters* __restrict__ counters,
                int T, int gx, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
-               uint32_t* __restrict__ class_tiles, uint32_t tight, int scan_first)
+               uint32_t* __restrict__ class_tiles, uint32_t tight)
 {
-    const int scan_block = scan_first ? 0 : nblocks;
-    const int my_block = (int)blockIdx.x - (scan_first ? 1 : 0);     // this workgroup's row of the count matrices
-    if ((int)blockIdx.x == scan_block) {
+    const int my_block = (int)blockIdx.x;     // this workgroup's row of the count matrices
+    if (my_block == nblocks) {
         // one more workgroup than the reorder needs: the scan of the tile totals (ranges, the sort's work lists,
         // the counters the host reads back) -- a single workgroup's latency chain, beside the reorder instead of in
         // front of it.  Nothing in the reorder depends on it.
@@ -949,7 +948,6 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 // ---- host launchers -----------------------------------------------------------
 // workgroups of the cell-ordered scatter (tuning knob: frg_set_option("rows_grid")), 2 per CU by default
 int g_rows_grid = 512;
-int g_scan_first = 0;   // (experiment) the tile-scan workgroup is dispatched first instead of last
 
 // The scatter runs over cell-ordered records (reorder_kernel + scatter_rows_kernel) in the reference-identical
 // binning mode; tight binning keeps the scatter in the caller's order (it would evaluate the per-instance tile test in
@@ -1031,7 +1029,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,
                            g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
-                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g_scan_first);
+                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight);
         return hipGetLastError();
     }
     // the tile totals sit in LDS (T words) when they fit
