@@ -616,7 +616,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
         FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact_blend() ? 0 : 1, g_probe_side.stream));
         FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
     }
     {
@@ -627,7 +627,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
             FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
-    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), stream), "preprocess_bwd"); }
+    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact_blend() ? 0 : 1, stream), "preprocess_bwd"); }
     return FRG_OK;
 }
 

@@ -50,7 +50,8 @@ struct BwdOutputs {
     float *dL_dshell_logits = nullptr, *dL_dshell_verts = nullptr;
 };
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
-                                 const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, hipStream_t s);
+                                 const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int tile_moments,
+                                 hipStream_t s);   // tile_moments: the slots hold moments about the tile centre (fast blend backward)
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);

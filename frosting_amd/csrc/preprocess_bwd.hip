@@ -52,7 +52,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
-                      const float* __restrict__ sh_dir)
+                      const float* __restrict__ sh_dir, int tile_moments)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -168,9 +168,27 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             if (in_run) {
                 const uint32_t e = live[b0 + lane];
                 owner = (int)(e >> 10);
-                const float* sp = slots + (size_t)(wave_base + w0 + (e & 1023u)) * FRG_SLOT_STRIDE;
+                const uint32_t sl = w0 + (e & 1023u);
+                const float* sp = slots + (size_t)(wave_base + sl) * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
+                if (tile_moments) {
+                    // the fast blend leaves the moments of v = G dL/dalpha about the TILE centre (offset (u, w) of the
+                    // pixel): with d = (Dx - u, Dy - w), (Dx, Dy) = Gaussian centre - tile centre,
+                    //   sum v dx = Dx m0 - mu,  sum v dx^2 = Dx^2 m0 - 2 Dx mu + muu,  sum v dx dy = Dx Dy m0 - Dx mw - Dy mu + muw
+                    const int4 info = own_info[owner];
+                    uint32_t ry, rx;
+                    rect_divmod(sl - own_start[owner], (uint32_t)info.z, ry, rx);
+                    const float2 c2 = own_xy[owner];
+                    const float Dx = c2.x - ((float)((info.x + (int)rx) * FRG_TILE) + 7.5f);
+                    const float Dy = c2.y - ((float)((info.y + (int)ry) * FRG_TILE) + 7.5f);
+                    const float m0 = part[8], mu = part[3], mw = part[4], muu = part[5], muw = part[6], mww = part[7];
+                    part[3] = Dx * m0 - mu;
+                    part[4] = Dy * m0 - mw;
+                    part[5] = (Dx * Dx) * m0 - 2.0f * Dx * mu + muu;
+                    part[6] = (Dx * Dy) * m0 - Dx * mw - Dy * mu + muw;
+                    part[7] = (Dy * Dy) * m0 - 2.0f * Dy * mw + mww;
+                }
             }
         };
         // software pipeline: the next batch's rows are in flight during the scan
@@ -483,7 +501,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 }
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
-                                 const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, hipStream_t s)
+                                 const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int tile_moments,
+                                 hipStream_t s)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
@@ -494,7 +513,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments)
     if (sh16) FRG_PBW(true); else FRG_PBW(false);
 #undef FRG_PBW
     return hipGetLastError();
