@@ -586,8 +586,11 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if ((means3D == nullptr) == (rw.shell_logits == nullptr)) return fail(FRG_EINVAL, "provide exactly one of means3D / shell_logits");
     if (rw.shell_logits && (!rw.shell_verts || !rw.shell_cells || !dL_dshell_logits))
         return fail(FRG_EINVAL, "shell_logits needs shell_cell_verts, shell_cells and dL_dshell_logits");
-    if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
-        return fail(FRG_EINVAL, "null gradient output");
+    if (!dL_dmean2D || !dL_dopacity || !dL_dmean3D) return fail(FRG_EINVAL, "null gradient output");
+    // intermediates of the chain may be left out when the caller has no use for them: dL_dcolor when the SH rows are
+    // written (it is then only the factor of dL_dsh), dL_dcov3D when the covariance comes from scales / rotations
+    if (!dL_dcolor && !(shs && dL_dsh)) return fail(FRG_EINVAL, "dL_dcolor may only be NULL when shs and dL_dsh are given");
+    if (!dL_dcov3D && cov3D_precomp) return fail(FRG_EINVAL, "dL_dcov3D may only be NULL without cov3D_precomp");
     if ((rw.raw_scale == nullptr) != (rw.raw_rot == nullptr)) return fail(FRG_EINVAL, "raw_scales and raw_rotations come together");
     if (((scales && (!dL_dscale || !dL_drot || !rotations))) || (rw.raw_scale && (!dL_dscale || !dL_drot)))
         return fail(FRG_EINVAL, "null gradient output for a provided input");

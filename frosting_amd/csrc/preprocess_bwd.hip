@@ -332,7 +332,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dL_dopacity[idx] = (raw.raw_opacity && visible) ? part[8] * ((1.0f - conic_opacity[FRG_REC * idx].w) * conic_opacity[FRG_REC * idx].w) : part[8];
         // with shs given and dL_dsh == nullptr the caller wants the factor of the SH gradient instead
         // (the clamp-masked colour gradient, stored below): see frg_backward in the header
-        if (!(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
+        if (dL_dcolor && !(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
     }
 
     // ---- 4. SH path (backward.cu:20-139) ----
@@ -415,7 +415,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     if (valid) {
         dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
 #pragma unroll
-        for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+        for (int i = 0; i < 6; i++) if (dL_dcov3D) dL_dcov3D[6 * idx + i] = dcov[i];
     }
     // shell-bound centres (frosting_model.py:707-724): mean = sum_k w_k v_k, w = softmax(logits).
     //   dL/dlogit_k = w_k (g_k - sum_j w_j g_j), g_k = v_k . dL/dmean          (softmax Jacobian)

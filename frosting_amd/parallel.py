@@ -282,7 +282,7 @@ class ViewParallelRasterizer:
         self.exchange = self.exchanges[0]
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.dev)
         # rank-local (not exchanged) backward outputs
-        self.dL_dmeans2D, self.dL_dcolors, self.dL_dcov3D = f(P, 3), f(P, 3), f(P, 6)
+        self.dL_dmeans2D, self.dL_dcolors = f(P, 3), f(P, 3)
         self.geom, self.binning, self.img, self.work = (_Arena(self.dev) for _ in range(4))
         self.radii = torch.empty(P, dtype=torch.int32, device=self.dev)
         self.out_color = None
@@ -375,8 +375,9 @@ class ViewParallelRasterizer:
                             _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
                             _p(self.dL_dmeans2D), None, _p(g["opacities"]),
                             # deferred SH rows: dL_dcolor receives the masked colour gradient = the exchange payload
-                            _p(ex.own_drgb) if defer_sh else _p(self.dL_dcolors),
-                            _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
+                            # (dL_dcolors is an intermediate: only the factored SH exchange reads it; dL_dcov3D likewise -- NULL)
+                            _p(ex.own_drgb) if defer_sh else (_p(self.dL_dcolors) if ex.factor_sh else None),
+                            _p(g["means3D"]), None, None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
                             _p(work), work.numel(), 0, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")

@@ -150,7 +150,9 @@ size_t frg_backward_workspace_bytes(int P, int R);
  * [P,4] = (a, b, -, c), dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3],
  * dL_dcov3D [P,6], dL_dsh [P,M,3] (ignored when shs==NULL), dL_dscale [P,3],
  * dL_drot [P,4] (ignored when scales==NULL).  dL_dconic may be NULL: it is an intermediate that the
- * reference's binding never hands to Python (rasterize_points.cu:195).  dL_dsh may be NULL with shs given: the
+ * reference's binding never hands to Python (rasterize_points.cu:195).  Two more intermediates of the chain
+ * may be NULL when the caller has no use for them (36 + 72 bytes per Gaussian less to write): dL_dcolor when shs and
+ * dL_dsh are given, dL_dcov3D when the covariance comes from scales / rotations.  dL_dsh may be NULL with shs given: the
  * SH row is then not materialised (its view-direction term still reaches dL_dmean3D) and dL_dcolor
  * receives the clamp-masked colour gradient (backward.cu:31-34), i.e. the per-Gaussian factor dRGB of
  * dL_dsh[i][ch] = basis_i * dRGB[ch], from which frg_sh_grad_from_views rebuilds the row.  Summation order is fixed, so
