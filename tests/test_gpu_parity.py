@@ -138,6 +138,30 @@ def test_lower_sh_degrees(gpu_device, deg):
     assert not dsh[:, (deg + 1) ** 2:, :].any()  # coefficients above the active degree get zero gradient
 
 
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_truncated_sh_storage(gpu_device, deg):
+    """A model that stores only (deg + 1)^2 coefficients per channel (M != 16): the per-coefficient SH path of the
+    forward, which also leaves d colour / d direction for the backward, against the C oracle -- image, dL_dsh and the
+    view-direction term inside dL_dmeans3D."""
+    scene, cam, bg = scenes.config_scene("mini", 1, P=1500)
+    M = (deg + 1) ** 2
+    scene = scenes.Scene(scene.means3D, scene.scales, scene.rotations, scene.opacities, scene.shs[:, :M, :].contiguous(), deg)
+    _lib.set_option("exact_blend", 1)
+    try:
+        out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+        assert out[0] == o["num_rendered"]
+        assert np.abs(out[1].cpu().numpy() - o["out_color"]).mean() <= 1e-6
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 6)
+        grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+        og = G.backward(o, gpix.numpy())
+        for name, g in zip(GRAD_NAMES, grads):
+            if name in ("dL_dsh", "dL_dmeans3D", "dL_dopacity", "dL_dscales"):
+                assert Hh.rel_l2(g.cpu().numpy(), og[name]) < Hh.grad_bar(name), (name, Hh.rel_l2(g.cpu().numpy(), og[name]))
+    finally:
+        _lib.set_option("exact_blend", 0)
+
+
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
 @pytest.mark.parametrize("cfg,P,view,binding", [("c2", 100_000, 0, "ext"), ("c3", 400_000, 2, "ctypes"),
                                                 ("c3", 3_000_000, 0, "ext")])
