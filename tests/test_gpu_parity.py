@@ -138,6 +138,24 @@ def test_lower_sh_degrees(gpu_device, deg):
     assert not dsh[:, (deg + 1) ** 2:, :].any()  # coefficients above the active degree get zero gradient
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_sh_colour_kernel_on_the_side_stream_changes_nothing(gpu_device, mode):
+    """Option async_sh: the SH colours (and d colour / d direction for the backward) come from sh_color_kernel on a side
+    stream instead of the preprocess.  Same arithmetic, same order: every output and gradient bit-identical."""
+    scene, cam, bg = scenes.config_scene("c2", 3, P=60_000)
+    out_a, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    gpix, _ = scenes.l1_target_grad(out_a[1].cpu(), 8)
+    g_a = _C.rasterize_gaussians_backward(*_bwd_args(args, out_a, gpix.to(gpu_device)))
+    _lib.set_option("async_sh", mode)
+    try:
+        out_b, args_b = Hh.run_ours_native(scene, cam, bg, gpu_device)
+        g_b = _C.rasterize_gaussians_backward(*_bwd_args(args_b, out_b, gpix.to(gpu_device)))
+    finally:
+        _lib.set_option("async_sh", 0)
+    assert out_a[0] == out_b[0] and torch.equal(out_a[1], out_b[1]) and torch.equal(out_a[2], out_b[2])
+    assert all(torch.equal(a, b) for a, b in zip(g_a, g_b))
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2])
 def test_truncated_sh_storage(gpu_device, deg):
     """A model that stores only (deg + 1)^2 coefficients per channel (M != 16): the per-coefficient SH path of the
