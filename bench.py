@@ -74,7 +74,16 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange path on a single-rank RCCL group when launched without torch.distributed.run")
     ap.add_argument("--sync-exchange", action="store_true",
-                    help="N>1: wait for the gradient exchange at the end of every step (no overlap with the next render)")
+                    help="N>1: plain form of the default schedule -- start the collectives behind the backward and wait for all of "
+                         "them before anything else (no overlap of the SH rebuild with the dense sum)")
+    ap.add_argument("--stale-overlap", action="store_true",
+                    help="N>1: round 2's default -- the collectives of step k are waited for in step k+2 and overlap the next "
+                         "view's render (two gradient buffers).  Only valid when the optimizer may apply one-step-stale "
+                         "gradients: a loop that updates the parameters between views needs the exchange finished first, "
+                         "which is what the default (in-step) schedule does")
+    ap.add_argument("--densify-stats", action="store_true",
+                    help="N>1: also all-reduce the densification statistics of vanilla 3DGS every step (radii MAX, "
+                         "viewspace-gradient norm and visibility count SUM; gaussian_model.py:404-407)")
     return ap.parse_args()
 
 
@@ -113,10 +122,13 @@ def pmc_traffic(stage: str, cfg_name: str, P: int):
     from frosting_amd import scenes
     if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"]:
         return None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         try:
-            return json.load(open(path))["per_launch"][stage]["hbm_bytes_corrected"]
+            per = json.load(open(path))["per_launch"]
+            if stage == "*":      # the whole op: every stage of one view
+                return {"bytes": sum(v["hbm_bytes_corrected"] for v in per.values()), "source": f"profiles/{rnd}_pmc_traffic.json"}
+            return per[stage]["hbm_bytes_corrected"]
         except Exception:
             continue
     return None
@@ -177,6 +189,68 @@ def reference_on_this_gpu(scene_d, cam_d, bg_d, gpix, backward: bool, iters: int
                     f"{iters}"}
 
 
+def side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, steps: int = 20):
+    """One of the other BASELINE configs on this GPU: ms per step over `steps` steps (wall clock between two
+    synchronisations) and the fraction of the 8 TB/s roofline of ITS algorithmic bytes (C4 adds the
+    triangle raster's 12 bytes per vertex of every face and 16 bytes per pixel, and the 9 bytes per Gaussian of the
+    mask gather)."""
+    cfg = scenes.CONFIGS[name]
+    shell = None
+    if cfg.get("kind") == "shell":
+        shell, cam, bg = scenes.config_shell_scene(name, 0)
+        scene = shell.scene
+    else:
+        scene, cam, bg = scenes.config_scene(name, 0)
+    backward = name != "c2"
+    vp = ViewParallelRasterizer(scene.to(dev), dev)
+    cam_d, bg_d = cam.to(dev), bg.to(dev)
+    ctx = M.RasterizeGLContext() if shell is not None else None
+    if shell is not None:
+        verts_d, faces_d, cell_d = shell.verts.to(dev), shell.faces.to(dev), shell.cell.to(dev)
+
+    def mask():
+        if shell is None:
+            return None
+        fm = M.visible_face_mask(verts_d, faces_d, cam_d.projmatrix, cam.image_height, cam.image_width, ctx)
+        return M.occlusion_mask_from_face_mask(cell_d, fm)
+
+    img, radii = vp.forward(cam_d, bg_d, keep_mask=mask())
+    g, _ = scenes.l1_target_grad(img.cpu(), 11)
+    g = g.to(dev)
+
+    def step():
+        vp.forward(cam_d, bg_d, keep_mask=mask())
+        if backward:
+            vp.backward(g, 0)
+
+    def timed(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return 1e3 * (time.perf_counter() - t0) / n
+    for _ in range(30):
+        step()
+    ms = timed(step, steps)
+    P, V, R = scene.P, int((radii > 0).sum()), int(vp.true_num_rendered)
+    N = cam.image_width * cam.image_height
+    T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
+    B = (312 * P + 614 * V + 160 * R + 40 * N + 8 * T) if backward else (28 * P + 311 * V + 84 * R + 20 * N + 8 * T)
+    out = {"workload": f"{name}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, " +
+                       ("forward only" if not backward else "mesh occlusion raster + cull + forward + backward" if shell else "forward+backward"),
+           "steps": steps, "ms_per_step": ms, "value": 1e3 / ms, "unit": "views/s", "visible": V, "num_rendered": R}
+    if shell is not None:
+        F = int(shell.faces.shape[0])
+        B += 12 * 3 * F + 16 * N + 9 * P
+        out["mesh_triangles"] = F
+        out["mesh_raster_ms"] = timed(mask, steps)
+        out["mesh_raster_note"] = "triangle raster + visible-face mask + per-Gaussian keep flag (the cull_mask() part of the step), timed on its own"
+    out["algorithmic_bytes_per_view"] = B
+    out["frac"] = B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
 def main():
     args = parse_args()
     self_launch_if_needed(args)
@@ -184,7 +258,7 @@ def main():
     import torch
     from frosting_amd import _lib, scenes
     from frosting_amd import mesh as M
-    from frosting_amd.parallel import ViewParallelRasterizer
+    from frosting_amd.parallel import DensificationStats, ViewParallelRasterizer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -243,23 +317,27 @@ def main():
     gpix, _ = scenes.l1_target_grad(image.cpu(), 20241022 + rank)
     gpix = gpix.to(dev)
 
-    # Software-pipelined exchange (N > 1): the collectives of step k are enqueued right behind its
-    # backward and only waited for when its gradient buffer is needed again (two buffers), so they
-    # overlap the render of step k+1.  Every step still performs its full forward, backward and
-    # exchange, and all of them have completed when the timer stops.  --sync-exchange waits at
-    # the end of every step instead.
+    # Exchange schedule (N > 1).  Default, IN-STEP: the collectives are enqueued right behind the backward and are all
+    # complete when the step ends -- what a training loop needs that updates the parameters before it renders the next
+    # view (every loop of the reference: refine.py:464-571, gaussian_splatting/train.py:79-130).  Inside the step the
+    # all-gather of the colour gradients is waited for alone and the SH rebuild it feeds runs beside the sum of the dense
+    # part.  --stale-overlap: round 2's software pipeline (the collectives of step k are waited for in step k+2 and
+    # overlap the next render; two buffers) -- valid only for one-step-stale gradients.
     counter = [0]
     exchange_on = [exchanging]
+    schedule = ["stale" if args.stale_overlap else "sync" if args.sync_exchange else "in-step"]
+    dstats = DensificationStats(P, dev, dist.group.WORLD) if (dist is not None and args.densify_stats) else None
 
     def step():
-        slot = counter[0] % 2
-        counter[0] += 1
         ex = exchange_on[0]
+        stale = ex and schedule[0] == "stale"
+        slot = counter[0] % 2 if stale else 0
+        counter[0] += 1
         vpr.forward(cam_d, bg_d, keep_mask=cull_mask())
         if not do_backward:
             vpr.finish()
             return
-        if ex and not args.sync_exchange:
+        if stale:
             # the exchange launched two steps ago on this buffer: its collectives are waited for here, its
             # SH rebuild runs on a side stream under the backward below
             vpr.prefetch_exchange(slot)
@@ -267,12 +345,16 @@ def main():
         if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
             vpr.forward(cam_d, bg_d, deferred=False, keep_mask=cull_mask())
             vpr.backward(gpix, slot)
-        if ex and not args.sync_exchange:
+        if stale:
             vpr.wait_exchange(slot)          # join the rebuild before this buffer's collectives start again
-        if ex:
             vpr.start_exchange(slot)
-            if args.sync_exchange:
-                vpr.wait_exchange(slot)
+        elif ex and schedule[0] == "sync":
+            vpr.start_exchange(slot)
+            vpr.wait_exchange(slot)
+        elif ex:
+            vpr.exchange_in_step(slot)
+        if ex and dstats is not None:
+            dstats.update(vpr.radii, vpr.dL_dmeans2D)
 
     def drain():
         if exchanging:
@@ -335,18 +417,31 @@ def main():
         dt = float(tmax.item())
 
     # ---- informative passes, all after and outside the timed region -------------------------------------------
-    compute_only = None
+    compute_only, other_schedule = None, None
     if exchanging:
-        # the same steps without the exchange: what the collectives add to a step that overlaps them
+        def max_over_ranks(x):
+            t_ = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        # the same steps without the exchange: what the collectives add to the step
         drain()
         exchange_on[0] = False
         for _ in range(3):
             step()
         dt_c, _ = timed(args.steps, with_drain=False)
         exchange_on[0] = True
-        tc = torch.tensor([dt_c], dtype=torch.float64, device=dev)
-        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-        compute_only = 1e3 * float(tc.item()) / args.steps
+        compute_only = 1e3 * max_over_ranks(dt_c) / args.steps
+        # and the other schedule, for the record (in-step <-> stale overlap)
+        mine = schedule[0]
+        schedule[0] = "in-step" if mine == "stale" else "stale"
+        for _ in range(4):
+            step()
+        drain()
+        dt_o, _ = timed(args.steps)
+        other_schedule = {"schedule": schedule[0], "ms_per_step": 1e3 * max_over_ranks(dt_o) / args.steps}
+        other_schedule["exposed_ms_per_step"] = other_schedule["ms_per_step"] - compute_only
+        drain()
+        schedule[0] = mine
     single = world == 1 and not exchanging
     tight = None
     if single and extras and not args.tight_binning:
@@ -425,6 +520,17 @@ def main():
                 "note": "scenes.make_skew_scene: half the Gaussians in four tight clusters, 400 large near-camera Gaussians"}
         del vs, sk
 
+    # BASELINE configs[1] (C2, forward only) and configs[3] (C4: triangle occlusion raster -> face mask -> culled forward
+    # + backward), 20 steps each with their own scenes, after and outside the timed region: the driver only runs the
+    # default command, so their numbers ride in the headline line
+    side = {}
+    if single and extras and args.config == "c3" and not args.points:
+        for name in ("c2", "c4"):
+            try:
+                side[name] = side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib)
+            except Exception as ex:
+                side[name] = {"error": repr(ex)}
+
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         views_per_s = world * args.steps / dt
@@ -460,10 +566,17 @@ def main():
                                      "summed SH gradient rebuilt per rank") +
                                     (", RCCL all-reduce" if args.reduce == "allreduce" else
                                      ", direct: all-to-all of 1/N shards + local sum + all-gather") +
-                                    (", synchronous" if args.sync_exchange else
-                                     ", overlapped with the next step's render (2 gradient buffers)")),
+                                    {"in-step": ", in-step schedule: complete before the step ends (valid with a parameter update between "
+                                                "views); SH rebuild beside the dense sum",
+                                     "sync": ", in-step schedule, no overlap inside the step",
+                                     "stale": ", STALE overlap: waited for two steps later, overlapping the next render (2 gradient "
+                                              "buffers; one-step-stale gradients only)"}[schedule[0]] +
+                                    (", + densification statistics (radii MAX, grad-norm / count SUM)" if dstats is not None else "")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"],
+                       "outputs_written": "all nine gradient tensors of SURVEY 8(d)'s 284 B / Gaussian except dL_dconic (an "
+                                          "intermediate the reference's binding never returns, rasterize_points.cu:195): "
+                                          "dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations",
                        "binning": "tight" if args.tight_binning else "reference-identical tile lists",
                        "counters": "deferred (no host synchronisation inside the step)" if args.deferred_counters
                                    else "blocking 48-byte read-back per forward"},
@@ -474,9 +587,10 @@ def main():
         if shell is not None:
             out["config"]["mesh_triangles"] = int(shell.faces.shape[0])
         if compute_only is not None:
-            out["exchange_timing"] = {"ms_per_step_without_exchange": compute_only,
-                                      "exposed_ms_per_step": ms_per_step - compute_only,
-                                      "note": "the same steps with the collectives switched off, timed after the timed region"}
+            out["exchange_timing"] = {"schedule": schedule[0], "ms_per_step_without_exchange": compute_only,
+                                      "exposed_ms_per_step": ms_per_step - compute_only, "other_schedule": other_schedule,
+                                      "note": "the same steps with the collectives switched off, and with the other exchange "
+                                              "schedule, both timed after the timed region"}
         if dom_ms and dom_ms > 0:
             dom = dom_stage
             ach = B[dom] / (dom_ms * 1e-3) / 1e9
@@ -494,6 +608,13 @@ def main():
             out["reference_on_mi355x"] = ref_gpu
         if skew:
             out["skew_scene"] = skew
+        out.update(side)
+        whole = pmc_traffic("*", args.config, P)
+        if whole:
+            out["op_hbm"]["measured_bytes_per_view"] = whole["bytes"]
+            out["op_hbm"]["measured_over_algorithmic"] = whole["bytes"] / total_bytes
+            out["op_hbm"]["measured_note"] = (f"sum over the stages of the HBM-side bytes per launch from the committed rocprofv3 PMC "
+                                              f"passes of this workload ({whole['source']}); below 1: L2 / Infinity-Cache reuse")
         if not args.no_cpu_baseline and world == 1 and shell is None:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, P, do_backward)

@@ -43,7 +43,21 @@ class ForwardArgs(C.Structure):
                 ("keep_mask", C.c_void_p),
                 # raw-parameter mode (activations and the shell gather inside the per-Gaussian kernels)
                 ("raw_opacities", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_rotations", C.c_void_p),
-                ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p)]
+                ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p),
+                # per-call modes: 0 = the process-wide frg_set_option value, k + 1 = value k for this call
+                ("exact_blend", C.c_int), ("tight_binning", C.c_int), ("async_sh", C.c_int),
+                ("shell_bary_mode", C.c_int)]
+
+
+def mode_fields(modes) -> dict:
+    """{'exact_blend': 0|1, 'tight_binning': 0|1, 'async_sh': 0..3} (any subset, or None) -> the per-call mode fields
+    of frg_forward_args (0 = process default, k + 1 = value k)."""
+    out = {"exact_blend": 0, "tight_binning": 0, "async_sh": 0}
+    for k, v in (modes or {}).items():
+        if k not in out:
+            raise KeyError(f"unknown per-call mode '{k}'")
+        out[k] = int(v) + 1
+    return out
 
 
 class BackwardArgs(C.Structure):
@@ -68,7 +82,8 @@ class BackwardArgs(C.Structure):
                 ("hip_stream", C.c_void_p),
                 ("raw_opacities", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_rotations", C.c_void_p),
                 ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p),
-                ("dL_dshell_logits", C.c_void_p), ("dL_dshell_cell_verts", C.c_void_p)]
+                ("dL_dshell_logits", C.c_void_p), ("dL_dshell_cell_verts", C.c_void_p),
+                ("exact_blend", C.c_int), ("shell_bary_mode", C.c_int)]
 
 
 def build(verbose: bool = False) -> str:

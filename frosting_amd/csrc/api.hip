@@ -220,7 +220,15 @@ thread_local ProbeSide g_probe_side;
         if (e_ != hipSuccess) return fail(FRG_EHIP, "stage '%s' failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
-frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_fovx, float tan_fovy, float scale_modifier)
+// Modes of one forward: each is the per-call value of frg_forward_args when given, else the process-wide option.
+struct FwdModes {
+    int exact, tight, async_sh;
+    static int pick(int field, int max_value, int fallback) { return field >= 1 && field <= max_value + 1 ? field - 1 : fallback; }
+};
+int exact_blend();
+FwdModes default_modes();
+
+frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_fovx, float tan_fovy, float scale_modifier, int tight)
 {
     (void)P;
     frg::ViewParams vp;
@@ -231,9 +239,11 @@ frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_
     vp.W = width; vp.H = height;
     vp.gx = (width + FRG_TILE - 1) / FRG_TILE; vp.gy = (height + FRG_TILE - 1) / FRG_TILE;
     vp.D = D; vp.M = M;
-    vp.tight = g_tight_binning.load();
+    vp.tight = tight;
     return vp;
 }
+
+FwdModes default_modes() { return FwdModes{exact_blend(), g_tight_binning.load(), g_async_sh.load()}; }
 
 }  // namespace
 
@@ -302,8 +312,7 @@ size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nu
 size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count).bytes; }
 size_t frg_backward_workspace_bytes(int P, int R)
 {
-    (void)P;
-    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256);
+    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256) + frg::bwd_heavy_bytes(P);
 }
 
 void frg_geometry_layout(int P, long long* out)
@@ -347,9 +356,11 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, int prefiltered,
                         float* out_color, int* radii, int debug, void* hip_stream, int capacity,
-                        const unsigned char* keep_mask = nullptr, const frg::RawInputs* raw = nullptr)
+                        const unsigned char* keep_mask = nullptr, const frg::RawInputs* raw = nullptr, const FwdModes* modes = nullptr)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
+    const FwdModes md = modes ? *modes : default_modes();
+    const int exact = md.exact;
     if (P < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (!out_color) return fail(FRG_EINVAL, "out_color is null");
     if (P == 0) {  // rasterize_points.cu:68,81: zero image, background not applied
@@ -376,7 +387,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         return fail(FRG_EINVAL, "SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(FRG_EINVAL, "null allocation callback");
 
-    const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+    const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, md.tight);
     const int T = vp.gx * vp.gy;
 
     char* geom_chunk = geometry_alloc(user, frg_geometry_bytes(P));
@@ -403,7 +414,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     // SH colours: nothing before the blend needs them, and the stages in between (scan, scatter, sort) leave the
     // HBM nearly idle -- the colour kernel (the largest single stream of the forward, 192 B per visible Gaussian)
     // runs beside them on a side stream; the blend joins it.
-    const int sh_mode = (shs != nullptr && !rw.shell_logits) ? g_async_sh.load() : 0;   // 0 inside preprocess | side stream forked after: 1 preprocess, 2 scan, 3 scatter
+    const int sh_mode = (shs != nullptr && !rw.shell_logits) ? md.async_sh : 0;   // 0 inside preprocess | side stream forked after: 1 preprocess, 2 scan, 3 scatter
     const bool defer_sh = sh_mode != 0 && g_sh_side.ensure();
     bool sh_forked = false;
     // an error return between the fork and the join must not leave the side kernel running on the caller's inputs
@@ -443,12 +454,13 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         char* bin_chunk = binning_alloc(user, frg_binning_bytes(capacity, FRG_SORT_LDS_CAP + 1));
         if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
         const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1);
+        FRG_STAGE(frg::launch_sort_plan(T, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)capacity, stream), "sort plan");
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, 0, index_bits, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, nullptr, g_pending.have_hint ? g_pending.last_class_count : nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, b.big_plan, (uint32_t)capacity, 0, index_bits, b.point_list, stream), "sort"); }
         if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
         StageScope sc_(ST_BLEND_FWD, stream);
-        if (exact_blend())
+        if (exact)
             FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
         else
             FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
@@ -471,8 +483,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
     const frg::BinningState b = frg::BinningState::carve(bin_chunk, R, max_tile);
 
-    const bool probe_fwd = (g_probe.load() & 1) && R > 0 && !exact_blend() && g_probe_side.ensure();
+    const bool probe_fwd = (g_probe.load() & 1) && R > 0 && !exact && g_probe_side.ensure();
     if (R > 0) {
+        FRG_STAGE(frg::launch_sort_plan(T, c.class_count, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream), "sort plan");
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
         if (probe_fwd) {
@@ -481,7 +494,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
             FRG_HIP(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, g_probe_side.stream));
             FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
         }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, max_tile, index_bits, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, b.big_plan, (uint32_t)R, max_tile, index_bits, b.point_list, stream), "sort"); }
         if (probe_fwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return R; }
     } else {
         // point_offsets must still be defined for backward
@@ -491,7 +504,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
     {
         StageScope sc_(ST_BLEND_FWD, stream);
-        if (exact_blend())
+        if (exact)
             FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
         else
             FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
@@ -528,22 +541,34 @@ int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc
 
 int frg_forward_ex(const frg_forward_args* a)
 {
-    // two generations of the struct: up to keep_mask (version 1 callers), or with the raw-parameter fields
-    const size_t v1 = offsetof(frg_forward_args, raw_opacities);
-    if (!a || (a->struct_size != sizeof(frg_forward_args) && a->struct_size != v1))
-        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu (or %zu)", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_forward_args), v1);
+    // three generations of the struct: up to keep_mask (version 1 callers), with the raw-parameter fields, with the
+    // per-call modes
+    const size_t v1 = offsetof(frg_forward_args, raw_opacities), v2 = offsetof(frg_forward_args, exact_blend);
+    if (!a || (a->struct_size != sizeof(frg_forward_args) && a->struct_size != v1 && a->struct_size != v2))
+        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu (or %zu, %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_forward_args), v2, v1);
     if (a->instance_capacity < 0) return fail(FRG_EINVAL, "instance_capacity < 0");
     frg::RawInputs rw;
-    if (a->struct_size == sizeof(frg_forward_args)) {
+    if (a->struct_size >= v2) {
         rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
         rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
+    }
+    FwdModes md = default_modes();
+    if (a->struct_size == sizeof(frg_forward_args)) {
+        if (a->exact_blend < 0 || a->exact_blend > 2 || a->tight_binning < 0 || a->tight_binning > 2 || a->async_sh < 0 ||
+            a->async_sh > 4 || a->shell_bary_mode < 0 || a->shell_bary_mode > 1)
+            return fail(FRG_EINVAL, "frg_forward_args: mode out of range (exact_blend %d, tight_binning %d, async_sh %d, shell_bary_mode %d)",
+                        a->exact_blend, a->tight_binning, a->async_sh, a->shell_bary_mode);
+        md.exact = FwdModes::pick(a->exact_blend, 1, md.exact);
+        md.tight = FwdModes::pick(a->tight_binning, 1, md.tight);
+        md.async_sh = FwdModes::pick(a->async_sh, 3, md.async_sh);
+        rw.bary_mode = a->shell_bary_mode;
     }
     return forward_impl(a->geometry_alloc, a->binning_alloc, a->image_alloc, a->user, a->P, a->D, a->M, a->background,
                         a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales,
                         a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->cam_pos,
                         a->tan_fovx, a->tan_fovy, a->prefiltered, a->out_color, a->radii,
-                        a->instance_capacity > 0 ? 0 : a->debug, a->hip_stream, a->instance_capacity, a->keep_mask, &rw);
+                        a->instance_capacity > 0 ? 0 : a->debug, a->hip_stream, a->instance_capacity, a->keep_mask, &rw, &md);
 }
 
 int frg_forward_finish(const char* image_buffer, int prefiltered, int* num_rendered)
@@ -576,9 +601,10 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  char* workspace, size_t workspace_bytes, int debug, void* hip_stream,
-                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts)
+                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
+    const int exact = FwdModes::pick(exact_mode, 1, exact_blend());
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
     if (P == 0) return FRG_OK;
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !viewmatrix || !projmatrix || !campos)
@@ -602,12 +628,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     // backward reads is carved from (P, W, H, R) alone (the option-dependent matrices of the binning stage
     // come last in the image chunk), and the kernels take the forward's binning mode from the counters it
     // stamped.  "exact_blend" only selects the arithmetic of this backward's own blend pass.
-    frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
-    vp.tight = 0;
+    frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, 0);
     const frg::GeomState g = frg::GeomState::carve(geom_buffer, P);
     const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, false);
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
+    uint32_t* heavy = reinterpret_cast<uint32_t*>(workspace + frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256));
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
@@ -619,18 +645,18 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
         FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact_blend() ? 0 : 1, g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, heavy, g_probe_side.stream));
         FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
     }
     {
         StageScope sc_(ST_BLEND_BWD, stream);
-        if (exact_blend())
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
+        if (exact)
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), heavy, stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), heavy, stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
-    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact_blend() ? 0 : 1, stream), "preprocess_bwd"); }
+    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, heavy, stream), "preprocess_bwd"); }
     return FRG_OK;
 }
 
@@ -654,18 +680,26 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
 
 int frg_backward_ex(const frg_backward_args* a)
 {
-    if (!a || a->struct_size != sizeof(frg_backward_args))
-        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_backward_args));
+    const size_t b1 = offsetof(frg_backward_args, exact_blend);
+    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1))
+        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_backward_args), b1);
     frg::RawInputs rw;
     rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
     rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
+    int exact_mode = 0;
+    if (a->struct_size == sizeof(frg_backward_args)) {
+        if (a->exact_blend < 0 || a->exact_blend > 2 || a->shell_bary_mode < 0 || a->shell_bary_mode > 1)
+            return fail(FRG_EINVAL, "frg_backward_args: mode out of range (exact_blend %d, shell_bary_mode %d)", a->exact_blend, a->shell_bary_mode);
+        exact_mode = a->exact_blend;
+        rw.bary_mode = a->shell_bary_mode;
+    }
     return backward_impl(a->P, a->D, a->M, a->R, a->background, a->width, a->height, a->means3D, a->shs, a->colors_precomp,
                          a->scales, a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos,
                          a->tan_fovx, a->tan_fovy, a->radii, a->geom_buffer, a->binning_buffer, a->image_buffer, a->dL_dpix,
                          a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh,
                          a->dL_dscale, a->dL_drot, a->workspace, a->workspace_bytes, a->debug, a->hip_stream, rw,
-                         a->dL_dshell_logits, a->dL_dshell_cell_verts);
+                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode);
 }
 
 int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,

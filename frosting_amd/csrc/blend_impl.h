@@ -137,12 +137,18 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
     const bool inside = px < W && py < H;
-    bool done = !inside;
+    // 1 while the pixel still blends, 0 once it has stopped (forward.cu:347-351) or lies outside the image.  A FLOAT
+    // factor of alpha rather than a boolean in the three tests: a finished pixel then fails the alpha test by itself
+    // (alpha * 1 == alpha exactly), and the per-lane state costs one v_cndmask instead of scalar mask arithmetic --
+    // rocprofv3 counted 0.73 scalar instructions per vector instruction in this kernel, most of them the exec-mask
+    // bookkeeping of a loop that every lane left on its own (`for (...; !done && ...)`), and the CU's four SIMDs
+    // share one scalar unit.  The trip count below is the wave's; the wave leaves when its last pixel is done.
+    float alive = inside ? 1.0f : 0.0f;
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
 
     for (int base = 0; base < n; base += 64) {
-        if (wave_ballot(!done) == 0ull) break;   // this quadrant is saturated
+        if (wave_ballot(alive != 0.0f) == 0ull) break;   // this quadrant is saturated
         const int cnt = min(64, n - base);
         bool hit = false;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
@@ -163,26 +169,25 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             s_rgb[d] = col;
         }
         wave_lds_sync();
-        for (int j = 0; !done && j < nkeep; j++) {
+        for (int j = 0; j < nkeep; j++) {
             const float4 ga = s_a[j];
             const float4 gco = s_co[j];
             float dx, dy;
             const float power = M::power(ga.x, ga.y, gco, pxf, pyf, dx, dy);
             // ONE divergence level for the reference's three tests (forward.cu:335-351): a wave almost
-            // never has all 64 pixels fail the same test, so nested branches skipped nothing and cost
-            // ~20 scalar exec-mask instructions per entry on the CU's single scalar unit, which was as
-            // busy as the vector ALUs (0.31 -> 0.27 ms)
+            // never has all 64 pixels fail the same test, so nested branches skipped nothing
             const float alpha = fminf(0.99f, gco.w * M::expo(power));
-            const bool skip = (power > 0.0f) | (alpha < 1.0f / 255.0f);
+            const bool keep_px = !(power > 0.0f) & !(alpha * alive < 1.0f / 255.0f);
             const float test_T = M::attenuate(Tr, alpha);
-            const bool stop = !skip & (test_T < 0.0001f);
-            done |= stop;
-            if (!skip & !stop) {
+            const bool stop = keep_px & (test_T < 0.0001f);
+            alive = stop ? 0.0f : alive;
+            if (keep_px & !stop) {
                 const float4 gc = s_rgb[j];
                 M::accumulate(gc, alpha, Tr, C0, C1, C2);
                 Tr = test_T;
                 last = __float_as_uint(ga.w);
             }
+            if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
         }
     }
 
@@ -209,8 +214,10 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
 // bucket, deepest first) inside their XCD band -- neighbouring tiles still share an L2 -- and dealt
 // to workgroups band-major, so workgroup b (XCD b % 8) takes the (b / 8)-th deepest tile of its band.
 static __global__ void __launch_bounds__(1024)
-bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order)
+bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order,
+                 uint32_t* __restrict__ heavy_count)
 {
+    if (threadIdx.x == 0 && heavy_count) *heavy_count = 0;   // hand-over list of the per-Gaussian backward (preprocess_bwd.hip)
     __shared__ uint32_t base[FRG_NUM_XCD * 64], cur[FRG_NUM_XCD * 64];
     const int tid = threadIdx.x;
     if (tid < FRG_NUM_XCD * 64) { base[tid] = 0; cur[tid] = 0; }
@@ -290,6 +297,11 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     __shared__ float4 s_a[64];     // x, y, quadrant mask, 0-based list position
     __shared__ float4 s_co[64];
     __shared__ float4 s_rgb[64];   // r, g, b, Gaussian-major slot index
+    // Reduction matrix, one column per lane.  (Measured in round 3, both slower: rows padded to 68 floats make the
+    // eight ds_read_b128 conflict-free -- 32 instead of 56 LDS cycles per batch in the bank model of
+    // MI355X_MICROARCH.md -- but 16 workgroups x 10 416 B no longer fit the CU's 160 KiB and the 16th wave per CU
+    // is worth more than the conflicts: 0.389 -> 0.407 ms; an XOR swizzle of the chunks by the row number keeps
+    // the size but needs eight address registers: 130 VGPRs, three waves per SIMD.)
     __shared__ __attribute__((aligned(16))) float s_red[BWD_BATCH * FRG_SLOT_FLOATS * 64];   // reduction matrix, one column per lane
 
     // Per-pixel state of the back-to-front walk.  The reference carries the colour

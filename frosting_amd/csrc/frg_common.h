@@ -171,11 +171,46 @@ struct ImageState {
 
 // ---- binning chunk --------------------------------------------------------
 #define FRG_SORT_LDS_CAP 8192   // largest tile list sorted entirely in LDS
+// lists of FRG_SORT_LDS_CAP + 1 .. FRG_SORT_MID_MAX entries: sorted chunks of FRG_SORT_CHUNK entries, every
+// FRG_SORT_SAMPLE-th entry a sample, splitters from the sorted samples (sort.hip); longer lists: global LSD passes
+#define FRG_SORT_CHUNK FRG_SORT_LDS_CAP
+#define FRG_SORT_SAMPLE 64
+#define FRG_SORT_MID_MAX (FRG_SORT_CHUNK * (FRG_SORT_CHUNK / FRG_SORT_SAMPLE / 2))   // 64 chunks: 524288 entries, 8192 samples
+
+// Work lists and tables of the splitter sort (uint32 words at BinningState::big_plan):
+//   hdr[0] chunk work items  hdr[1] buckets queued so far  hdr[2] lists planned  hdr[3] diagnostics
+//   chunks   uint2 {list, chunk}              one per chunk of every long list: at most R / CHUNK + #lists
+//   buckets  uint4 {list, bucket, first output position inside the list, entries}: a list of m chunks has at most
+//            128 m / (128 - m) + 1 buckets: fewer than n / 4064 + 1
+//   lists    uint4 {tile, table offset, m, buckets}
+//   tables   pos[bucket][chunk] = entries of the chunk at or below the bucket's upper splitter: buckets * m <= 129 m words
+struct BigPlan {
+    uint32_t* hdr; uint2* chunks; uint4* buckets; uint4* lists; uint32_t* tables;
+    __host__ __device__ static size_t max_lists(size_t R) { return R / FRG_SORT_CHUNK + 1; }
+    __host__ __device__ static size_t words(size_t R)
+    {
+        const size_t nl = max_lists(R);
+        return 64 + 2 * (2 * nl + 2) + 4 * (4 * nl + 4) + 4 * (nl + 1) + 129 * 2 * nl + 64;
+    }
+    __host__ __device__ static BigPlan carve(uint32_t* base, size_t R)
+    {
+        BigPlan p;
+        const size_t nl = max_lists(R);
+        p.hdr = base;
+        p.chunks = reinterpret_cast<uint2*>(base + 64);
+        p.buckets = reinterpret_cast<uint4*>(base + 64 + 2 * (2 * nl + 2));
+        p.lists = p.buckets + (4 * nl + 4);
+        p.tables = reinterpret_cast<uint32_t*>(p.lists + (nl + 1));
+        return p;
+    }
+};
+
 struct BinningState {
     uint32_t* point_list;    // sorted Gaussian indices, tile-major
     uint2* pairs;            // (depth bits, index), tile-major, scatter order
-    uint2* pairs_tmp;        // ping-pong buffer, only when some tile exceeds the LDS capacity
-    uint32_t* big_hist;      // digit counters of the multi-workgroup sort of those tiles: one 256-entry row per 1024 elements
+    uint2* pairs_tmp;        // second pair buffer (sorted chunks / ping-pong), only when some tile exceeds the LDS capacity
+    uint32_t* big_hist;      // digit counters of the LSD sort of lists beyond FRG_SORT_MID_MAX: one 256-entry row per 1024 elements
+    uint32_t* big_plan;      // BigPlan of the splitter sort
     size_t bytes;
     // rows of big_hist: row r of the tile whose list starts at element x has the id (x >> 10) + (x >> 13) + r --
     // unique and increasing, because only lists longer than 8192 = 2^13 entries own rows
@@ -190,9 +225,14 @@ struct BinningState {
         s.pairs = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
         s.pairs_tmp = nullptr;
         s.big_hist = nullptr;
+        s.big_plan = nullptr;
         if (max_tile_count > FRG_SORT_LDS_CAP) {
             s.pairs_tmp = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
-            s.big_hist = (uint32_t*)(base + o); o = align_up(o + big_hist_rows(Rr) * 256 * 4, 256);
+            s.big_plan = (uint32_t*)(base + o); o = align_up(o + BigPlan::words(Rr) * 4, 256);
+            // (the deferred-counters forward passes FRG_SORT_LDS_CAP + 1: "unknown" -- sized for every path)
+            if (max_tile_count > FRG_SORT_MID_MAX || max_tile_count == FRG_SORT_LDS_CAP + 1) {
+                s.big_hist = (uint32_t*)(base + o); o = align_up(o + big_hist_rows(Rr) * 256 * 4, 256);
+            }
         }
         s.bytes = o;
         return s;

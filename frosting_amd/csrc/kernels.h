@@ -26,11 +26,16 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // class_count: host copy of the per-class tile counts, or nullptr when they are only known on the
 // device (deferred-counters forward) -- grid_hint[] then sizes the launches and the workgroups
 // stride over the device-side lists (class_count_dev), whatever their true length.
-// big_hist: digit counters of the multi-workgroup sort (lists longer than the LDS capacity); max_tile_count: longest
-// list (0: unknown, kernels stride); index_bits: bits needed for a Gaussian index (tie order = ascending index)
+// big_plan / big_hist: BinningState's scratch of the two sorts of lists longer than the LDS capacity (R: the instance
+// count the binning chunk was carved with); max_tile_count: longest list (0: unknown, kernels stride); index_bits:
+// bits needed for a Gaussian index (tie order = ascending index)
+// to be called before launch_scatter (same arguments as launch_tile_sort's): plans the sort of the long lists
+hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
+                            const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream);
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
                             const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
-                            uint32_t* big_hist, int max_tile_count, int index_bits, uint32_t* point_list, hipStream_t stream);
+                            uint32_t* big_hist, uint32_t* big_plan, uint32_t R, int max_tile_count, int index_bits,
+                            uint32_t* point_list, hipStream_t stream);
 
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                   const float* bg, float* out_color, hipStream_t s);
@@ -38,9 +43,9 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
                                  const float* bg, float* out_color, hipStream_t s);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
+                                  const float* bg, const float* dL_dpix, float* slots, int batch, uint32_t* heavy, hipStream_t s);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
+                                 const float* bg, const float* dL_dpix, float* slots, int batch, uint32_t* heavy, hipStream_t s);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
@@ -49,9 +54,13 @@ struct BwdOutputs {
     // [F,6,3] is ACCUMULATED into (caller zeroes it): the learnable shell of learn_shell = True
     float *dL_dshell_logits = nullptr, *dL_dshell_verts = nullptr;
 };
+// tile_moments: the slots hold moments about the tile centre (fast blend backward); heavy: bwd_heavy_bytes(P) of
+// the backward workspace behind the slots -- hand-over list of the waves whose Gaussians own too many slots, zeroed by
+// the blend backward's launch (bwd_order_kernel)
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int tile_moments,
-                                 hipStream_t s);   // tile_moments: the slots hold moments about the tile centre (fast blend backward)
+                                 uint32_t* heavy, hipStream_t s);
+size_t bwd_heavy_bytes(int P);
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);

@@ -29,6 +29,14 @@ namespace frg {
 #define BWD_SUB 16                       // Gaussians per SH transpose step
 #define BWD_ROW_F4 13                    // 12 float4 of SH + 1 pad (odd stride: conflict-free b128)
 #define BWD_LDS_WORDS (68 + 256 + 576 + BWD_SUB * BWD_ROW_F4 * 4)
+// Slots are reduced in WINDOWS of BWD_WIN slots of the wave's run; a wave whose 64 Gaussians own more than
+// BWD_HEAVY_WINDOWS windows (a handful of near-camera Gaussians covering hundreds of tiles each: one wave walked
+// 38 000 slots while the average wave has 400, and the kernel waited for it -- 0.99 instead of 0.28 ms on the
+// clustered scene) hands its Gaussians to a second launch in which a whole 16-wave workgroup takes the windows
+// 16 at a time.  Per-window sums are added in window order in both forms: the same bits either way.
+#define BWD_WIN 896u                     // 10 bits of position, 6 bits of owner
+#define BWD_HEAVY_WINDOWS 4u
+#define BWD_HEAVY_WAVES 16
 
 __device__ __forceinline__ void wave_fence()
 {
@@ -37,8 +45,8 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool SH16>
-__global__ void __launch_bounds__(BWD_THREADS, 4)
+template <bool SH16, bool HEAVY>
+__global__ void __launch_bounds__(HEAVY ? BWD_HEAVY_WAVES * 64 : BWD_THREADS, 4)
 preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ cam_pos,
                       const float* __restrict__ means3D, const int* __restrict__ radii,
@@ -52,17 +60,22 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
-                      const float* __restrict__ sh_dir, int tile_moments)
+                      const float* __restrict__ sh_dir, int tile_moments, uint32_t* __restrict__ heavy)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(BWD_THREADS / 64) * BWD_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* lds = lds_all + wave * BWD_LDS_WORDS;
     uint32_t* own_start = lds;                                   // [65] slot start relative to the wave's first slot
     int4* own_info = reinterpret_cast<int4*>(lds + 68);          // [64] x0, y0, rect width, depth bits
-    float* acc = reinterpret_cast<float*>(lds + 68 + 256);       // [64][9]
+    float* wacc = reinterpret_cast<float*>(lds + 68 + 256);      // [64][9] per-owner sums of the current window
     float4* shbuf = reinterpret_cast<float4*>(lds + 68 + 256 + 576);  // [BWD_SUB][BWD_ROW_F4]
 
-    const int idx0 = blockIdx.x * BWD_THREADS + wave * 64;       // first Gaussian of this wave
+    // heavy[0] = number of handed-over waves, heavy[1 + k] = their wave numbers (zeroed by bwd_order_kernel)
+  uint32_t heavy_item = HEAVY ? blockIdx.x : 0u;
+  if (HEAVY && heavy_item >= heavy[0]) return;                  // (usually: nothing was handed over)
+  do {   // HEAVY: the workgroup strides over the handed-over waves; otherwise once
+    if (HEAVY && heavy_item != blockIdx.x) __syncthreads();     // the previous item's LDS contents are dead
+    const int idx0 = HEAVY ? (int)heavy[1 + heavy_item] * 64 : (int)blockIdx.x * BWD_THREADS + wave * 64;       // first Gaussian of this wave
     const int idx = idx0 + lane;
     const bool valid = idx < P;
     ViewMats vmx;
@@ -102,8 +115,9 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     float2* own_xy = reinterpret_cast<float2*>(shbuf + 64);         // [64]
     own_co[lane] = visible ? conic_opacity[FRG_REC * idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     own_xy[lane] = make_float2(g.x, g.y);
+    float part[FRG_SLOT_FLOATS];                                  // this lane's Gaussian: sum over the windows, in window order
 #pragma unroll
-    for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
+    for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = 0.0f;
     wave_fence();
     // Only a quarter of the slots were processed by the blend backward (the tiles stop at saturation); the rest hold
     // nothing.  Two passes over windows of BWD_WIN slots of the wave's run:
@@ -112,10 +126,20 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     //      16-bit entries {position in the window, owner};
     //   B  64 list entries at a time: the 36-byte rows, the segmented sum per owner, the accumulators.
     // The nine loads and the ~130-instruction segmented scan run on a quarter of the batches instead of all of them.
-    constexpr uint32_t BWD_WIN = 896;                                   // 10 bits of position, 6 bits of owner
     uint16_t* live = reinterpret_cast<uint16_t*>(shbuf + 96);           // [BWD_WIN] behind own_co / own_xy
     if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
-    for (uint32_t w0 = 0; w0 < S; w0 += BWD_WIN) {
+    const uint32_t nwin = (S + BWD_WIN - 1) / BWD_WIN;                   // wave-uniform
+    if (!HEAVY && nwin > BWD_HEAVY_WINDOWS && heavy) {                   // hand the 64 Gaussians to the second launch
+        if (lane == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)(idx0 >> 6);
+        return;
+    }
+    // HEAVY: round r gives window 16 r + wave to this wave; non-heavy: window after window
+    for (uint32_t wr = 0; wr < (HEAVY ? (nwin + BWD_HEAVY_WAVES - 1) / BWD_HEAVY_WAVES : nwin); wr++) {
+        const uint32_t w0 = (HEAVY ? wr * BWD_HEAVY_WAVES + (uint32_t)wave : wr) * BWD_WIN;
+#pragma unroll
+        for (int c = 0; c < FRG_SLOT_FLOATS; c++) wacc[lane * FRG_SLOT_FLOATS + c] = 0.0f;
+        wave_fence();
+      if (w0 < S) {
         const uint32_t wend = min(S, w0 + BWD_WIN);
         uint32_t nlive = 0;                                              // wave-uniform
         // ---- A: two batches per step, so that their cutoff loads are in flight together ----
@@ -160,7 +184,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
         wave_fence();
         // ---- B ----
-        auto fetch = [&](uint32_t b0, int& owner, bool& in_run, float (&part)[FRG_SLOT_FLOATS]) {
+        auto fetch = [&](uint32_t b0, int& owner, bool& in_run, float (&part)[FRG_SLOT_FLOATS]) {   // (part: the batch's rows, not the outer totals)
             in_run = b0 + lane < nlive;
             owner = 64 + lane;  // unique: never merges with a neighbour
 #pragma unroll
@@ -230,14 +254,29 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             const int o_next = __shfl_down(owner, 1, 64);
             if (in_run && (lane == 63 || o_next != owner)) {
 #pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) acc[owner * FRG_SLOT_FLOATS + c] += part[c];
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) wacc[owner * FRG_SLOT_FLOATS + c] += part[c];
             }
             wave_fence();
         }
-    }
-    float part[FRG_SLOT_FLOATS];
+      }
+        // the window's sums join the totals in window order
+        if (HEAVY) {
+            __syncthreads();
+            if (wave == 0)
+                for (uint32_t j = 0; j < BWD_HEAVY_WAVES && (wr * BWD_HEAVY_WAVES + j) * BWD_WIN < S; j++) {
+                    const float* wj = reinterpret_cast<const float*>(lds_all + j * BWD_LDS_WORDS + 68 + 256);
 #pragma unroll
-    for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = acc[lane * FRG_SLOT_FLOATS + c];
+                    for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] += wj[lane * FRG_SLOT_FLOATS + c];
+                }
+            __syncthreads();
+        } else {
+            wave_fence();
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] += wacc[lane * FRG_SLOT_FLOATS + c];
+            wave_fence();
+        }
+    }
+    if (HEAVY && wave != 0) continue;      // (workgroup-level loop over the handed-over waves; wave 0 does the per-Gaussian part)
     // The blend backward stores pixel MOMENTS of v = G dL/dalpha per (tile, Gaussian): sum v dx, v dy, v dx^2,
     // v dx dy, v dy^2, v.  The map to the reference's terms (backward.cu:536-554: dL/dG = o dL/dalpha,
     // dG/d(delta) = -G (a dx + b dy, c dy + b dx), d(delta)/d(NDC) = (W/2, H/2)) is linear with per-GAUSSIAN
@@ -417,14 +456,15 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
         for (int i = 0; i < 6; i++) if (dL_dcov3D) dL_dcov3D[6 * idx + i] = dcov[i];
     }
-    // shell-bound centres (frosting_model.py:707-724): mean = sum_k w_k v_k, w = softmax(logits).
+    // shell-bound centres (frosting_model.py:707-724): mean = sum_k w_k v_k, w = softmax(logits) or relu(x) / sum relu(x).
     //   dL/dlogit_k = w_k (g_k - sum_j w_j g_j), g_k = v_k . dL/dmean          (softmax Jacobian)
+    //   dL/dx_k     = [x_k > 0] (g_k - sum_j w_j g_j) / sum relu(x)            (relu + renormalise)
     //   dL/dv_k    += w_k dL/dmean                                              (learnable shell, learn_shell = True)
     if (raw.shell_logits && valid) {
         float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (visible) {
             float w[6], gk[6];
-            raw_softmax6(raw.shell_logits + 6 * (size_t)idx, w);
+            raw_bary6(raw, idx, w);
             const size_t cell = (size_t)raw.shell_cells[idx];
             const float* v = raw.shell_verts + 18 * cell;
             float dot = 0.f;
@@ -435,6 +475,14 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             }
 #pragma unroll
             for (int k = 0; k < 6; k++) gl[k] = w[k] * (gk[k] - dot);
+            if (raw.bary_mode == 1) {
+                const float* x = raw.shell_logits + 6 * (size_t)idx;
+                float ssum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; k++) ssum += fmaxf(x[k], 0.0f);
+#pragma unroll
+                for (int k = 0; k < 6; k++) gl[k] = x[k] > 0.0f ? (gk[k] - dot) / ssum : 0.0f;
+            }
             if (dL_dshell_verts) {
                 // several Gaussians share a cell: float atomics (the one place of this path whose summation order is
                 // not fixed; the reference's autograd index_add has the same property)
@@ -498,25 +546,31 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dL_dscale[3 * idx] = ds[0]; dL_dscale[3 * idx + 1] = ds[1]; dL_dscale[3 * idx + 2] = ds[2];
         *reinterpret_cast<float4*>(dL_drot + 4 * idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
+  } while (HEAVY && (heavy_item += gridDim.x) < heavy[0]);
 }
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int tile_moments,
-                                 hipStream_t s)
+                                 uint32_t* heavy, hipStream_t s)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
     const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(o.dL_dsh) % 16 == 0);
-#define FRG_PBW(S16)                                                                                                  \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<S16>), grid, block, 0, s, P, vp, in.viewmatrix, in.projmatrix,              \
+#define FRG_PBW(S16, HV, GRID, BLOCK)                                                                                  \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<S16, HV>), GRID, BLOCK, 0, s, P, vp, in.viewmatrix, in.projmatrix,              \
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments)
-    if (sh16) FRG_PBW(true); else FRG_PBW(false);
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, heavy)
+    if (sh16) FRG_PBW(true, false, grid, block); else FRG_PBW(false, false, grid, block);
+    // the waves that handed their Gaussians over (usually none: the workgroups read the count and leave)
+    const dim3 hgrid(64), hblock(BWD_HEAVY_WAVES * 64);
+    if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock);
 #undef FRG_PBW
     return hipGetLastError();
 }
+
+size_t bwd_heavy_bytes(int P) { return align_up(((size_t)(P > 0 ? P : 1) / 64 + 2) * 4, 256); }
 
 }  // namespace frg

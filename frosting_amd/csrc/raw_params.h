@@ -5,7 +5,8 @@
 //   opacity  = sigmoid(_opacities)                       frosting_model.py:726-727, gaussian_model.py:104-106
 //   scale    = exp(_scales)                              frosting_model.py:32,763, gaussian_model.py:96-98
 //   rotation = F.normalize(_quaternions)  (eps 1e-12)    frosting_model.py:797-798, gaussian_model.py:100-102
-//   mean     = (softmax(_bary_coords)[..., None] * shell_cells_verts[_point_cell_indices].reshape(-1, 6, 3)).sum(-2)
+//   mean     = (bary_coords[..., None] * shell_cells_verts[_point_cell_indices].reshape(-1, 6, 3)).sum(-2),
+//              bary_coords = softmax(_bary_coords) | relu(_bary_coords) / its sum (use_softmax_for_bary_coords)
 //                                                        frosting_model.py:707-724 (Frosting's shell-bound centres)
 // and autograd runs the chain backwards.  With RawInputs set, preprocess_fwd_kernel / preprocess_bwd_kernel read
 // the raw parameters themselves: the activated tensors never exist in memory (2 x 44 bytes per Gaussian of
@@ -23,6 +24,7 @@ struct RawInputs {
     const float* shell_logits = nullptr;      // [P,6]  (replaces means3D, together with the two below)
     const float* shell_verts = nullptr;       // [F,6,3] = shell_cells_verts.reshape(-1, 6, 3): inner triangle, outer triangle
     const long long* shell_cells = nullptr;   // [P] _point_cell_indices
+    int bary_mode = 0;                        // 0 softmax(logits) | 1 relu(x) / sum relu(x)  (use_softmax_for_bary_coords = False)
 };
 
 __device__ __forceinline__ float raw_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -40,11 +42,28 @@ __device__ __forceinline__ void raw_softmax6(const float* __restrict__ x, float*
     for (int k = 0; k < 6; k++) w[k] = w[k] / s;
 }
 
+// frosting_model.py:716-718 (use_softmax_for_bary_coords = False): relu, then divided by the sum -- no epsilon: the
+// reference's expression, inf / nan for an all-negative row included
+__device__ __forceinline__ void raw_relu_norm6(const float* __restrict__ x, float* w)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { w[k] = fmaxf(x[k], 0.0f); s += w[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) w[k] = w[k] / s;
+}
+
+__device__ __forceinline__ void raw_bary6(const RawInputs& r, int idx, float* w)
+{
+    if (r.bary_mode == 1) raw_relu_norm6(r.shell_logits + 6 * (size_t)idx, w);
+    else raw_softmax6(r.shell_logits + 6 * (size_t)idx, w);
+}
+
 __device__ __forceinline__ float3 param_mean(const float* __restrict__ means3D, const RawInputs& r, int idx)
 {
     if (!r.shell_logits) return make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float w[6];
-    raw_softmax6(r.shell_logits + 6 * (size_t)idx, w);
+    raw_bary6(r, idx, w);
     const float* v = r.shell_verts + 18 * (size_t)r.shell_cells[idx];
     float p[3] = {0.f, 0.f, 0.f};
 #pragma unroll

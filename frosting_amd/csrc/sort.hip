@@ -9,6 +9,7 @@
 #include "frg_common.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <atomic>
 
 namespace frg {
@@ -17,12 +18,14 @@ namespace frg {
 // sign-extended to a mask sb (v_bfe_i32), one ballot, and peers &= ~(ballot ^ sb) per 32-bit half (v_xnor + v_and):
 // six vector instructions.  (`peers &= bit ? m : ~m` on 64-bit values compiled to nine: the ranking is the sort's
 // instruction-bound inner loop.)
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int width = 8)
 {
     const uint64_t v = __builtin_amdgcn_ballot_w64(valid);
     uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
+    // (width is wave-uniform: the digits of a pass only have as many bits as the key range needs -- the ranking costs
+    // six vector instructions per BIT)
+#pragma unroll 1
+    for (int b = 0; b < width; b++) {
         const uint32_t sb = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);   // 0 or 0xFFFFFFFF
         const uint64_t m = __builtin_amdgcn_ballot_w64(sb != 0u);
         plo &= ~((uint32_t)m ^ sb);
@@ -36,34 +39,25 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane)
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// Depth ties: order equal-depth runs by ascending index (the stable-sort tie rule,
-// SURVEY Appendix A-7).  count_ties() returns the number of adjacent equal-depth
-// pairs; a handful are fixed by insertion (fix_ties), many (coplanar scenes) by
-// re-sorting on the index first and the depth again, which LSD stability turns
-// into (depth, index) order.
+// Depth ties: order equal-depth runs by ascending index (the stable-sort tie rule).  Runs of up
+// to FRG_TIE_RUN entries are put in order by insertion, each by the thread that finds its first entry; a longer run
+// (coplanar scenes: thousands of equal depths) raises the flag and the caller re-sorts on the index first and the depth
+// again, which LSD stability turns into (depth, index).  The criterion is the LENGTH of the runs, not their number: the
+// 8192-entry chunks of a tight cluster hold ~150 equal-depth pairs each (float depths 4 +- 0.03 take 4e5 values), and
+// counting them (round 2: more than 32 -> re-sort) sent every chunk through nine radix passes instead of three.
+#define FRG_TIE_RUN 8
 template <typename PtrT>
-__device__ __forceinline__ int count_ties(PtrT a, int n, int nthreads, uint32_t* scratch)
+__device__ __forceinline__ bool fix_short_ties(PtrT a, int n, int nthreads, uint32_t* scratch)
 {
     if (threadIdx.x == 0) scratch[260] = 0;
     __syncthreads();
-    uint32_t c = 0;
-    for (int i = threadIdx.x; i < n - 1; i += nthreads) c += (a[i].x == a[i + 1].x) ? 1u : 0u;
-    if (c) atomicAdd(&scratch[260], c);
-    __syncthreads();
-    const int r = (int)scratch[260];
-    __syncthreads();
-    return r;
-}
-
-template <typename PtrT>
-__device__ __forceinline__ void fix_ties(PtrT a, int n, int nthreads)
-{
     for (int i = threadIdx.x; i < n - 1; i += nthreads) {
         const uint32_t k = a[i].x;
         if (a[i + 1].x != k) continue;
         if (i > 0 && a[i - 1].x == k) continue;  // not the run start
         int j = i + 1;
-        while (j + 1 < n && a[j + 1].x == k) j++;
+        while (j + 1 < n && j - i < FRG_TIE_RUN && a[j + 1].x == k) j++;
+        if (j - i >= FRG_TIE_RUN) { scratch[260] = 1; continue; }
         for (int p = i + 1; p <= j; p++) {  // insertion sort on .y within [i, j]
             const uint2 v = a[p];
             int q = p - 1;
@@ -72,6 +66,9 @@ __device__ __forceinline__ void fix_ties(PtrT a, int n, int nthreads)
         }
     }
     __syncthreads();
+    const bool long_run = scratch[260] != 0;
+    __syncthreads();
+    return long_run;
 }
 
 // ---- LDS classes: register-staged, in-place passes --------------------------------
@@ -80,8 +77,8 @@ __device__ __forceinline__ void fix_ties(PtrT a, int n, int nthreads)
 // single LDS buffer and reloads its strip: one 8-byte buffer instead of a ping-pong pair,
 // so twice the workgroups fit per CU and different size classes can share a CU.
 template <int NWAVES, int SORT_ITEMS, bool BY_INDEX>
-__device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, int begin, int end, int shift,
-                                                uint2* buf, uint32_t* whist, uint32_t* scratch)
+__device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, int begin, int end, int shift, int width, int pass,
+                                                uint32_t kmin, uint2* buf, uint32_t* whist, uint32_t* scratch)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* myhist = whist + wave * 256;
@@ -93,8 +90,8 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
         meta[it] = 0;
         if (begin + it * 64 >= end) continue;     // wave-uniform: nothing of the strip in this step
         const bool valid = begin + it * 64 + lane < end;
-        const uint32_t d = ((BY_INDEX ? e[it].y : e[it].x) >> shift) & 255u;
-        const uint64_t peers = match_digit(d, valid);
+        const uint32_t d = (((BY_INDEX ? e[it].y : e[it].x) - kmin) >> shift) & ((1u << width) - 1u);
+        const uint64_t peers = match_digit(d, valid, width);
         const uint32_t rank = lanes_below(peers, lane), cnt = (uint32_t)__popcll(peers);
         meta[it] = rank | (cnt << 8) | (d << 16);
         if (valid && rank == 0) atomicAdd(&myhist[d], cnt);    // ds_add_u32: no read / wait / write-back round trip
@@ -113,10 +110,10 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
         scratch[dg] = run;
         // one digit holds everything: nothing to move.  One flag per pass position (reset once per group of
         // passes by the caller), so no barrier is spent on clearing it
-        if (run == (uint32_t)n) scratch[256 + (shift >> 3)] = 1;
+        if (run == (uint32_t)n) scratch[256 + pass] = 1;
     }
     __syncthreads();   // (every thread also holds its elements in registers by now: the buffer may be overwritten)
-    if (scratch[256 + (shift >> 3)] != 0) return false;
+    if (scratch[256 + pass] != 0) return false;
     {   // EVERY wave scans the 256 digit totals itself (4 per lane, DPP) and adds the digit bases to its own cursor
         // row: no single-wave scan with a barrier on either side, three workgroup barriers per pass instead of six
         const uint32_t v0 = scratch[4 * lane], v1 = scratch[4 * lane + 1], v2 = scratch[4 * lane + 2], v3 = scratch[4 * lane + 3];
@@ -148,10 +145,107 @@ __device__ __forceinline__ bool radix_pass_regs(uint2 (&e)[SORT_ITEMS], int n, i
     return true;
 }
 
+// Smallest key (depth bits, or Gaussian index) of the workgroup's elements and the number of bits of (largest -
+// smallest): the passes sort key - smallest, whose high bits are zero, in ceil(bits / 8) digits of just enough
+// bits each.  The depths of one tile span a fraction of the float range -- 25 bits at C3 (depths 1 .. 7), 19 in a tight
+// cluster -- so the ranking, six vector instructions per key BIT and the sort's instruction-bound part, runs on 25 bits
+// instead of 32, and a range of 16 bits or less takes two passes.  scratch[264 .. 264 + 2 * 16): per-wave min / max.
+template <int NWAVES, int SORT_ITEMS, bool BY_INDEX>
+__device__ __forceinline__ void key_range(const uint2 (&e)[SORT_ITEMS], int begin, int end, uint32_t* scratch, uint32_t& kmin, int& nbits)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; it++) {
+        const uint32_t k = BY_INDEX ? e[it].y : e[it].x;
+        if (begin + it * 64 + lane < end) { lo = min(lo, k); hi = max(hi, k); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); }
+    __syncthreads();                       // earlier readers of the scratch words are done
+    if (lane == 0) { scratch[264 + wave] = lo; scratch[264 + 16 + wave] = hi; }
+    __syncthreads();
+    lo = 0xFFFFFFFFu; hi = 0u;
+#pragma unroll
+    for (int w = 0; w < NWAVES; w++) { lo = min(lo, scratch[264 + w]); hi = max(hi, scratch[264 + 16 + w]); }
+    kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);          // (the same in every lane: scalar registers)
+    const uint32_t range = (uint32_t)__builtin_amdgcn_readfirstlane((int)(hi - lo));
+    nbits = hi >= lo ? 32 - __builtin_clz(range | 1u) : 0;              // no element at all: nothing to sort
+    if (range == 0u) nbits = 0;
+}
+
+// the passes of one key: ceil(nbits / 8) digits, the first (nbits % passes) of them one bit wider
+template <int NWAVES, int SORT_ITEMS, bool BY_INDEX>
+__device__ __forceinline__ bool radix_passes(uint2 (&e)[SORT_ITEMS], int n, int begin, int end, uint32_t kmin, int nbits,
+                                             uint2* buf, uint32_t* whist, uint32_t* scratch)
+{
+    const int npass = (nbits + 7) >> 3;
+    bool moved = false;
+    int shift = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+        const int width = nbits / npass + (pass < nbits % npass ? 1 : 0);
+        moved |= radix_pass_regs<NWAVES, SORT_ITEMS, BY_INDEX>(e, n, begin, end, shift, width, pass, kmin, buf, whist, scratch);
+        shift += width;
+    }
+    return moved;
+}
+
+// Sorts the workgroup's n <= NWAVES * 64 * SORT_ITEMS elements by (depth bits, index); e[] holds the calling thread's
+// elements of its wave's strip (element begin + it * 64 + lane in e[it]).  On return buf[0, n) holds the sorted
+// pairs (and every thread is past a barrier behind the last write).
+template <int NWAVES, int SORT_ITEMS>
+__device__ __forceinline__ void sort_block_lds(uint2 (&e)[SORT_ITEMS], int n, int begin, int end, uint2* buf, uint32_t* whist,
+                                               uint32_t* scratch)
+{
+    constexpr int NT = NWAVES * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t kmin;
+    int nbits;
+    key_range<NWAVES, SORT_ITEMS, false>(e, begin, end, scratch, kmin, nbits);
+    if (tid < 4) scratch[256 + tid] = 0;
+    __syncthreads();
+    bool in_lds = false;
+    if (n > 1) in_lds = radix_passes<NWAVES, SORT_ITEMS, false>(e, n, begin, end, kmin, nbits, buf, whist, scratch);
+    if (!in_lds) {   // nothing moved (n == 1 or all keys equal): materialise the strip for the steps below
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; it++) {
+            const int i = begin + it * 64 + lane;
+            if (i < end) buf[i] = e[it];
+        }
+        __syncthreads();
+    }
+    if (n > 1) {
+        if (fix_short_ties<uint2*>(buf, n, NT, scratch)) {
+            // long runs of equal depths (coplanar scenes): order by index, then by depth again -- LSD
+            // stability turns that into (depth, index).  (e[] still holds the strips as the last pass left them.)
+            uint32_t imin;
+            int ibits;
+            key_range<NWAVES, SORT_ITEMS, true>(e, begin, end, scratch, imin, ibits);
+            if (tid < 4) scratch[256 + tid] = 0;      // (the first pass has a barrier before the flags are used)
+            radix_passes<NWAVES, SORT_ITEMS, true>(e, n, begin, end, imin, ibits, buf, whist, scratch);
+            __syncthreads();                          // every thread is past the last pass's flag
+            if (tid < 4) scratch[256 + tid] = 0;
+            radix_passes<NWAVES, SORT_ITEMS, false>(e, n, begin, end, kmin, nbits, buf, whist, scratch);
+        }
+    }
+}
+
+// the strip of wave w in a block of n elements: contiguous (keeps every pass stable), a multiple of 64, at most 64 * SORT_ITEMS
+template <int NWAVES>
+__device__ __forceinline__ void wave_strip(int n, int wave, int& begin, int& end)
+{
+    const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
+    begin = wave * strip;
+    end = min(n, begin + strip);
+}
+
+#define FRG_SORT_SCRATCH_WORDS (264 + 32)   // 256 digit totals, 4 uniform-pass flags, tie counter, per-wave OR / AND of the keys
+
 // CAP = 8 * threads; tiles with lo < n <= CAP are handled by this instantiation (the host
 // launches one instantiation per size class; workgroups whose tile is outside exit at once).
 template <int NWAVES, int CAP>
-__global__ void __launch_bounds__(NWAVES * 64)
+__global__ void __launch_bounds__(NWAVES * 64, CAP <= 4096 ? 6 : 4)   // (80 registers: three 4096-entry workgroups per CU)
 sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len,
                       const uint2* __restrict__ ranges, const uint2* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
@@ -160,65 +254,254 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2* buf = reinterpret_cast<uint2*>(smem);
     uint32_t* whist = reinterpret_cast<uint32_t*>(buf + CAP);
-    uint32_t* scratch = whist + NWAVES * 256;  // 264 words: 256 digit totals, 4 uniform-pass flags, tie counter
+    uint32_t* scratch = whist + NWAVES * 256;
     constexpr int NT = NWAVES * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the grid normally covers exactly the tiles of this size class (one pass of this loop); when the
     // host only had an estimate of the list length, workgroups stride over the device-side list
     const uint32_t ntiles = *list_len;
     for (uint32_t item = blockIdx.x; item < ntiles; item += gridDim.x) {
-        if (item != blockIdx.x) __syncthreads();   // the previous tile's LDS contents are dead
         const int tile = (int)tile_list[item];
         const uint2 rg = ranges[tile];
         const int n = (int)(rg.y - rg.x);
         if (n > CAP) continue;
-        // contiguous strip per wave (keeps every pass stable), multiple of 64, at most 64 * SORT_ITEMS
-        const int strip = ((n + NWAVES - 1) / NWAVES + 63) & ~63;
-        const int begin = wave * strip, end = min(n, begin + strip);
+        int begin, end;
+        wave_strip<NWAVES>(n, wave, begin, end);
         uint2 e[SORT_ITEMS];
 #pragma unroll
         for (int it = 0; it < SORT_ITEMS; it++) {
             const int i = begin + it * 64 + lane;
             e[it] = i < end ? pairs[rg.x + i] : make_uint2(0u, 0u);
         }
-        if (tid < 4) scratch[256 + tid] = 0;
-        __syncthreads();
-        bool in_lds = false;
-        if (n > 1) {
-#pragma unroll 1
-            for (int pass = 0; pass < 4; pass++)
-                in_lds |= radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
-        }
-        if (!in_lds) {   // nothing moved (n == 1 or all keys equal): materialise the strip for the steps below
-#pragma unroll
-            for (int it = 0; it < SORT_ITEMS; it++) {
-                const int i = begin + it * 64 + lane;
-                if (i < end) buf[i] = e[it];
-            }
-            __syncthreads();
-        }
-        if (n > 1) {
-            const int ties = count_ties<uint2*>(buf, n, NT, scratch);
-            if (ties > 32) {
-                // many equal depths (coplanar scenes): order by index, then by depth again -- LSD
-                // stability turns that into (depth, index)
-                if (tid < 4) scratch[256 + tid] = 0;      // (count_ties ended with a barrier; the first pass has one before the flags are used)
-#pragma unroll 1
-                for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, true>(e, n, begin, end, 8 * pass, buf, whist, scratch);
-                if (tid < 4) scratch[256 + tid] = 0;      // (every thread is past the last pass's flag; the next read is two barriers away)
-#pragma unroll 1
-                for (int pass = 0; pass < 4; pass++) radix_pass_regs<NWAVES, SORT_ITEMS, false>(e, n, begin, end, 8 * pass, buf, whist, scratch);
-            } else if (ties > 0) {
-                fix_ties<uint2*>(buf, n, NT);
-            }
-        }
+        sort_block_lds<NWAVES, SORT_ITEMS>(e, n, begin, end, buf, whist, scratch);   // (opens with a barrier: the previous tile's LDS contents are dead)
         for (int i = tid; i < n; i += NT) point_list[rg.x + i] = buf[i].y;
     }
 }
 
-// ---- lists longer than the LDS capacity: multi-workgroup LSD radix sort in global memory ----------------
-// One workgroup per list takes milliseconds on a list of 10^5 entries -- clustered scenes
-// have them.  Here every 1024-element strip of such a list is one WAVE's work: per 8-bit digit
+// ---- lists of 8193 .. FRG_SORT_MID_MAX entries: sorted chunks + exact splitters -----------------------------
+// Clustered scenes have tile lists of 10^4 .. 10^5 entries.  (depth, index) is a TOTAL order, so such
+// a list may be cut into key ranges that are sorted independently:
+//   big_plan          one workgroup: the chunks (8192 entries) of every long list -> work items; table space per list
+//   big_chunk_sort    every chunk sorted in LDS by (depth, index) -> pairs_tmp                     (8 B read + written)
+//   big_splitters     one workgroup per list: every 64th entry of each sorted chunk is a SAMPLE (n / 64 <= 8192 of
+//                     them); the samples are sorted in LDS and every g-th one is a splitter.  Between two consecutive
+//                     splitters lie at most (g + m) * 64 - m entries of the m chunks -- chunk c contributes fewer
+//                     than 64 per sample it owns in the range, plus fewer than 64 -- so with g = 128 - m every bucket
+//                     fits the LDS sort, WHATEVER the key distribution (no fallback, no recursion).  The exact bucket
+//                     boundaries in every chunk (binary searches) go to the list's table, the buckets to a work queue.
+//   big_bucket_sort   per bucket: its piece of every chunk gathered (m contiguous runs), sorted in LDS, written to
+//                     point_list at the bucket's offset = number of entries below its lower splitter   (8 B read, 4 written)
+// 28 bytes per entry and three passes of the LDS sort's instructions, against 7 global passes of the LSD form.
+// (FRG_SORT_CHUNK, FRG_SORT_SAMPLE, FRG_SORT_MID_MAX and the BigPlan layout: frg_common.h)
+#define BIG_NW 8
+#define BIG_ITEMS (FRG_SORT_CHUNK / (BIG_NW * 64))
+
+// (depth bits, index) <= (depth bits, index)
+__device__ __forceinline__ bool pair_le(uint2 a, uint2 b) { return a.x < b.x || (a.x == b.x && a.y <= b.y); }
+
+__global__ void __launch_bounds__(1024)
+big_plan_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ list_len, const uint2* __restrict__ ranges,
+                uint32_t* __restrict__ plan_base, uint32_t R)
+{
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t carry[2];
+    const BigPlan pl = BigPlan::carve(plan_base, R);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 2) carry[tid] = 0;
+    if (tid == 0) { pl.hdr[1] = 0; pl.hdr[3] = 0; }
+    __syncthreads();
+    const uint32_t nl = *list_len;
+    for (uint32_t base = 0; base < nl; base += 1024) {
+        const uint32_t i = base + tid;
+        uint32_t tile = 0, m = 0, nb = 0, n = 0;
+        if (i < nl) {
+            tile = tile_list[i];
+            const uint2 rg = ranges[tile];
+            n = rg.y - rg.x;
+            if (n > (uint32_t)FRG_SORT_MID_MAX) { n = 0; pl.hdr[3] = 1; }     // the LSD kernels take it
+            if (n > (uint32_t)FRG_SORT_CHUNK) {
+                m = (n + FRG_SORT_CHUNK - 1) / FRG_SORT_CHUNK;
+                const uint32_t ns = (m - 1) * (FRG_SORT_CHUNK / FRG_SORT_SAMPLE) + (n - (m - 1) * FRG_SORT_CHUNK) / FRG_SORT_SAMPLE;
+                nb = ns / (FRG_SORT_CHUNK / FRG_SORT_SAMPLE - m) + 1;
+            }
+        }
+        // two exclusive prefix sums over the lists: chunk items, table words
+        uint32_t v[2] = {m, nb * m}, ex[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t inc = wave_incl_scan_dpp(v[k]);
+            if (lane == 63) wsum[k][wave] = inc;
+            ex[k] = inc - v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            uint32_t off = carry[k];
+            for (int w = 0; w < wave; w++) off += wsum[k][w];
+            ex[k] += off;
+        }
+        if (m) {
+            pl.lists[i] = make_uint4(tile, ex[1], m, nb);
+            for (uint32_t c = 0; c < m; c++) pl.chunks[ex[0] + c] = make_uint2(i, c);
+        } else if (i < nl) {
+            pl.lists[i] = make_uint4(tile, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        if (tid == 1023) { carry[0] = ex[0] + v[0]; carry[1] = ex[1] + v[1]; }
+        __syncthreads();
+    }
+    if (tid == 0) { pl.hdr[0] = carry[0]; pl.hdr[2] = nl; }
+}
+
+__global__ void __launch_bounds__(BIG_NW * 64)
+big_chunk_sort_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs, uint2* __restrict__ sorted,
+                      const uint32_t* __restrict__ plan_base, uint32_t R)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2* buf = reinterpret_cast<uint2*>(smem);
+    uint32_t* whist = reinterpret_cast<uint32_t*>(buf + FRG_SORT_CHUNK);
+    uint32_t* scratch = whist + BIG_NW * 256;
+    const BigPlan pl = BigPlan::carve(const_cast<uint32_t*>(plan_base), R);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nitems = pl.hdr[0];
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint2 it2 = pl.chunks[item];
+        const uint2 rg = ranges[pl.lists[it2.x].x];
+        const uint32_t first = rg.x + it2.y * FRG_SORT_CHUNK;
+        const int n = (int)min((uint32_t)FRG_SORT_CHUNK, rg.y - first);
+        int begin, end;
+        wave_strip<BIG_NW>(n, wave, begin, end);
+        uint2 e[BIG_ITEMS];
+#pragma unroll
+        for (int it = 0; it < BIG_ITEMS; it++) {
+            const int i = begin + it * 64 + lane;
+            e[it] = i < end ? pairs[first + i] : make_uint2(0u, 0u);
+        }
+        sort_block_lds<BIG_NW, BIG_ITEMS>(e, n, begin, end, buf, whist, scratch);
+        for (int i = tid; i < n; i += BIG_NW * 64) sorted[first + i] = buf[i];
+    }
+}
+
+__global__ void __launch_bounds__(BIG_NW * 64)
+big_splitters_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ sorted, uint32_t* __restrict__ plan_base, uint32_t R)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2* buf = reinterpret_cast<uint2*>(smem);
+    uint32_t* whist = reinterpret_cast<uint32_t*>(buf + FRG_SORT_CHUNK);
+    uint32_t* scratch = whist + BIG_NW * 256;
+    __shared__ uint32_t bucket_sum[FRG_SORT_CHUNK / FRG_SORT_SAMPLE + 1];   // entries at or below splitter k, all chunks
+    __shared__ uint32_t queue_base;
+    const BigPlan pl = BigPlan::carve(plan_base, R);
+    constexpr int NT = BIG_NW * 64, SPC = FRG_SORT_CHUNK / FRG_SORT_SAMPLE;   // samples per full chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nl = pl.hdr[2];
+    for (uint32_t li = blockIdx.x; li < nl; li += gridDim.x) {
+        const uint4 info = pl.lists[li];
+        const int m = (int)info.z, nb = (int)info.w;
+        if (m == 0) continue;                                   // workgroup-uniform
+        const uint2 rg = ranges[info.x];
+        const int n = (int)(rg.y - rg.x);
+        const int ns = (m - 1) * SPC + (n - (m - 1) * FRG_SORT_CHUNK) / FRG_SORT_SAMPLE;
+        const int g = SPC - m;                                  // (g + m) * 64 <= 8192: every bucket fits the LDS sort
+        const uint2* src = sorted + rg.x;
+        int begin, end;
+        wave_strip<BIG_NW>(ns, wave, begin, end);
+        uint2 e[BIG_ITEMS];
+#pragma unroll
+        for (int it = 0; it < BIG_ITEMS; it++) {
+            const int t = begin + it * 64 + lane;
+            // sample t: the last entry of the (t % SPC)-th group of 64 of chunk t / SPC
+            e[it] = t < end ? src[(size_t)(t / SPC) * FRG_SORT_CHUNK + (size_t)(t % SPC + 1) * FRG_SORT_SAMPLE - 1] : make_uint2(0u, 0u);
+        }
+        sort_block_lds<BIG_NW, BIG_ITEMS>(e, ns, begin, end, buf, whist, scratch);
+        for (int k = tid; k < nb; k += NT) bucket_sum[k] = 0;
+        __syncthreads();
+        // pos[k][c] = entries of chunk c at or below splitter k = buf[(k + 1) * g - 1]
+        uint32_t* table = pl.tables + info.y;
+        for (int q = tid; q < (nb - 1) * m; q += NT) {
+            const int k = q / m, c = q - k * m;
+            const uint2 key = buf[(k + 1) * g - 1];
+            const uint2* ch = src + (size_t)c * FRG_SORT_CHUNK;
+            int lo = 0, hi = min(FRG_SORT_CHUNK, n - c * FRG_SORT_CHUNK);     // first entry above the key
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (pair_le(ch[mid], key)) lo = mid + 1; else hi = mid;
+            }
+            table[q] = (uint32_t)lo;
+            atomicAdd(&bucket_sum[k], (uint32_t)lo);
+        }
+        __syncthreads();
+        if (tid == 0) { bucket_sum[nb - 1] = (uint32_t)n; queue_base = atomicAdd(&pl.hdr[1], (uint32_t)nb); }
+        __syncthreads();
+        for (int k = tid; k < nb; k += NT) {
+            const uint32_t below = k ? bucket_sum[k - 1] : 0u;
+            pl.buckets[queue_base + k] = make_uint4(li, (uint32_t)k, below, bucket_sum[k] - below);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(BIG_NW * 64)
+big_bucket_sort_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ sorted, uint32_t* __restrict__ point_list,
+                       uint32_t* __restrict__ plan_base, uint32_t R)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2* buf = reinterpret_cast<uint2*>(smem);
+    uint32_t* whist = reinterpret_cast<uint32_t*>(buf + FRG_SORT_CHUNK);
+    uint32_t* scratch = whist + BIG_NW * 256;
+    __shared__ uint32_t piece_lo[FRG_SORT_MID_MAX / FRG_SORT_CHUNK], piece_start[FRG_SORT_MID_MAX / FRG_SORT_CHUNK + 1];
+    const BigPlan pl = BigPlan::carve(plan_base, R);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nbuckets = pl.hdr[1];
+    for (uint32_t item = blockIdx.x; item < nbuckets; item += gridDim.x) {
+        const uint4 bk = pl.buckets[item];
+        const uint4 info = pl.lists[bk.x];
+        const int m = (int)info.z, nb = (int)info.w, k = (int)bk.y;
+        const uint2 rg = ranges[info.x];
+        const int ntot = (int)(rg.y - rg.x);
+        int n = (int)bk.w;
+        if (n > FRG_SORT_CHUNK) { if (tid == 0) pl.hdr[3] = 2; n = 0; }   // cannot happen (bound above); never write out of bounds
+        const uint32_t* table = pl.tables + info.y;
+        __syncthreads();                                       // the previous bucket's piece table is dead
+        if (tid < 64) {                                        // m <= 64: one wave scans the piece lengths
+            uint32_t lo = 0, hi = 0;
+            if (tid < m) {
+                lo = k ? table[(k - 1) * m + tid] : 0u;
+                hi = k < nb - 1 ? table[k * m + tid] : (uint32_t)min(FRG_SORT_CHUNK, ntot - tid * FRG_SORT_CHUNK);
+                piece_lo[tid] = lo;
+            }
+            const uint32_t inc = wave_incl_scan_dpp(hi - lo);
+            if (tid < m) piece_start[tid] = inc - (hi - lo);
+            if (tid == 63) piece_start[m] = inc;               // (lanes >= m add nothing)
+        }
+        __syncthreads();
+        int begin, end;
+        wave_strip<BIG_NW>(n, wave, begin, end);
+        uint2 e[BIG_ITEMS];
+#pragma unroll
+        for (int it = 0; it < BIG_ITEMS; it++) {
+            const int i = begin + it * 64 + lane;
+            e[it] = make_uint2(0u, 0u);
+            if (i < end) {
+                int c = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int mid = c + step;
+                    if (mid < m && piece_start[mid] <= (uint32_t)i) c = mid;
+                }
+                e[it] = sorted[rg.x + (size_t)c * FRG_SORT_CHUNK + piece_lo[c] + ((uint32_t)i - piece_start[c])];
+            }
+        }
+        sort_block_lds<BIG_NW, BIG_ITEMS>(e, n, begin, end, buf, whist, scratch);
+        for (int i = tid; i < n; i += BIG_NW * 64) point_list[rg.x + bk.z + i] = buf[i].y;
+    }
+}
+
+// ---- lists longer than FRG_SORT_MID_MAX: multi-workgroup LSD radix sort in global memory ----------------
+// (Round 2 sorted every list above the LDS capacity this way: 21 launches, one wave per 1024-element strip ranking
+// its strip twice per digit -- 1.6 ms for the 8 M elements in the 139 long lists of the clustered scene.  It remains for
+// lists of more than half a million entries, beyond what one workgroup's sample sort of the splitter path holds.)
+// Every 1024-element strip of such a list is one WAVE's work: per 8-bit digit
 //   big_count   each wave counts the digits of its strip -> one 256-entry row of big_hist
 //   big_offsets per list: exclusive scan of the rows, digit-major then strip-major (stable)
 //   big_move    each wave ranks its strip again (ballot matching keeps the strip's order) and scatters
@@ -240,6 +523,7 @@ big_count_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restr
     for (uint32_t item = blockIdx.y; item < *list_len; item += gridDim.y) {
         const uint2 rg = ranges[tile_list[item]];
         const int n = (int)(rg.y - rg.x);
+        if (n <= FRG_SORT_MID_MAX) continue;
         for (int strip = blockIdx.x * (BIG_THREADS / 64) + wave; strip * BIG_STRIP < n; strip += gridDim.x * (BIG_THREADS / 64)) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -269,6 +553,7 @@ big_offsets_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __res
     for (uint32_t item = blockIdx.x; item < *list_len; item += gridDim.x) {
         const uint2 rg = ranges[tile_list[item]];
         const int n = (int)(rg.y - rg.x);
+        if (n <= FRG_SORT_MID_MAX) continue;       // workgroup-uniform
         const int nstrips = (n + BIG_STRIP - 1) / BIG_STRIP;
         uint32_t* rows = hist + BinningState::big_hist_row(rg.x, 0u) * 256;
         uint32_t run = 0;
@@ -300,6 +585,7 @@ big_move_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __restri
     for (uint32_t item = blockIdx.y; item < *list_len; item += gridDim.y) {
         const uint2 rg = ranges[tile_list[item]];
         const int n = (int)(rg.y - rg.x);
+        if (n <= FRG_SORT_MID_MAX) continue;
         for (int strip = blockIdx.x * (BIG_THREADS / 64) + wave; strip * BIG_STRIP < n; strip += gridDim.x * (BIG_THREADS / 64)) {
             const uint32_t* row = hist + BinningState::big_hist_row(rg.x, (uint32_t)strip) * 256;
             __builtin_amdgcn_wave_barrier();
@@ -333,7 +619,7 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
                                    const uint2* pairs, uint32_t* point_list, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
-    const size_t lds = (size_t)CAP * 8 + NW * 1024 + 264 * 4;
+    const size_t lds = (size_t)CAP * 8 + NW * 1024 + FRG_SORT_SCRATCH_WORDS * 4;
     if (lds > 48 * 1024) {
         // the attribute is per device: remember it per device, not per process
         static std::atomic<unsigned long long> attr_set{0};
@@ -359,7 +645,7 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
 // early exits was dominated by dispatching ~6000 no-op 1024-thread workgroups.
 struct SortStreams {
     hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}, plan_fork = nullptr;
     int device = -1;
     bool ensure()
     {
@@ -373,21 +659,60 @@ struct SortStreams {
             side[i] = nullptr; join[i] = nullptr;
         }
         if (fork) (void)hipEventDestroy(fork);
-        fork = nullptr;
+        if (plan_fork) (void)hipEventDestroy(plan_fork);
+        fork = nullptr; plan_fork = nullptr;
         device = -1;
         for (int i = 0; i < 2; i++) {
             if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return false;
             if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
         }
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&plan_fork, hipEventDisableTiming) != hipSuccess) return false;
         device = dev;
         return true;
     }
 };
 
+// the three LDS-sorting kernels of the splitter path use the largest class's workgroup shape; their dynamic LDS
+// attribute is set once per device
+template <int WHICH, typename K>
+static hipError_t allow_sort_lds(K kernel, size_t lds)
+{
+    static std::atomic<unsigned long long> attr_set{0};   // one per kernel (WHICH)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (attr_set.load() & bit) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) attr_set.fetch_or(bit);
+    return e;
+}
+
+static thread_local SortStreams g_sort_streams;
+
+// The long lists' plan only needs the scan's outputs (ranges, the class lists): launched on the sort's second side
+// stream BEFORE the scatter is enqueued, its single workgroup's latency chain hides under the scatter.
+hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
+                            const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream)
+{
+    if (!big_plan || T <= 0 || (class_count && class_count[4] == 0)) return hipSuccess;
+    SortStreams& ss = g_sort_streams;
+    hipStream_t s2 = stream;
+    hipError_t e;
+    if (ss.ensure()) {
+        if ((e = hipEventRecord(ss.plan_fork, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ss.side[1], ss.plan_fork, 0)) != hipSuccess) return e;
+        s2 = ss.side[1];
+    }
+    hipLaunchKernelGGL(big_plan_kernel, dim3(1), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, class_count_dev + 4, ranges, big_plan, R);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
                             const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
-                            uint32_t* big_hist, int max_tile_count, int index_bits, uint32_t* point_list, hipStream_t stream)
+                            uint32_t* big_hist, uint32_t* big_plan, uint32_t R, int max_tile_count, int index_bits,
+                            uint32_t* point_list, hipStream_t stream)
 {
     int cc[FRG_SORT_CLASSES];
     for (int k = 0; k < FRG_SORT_CLASSES; k++) {
@@ -402,38 +727,59 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
     const int c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4];
     const uint32_t* len = class_count_dev;
     if (T <= 0 || c0 + c1 + c2 + c3 + c4 == 0) return hipSuccess;
-    thread_local SortStreams ss;
+    SortStreams& ss = g_sort_streams;
     const bool big = (c2 + c3 + c4) > 0;
     const bool forked = big && ss.ensure();
     hipStream_t s1 = stream, s2 = stream;
     hipError_t e;
+    // the (4096, 8192] class shares the second side stream with the long lists -- unless those are known to exist:
+    // their chain of four kernels then has that stream to itself and the class queues behind the (2048, 4096] one
+    const bool c3_on_s1 = class_count && c4 > 0;
+    const bool use_s1 = c2 > 0 || (c3 > 0 && c3_on_s1), use_s2 = c4 > 0 || (c3 > 0 && !c3_on_s1);
     if (forked) {
         if ((e = hipEventRecord(ss.fork, stream)) != hipSuccess) return e;
         s1 = ss.side[0]; s2 = ss.side[1];
-        if (c2 && (e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
-        if ((c3 + c4) && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
+        if (use_s1 && (e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
+        if (use_s2 && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
     }
     // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 8 waves x 16 elements,
-    // >8192 global ping-pong; longest-running classes first
+    // >8192 sorted chunks + splitters (beyond FRG_SORT_MID_MAX: global LSD passes); longest-running classes first
     auto launch_global_class = [&]() -> hipError_t {
         if (!c4) return hipSuccess;
-        if (!pairs_tmp || !big_hist) return hipErrorInvalidValue;
+        if (!pairs_tmp || !big_plan) return hipErrorInvalidValue;
         const uint32_t* list = class_tiles + (size_t)4 * T;
-        // strips of the longest list per workgroup row; when its length is only an estimate the kernels stride
-        const int strips = ((max_tile_count > 0 ? max_tile_count : 4 * FRG_SORT_LDS_CAP) + BIG_STRIP - 1) / BIG_STRIP;
-        const dim3 grid((strips + BIG_THREADS / 64 - 1) / (BIG_THREADS / 64), c4 < 4096 ? c4 : 4096);
-        uint2 *src = pairs, *dst = pairs_tmp;
-        const int index_passes = (index_bits + 7) / 8;
-        for (int pass = 0; pass < index_passes + 4; pass++) {
-            const bool by_index = pass < index_passes, last = pass == index_passes + 3;
-            const int shift = 8 * (by_index ? pass : pass - index_passes);
-            if (by_index) hipLaunchKernelGGL((big_count_kernel<true>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, shift, big_hist);
-            else          hipLaunchKernelGGL((big_count_kernel<false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, shift, big_hist);
-            hipLaunchKernelGGL(big_offsets_kernel, dim3(grid.y), dim3(256), 0, s2, list, len + 4, ranges, big_hist);
-            if (by_index)  hipLaunchKernelGGL((big_move_kernel<true, false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
-            else if (last) hipLaunchKernelGGL((big_move_kernel<false, true>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
-            else           hipLaunchKernelGGL((big_move_kernel<false, false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
-            uint2* t = src; src = dst; dst = t;
+        {   // 8193 .. FRG_SORT_MID_MAX entries
+            constexpr size_t lds = (size_t)FRG_SORT_CHUNK * 8 + BIG_NW * 1024 + FRG_SORT_SCRATCH_WORDS * 4;
+            if ((e = allow_sort_lds<0>(big_chunk_sort_kernel, lds)) != hipSuccess) return e;
+            if ((e = allow_sort_lds<1>(big_splitters_kernel, lds)) != hipSuccess) return e;
+            if ((e = allow_sort_lds<2>(big_bucket_sort_kernel, lds)) != hipSuccess) return e;
+            // work items are counted on the device; the grids are bounds (the kernels stride): chunks <= R / 8192 + lists,
+            // buckets < R / 4064 + lists
+            const unsigned chunks = (unsigned)std::min<size_t>((size_t)R / FRG_SORT_CHUNK + (size_t)c4, 2048);
+            const unsigned buckets = (unsigned)std::min<size_t>((size_t)R / 4064 + (size_t)c4, 2048);
+            // (big_plan_kernel: launch_sort_plan, before the scatter)
+            hipLaunchKernelGGL(big_chunk_sort_kernel, dim3(chunks), dim3(BIG_NW * 64), lds, s2, ranges, pairs, pairs_tmp, big_plan, R);
+            hipLaunchKernelGGL(big_splitters_kernel, dim3(c4 < 2048 ? c4 : 2048), dim3(BIG_NW * 64), lds, s2, ranges, pairs_tmp, big_plan, R);
+            hipLaunchKernelGGL(big_bucket_sort_kernel, dim3(buckets), dim3(BIG_NW * 64), lds, s2, ranges, pairs_tmp, point_list, big_plan, R);
+        }
+        // beyond: only when the longest list is known to need it (deferred counters: not known not to)
+        if (big_hist && (max_tile_count == 0 || max_tile_count > FRG_SORT_MID_MAX)) {
+            // strips of the longest list per workgroup row; when its length is only an estimate the kernels stride
+            const int strips = ((max_tile_count > 0 ? max_tile_count : 4 * FRG_SORT_MID_MAX) + BIG_STRIP - 1) / BIG_STRIP;
+            const dim3 grid((strips + BIG_THREADS / 64 - 1) / (BIG_THREADS / 64), c4 < 4096 ? c4 : 4096);
+            uint2 *src = pairs, *dst = pairs_tmp;
+            const int index_passes = (index_bits + 7) / 8;
+            for (int pass = 0; pass < index_passes + 4; pass++) {
+                const bool by_index = pass < index_passes, last = pass == index_passes + 3;
+                const int shift = 8 * (by_index ? pass : pass - index_passes);
+                if (by_index) hipLaunchKernelGGL((big_count_kernel<true>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, shift, big_hist);
+                else          hipLaunchKernelGGL((big_count_kernel<false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, shift, big_hist);
+                hipLaunchKernelGGL(big_offsets_kernel, dim3(grid.y), dim3(256), 0, s2, list, len + 4, ranges, big_hist);
+                if (by_index)  hipLaunchKernelGGL((big_move_kernel<true, false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
+                else if (last) hipLaunchKernelGGL((big_move_kernel<false, true>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
+                else           hipLaunchKernelGGL((big_move_kernel<false, false>), grid, dim3(BIG_THREADS), 0, s2, list, len + 4, ranges, src, dst, point_list, shift, big_hist);
+                uint2* t = src; src = dst; dst = t;
+            }
         }
         return hipGetLastError();
     };
@@ -443,17 +789,17 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
     if (class_count && (e = launch_global_class()) != hipSuccess) return e;
     // (4096,8192]: 8 waves x 16 staged elements rather than 16 x 8 -- two workgroups fit a CU and
     // one's barrier stalls overlap the other's ranking (0.286 -> 0.256 ms at C3)
-    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, len + 3, ranges, pairs, point_list, s2)) != hipSuccess) return e;
+    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, len + 3, ranges, pairs, point_list, c3_on_s1 ? s1 : s2)) != hipSuccess) return e;
     if (!class_count && (e = launch_global_class()) != hipSuccess) return e;
     if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, len + 2, ranges, pairs, point_list, s1)) != hipSuccess) return e;
     if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, len + 1, ranges, pairs, point_list, stream)) != hipSuccess) return e;
     if ((e = launch_lds_class<1, 512>(c0, class_tiles, len, ranges, pairs, point_list, stream)) != hipSuccess) return e;
     if (forked) {
-        if (c2) {
+        if (use_s1) {
             if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, ss.join[0], 0)) != hipSuccess) return e;
         }
-        if (c3 + c4) {
+        if (use_s2) {
             if ((e = hipEventRecord(ss.join[1], s2)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, ss.join[1], 0)) != hipSuccess) return e;
         }

@@ -144,10 +144,13 @@ class GradientExchange:
         return self._works
 
     def _start_direct(self, summed):
-        """Phase 1 of the direct plan: all-to-all of the N shards (the tail shard is zero-padded in a staging
-        copy only when the length does not divide).  Phase 2 (local sum + all-gather) runs in wait()."""
+        """Phase 1 of the direct plan.  RCCL: ONE reduce_scatter_tensor -- rank j receives the sum of everyone's shard
+        j.  Backends without it (gloo, the CPU tests): an all-to-all of the N shards and a local sum in rank order.
+        The tail shard is zero-padded in a staging copy only when the length does not divide.  Phase 2 (all-gather of
+        the reduced shards) runs in wait()."""
         import torch.distributed as dist
         world = dist.get_world_size(self.group)
+        self._direct_rs = dist.get_backend(self.group) == "nccl"
         n = summed.numel()
         shard = (n + world - 1) // world
         if self._direct is None or self._direct[2] != shard or self._direct[1].shape[0] != world:
@@ -159,14 +162,18 @@ class GradientExchange:
         if send is not summed:
             send[:n].copy_(summed)
         self._direct_target = summed
-        self._works.append(dist.all_to_all_single(recv.view(-1), send, group=self.group, async_op=True))
+        if self._direct_rs:
+            self._works.append(dist.reduce_scatter_tensor(mine, send, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_to_all_single(recv.view(-1), send, group=self.group, async_op=True))
 
     def _finish_direct(self):
         import torch.distributed as dist
         send, recv, shard, mine = self._direct
         summed = self._direct_target
         n = summed.numel()
-        torch.sum(recv, dim=0, out=mine)          # fixed order over source ranks: identical on every rank after the gather
+        if not self._direct_rs:
+            torch.sum(recv, dim=0, out=mine)      # fixed order over source ranks: identical on every rank after the gather
         world = recv.shape[0]
         if shard * world == n:
             dist.all_gather_into_tensor(summed, mine, group=self.group)
@@ -195,6 +202,35 @@ class GradientExchange:
             self.sh_reducer(self)
         if self.average:
             self.flat.mul_(1.0 / dist.get_world_size(self.group))
+
+    def finish_in_step(self):
+        """The schedule of a training step that updates the parameters before the next view is rendered: everything
+        started by start() is complete (on the current stream) when this returns -- nothing is left for a later step.
+        Inside it, factored plan on a GPU: the all-gather (started first, 3 floats per Gaussian) is waited for alone
+        and the SH rebuild it feeds runs on a side stream WHILE the sum of the dense part is still on the wire; the
+        current stream then waits for both."""
+        if not self._works:
+            return self.flat
+        overlap = self.factor_sh and not self.average and self.flat.device.type == "cuda"
+        if not overlap:
+            self._finish_on_current_stream()
+            return self.flat
+        if self.means3D is None:
+            raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
+        self._works[0].wait()                          # the all-gather of dRGB / camera centres
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.flat.device)
+        cur = torch.cuda.current_stream(self.flat.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self.sh_reducer(self)                      # writes views["shs"] only: disjoint from the dense part
+        for w in self._works[1:]:
+            w.wait()
+        self._works = []
+        if self.reduce == "direct":
+            self._finish_direct()
+        cur.wait_stream(self._side)
+        return self.flat
 
     def wait_on_side_stream(self):
         """GPU, factored plan: the current stream waits for the pending collectives (so the dense part
@@ -230,6 +266,42 @@ class GradientExchange:
             self._joined = None
 
 
+class DensificationStats:
+    """The per-Gaussian statistics vanilla 3DGS densification keeps (gaussian_splatting/train.py:116-117,
+    gaussian_splatting/scene/gaussian_model.py:404-407), over a view-parallel batch: every rank holds one view's
+    `radii` and screen-space gradient; the batch's contribution is
+        max_radii2D         = max(max_radii2D, max over views of radii)          on the Gaussians visible in that view
+        xyz_gradient_accum += sum over visible views of ||viewspace_grad[:, :2]||
+        denom              += number of views in which the Gaussian was visible
+    i.e. ONE all-reduce(MAX) of P int32 and ONE all-reduce(SUM) of 2 P floats.  Frosting's
+    refinement does not densify (refine.py has no such step), so this is optional on the C5 path."""
+
+    def __init__(self, P: int, device, process_group=None):
+        self.group = process_group
+        dev = torch.device(device)
+        self.max_radii2D = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.xyz_gradient_accum = torch.zeros(P, 1, dtype=torch.float32, device=dev)
+        self.denom = torch.zeros(P, 1, dtype=torch.float32, device=dev)
+        self._radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        self._sums = torch.zeros(P, 2, dtype=torch.float32, device=dev)
+
+    def update(self, radii: torch.Tensor, viewspace_grad: torch.Tensor):
+        """radii [P] int32, viewspace_grad [P,3] (dL_dmeans2D) of THIS rank's view; collective over the group."""
+        import torch.distributed as dist
+        vis = radii > 0
+        torch.where(vis, radii, torch.zeros_like(radii), out=self._radii)
+        self._sums[:, 0] = torch.where(vis, viewspace_grad[:, :2].norm(dim=-1), torch.zeros_like(self._sums[:, 0]))
+        self._sums[:, 1] = vis.to(torch.float32)
+        if self.group is not None and dist.is_initialized():
+            works = [dist.all_reduce(self._radii, op=dist.ReduceOp.MAX, group=self.group, async_op=True),
+                     dist.all_reduce(self._sums, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+            for w in works:
+                w.wait()
+        torch.maximum(self.max_radii2D, self._radii.to(torch.float32), out=self.max_radii2D)
+        self.xyz_gradient_accum += self._sums[:, 0:1]
+        self.denom += self._sums[:, 1:2]
+
+
 class _Arena:
     """Grow-only device buffer handed to the C ABI's allocation callbacks: after
     the first view no allocator call remains on the per-step path (image size and
@@ -259,7 +331,8 @@ class ViewParallelRasterizer:
     in place into the flat exchange buffer (no copies, no zero-fill)."""
 
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
-                 deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce"):
+                 deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce",
+                 write_all_outputs: bool = True):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
@@ -281,8 +354,13 @@ class ViewParallelRasterizer:
                 ex.set_sh_context(scene.means3D, scene.sh_degree)
         self.exchange = self.exchanges[0]
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.dev)
-        # rank-local (not exchanged) backward outputs
+        # rank-local (not exchanged) backward outputs.  dL_dcov3D is an intermediate of the chain when the covariance
+        # comes from scales / rotations, but it is one of the eight tensors the reference's backward returns
+        # (rasterize_points.cu:195) and part of SURVEY 8(d)'s byte model (24 of the 284 B per Gaussian): written unless
+        # the caller opts out (write_all_outputs=False)
         self.dL_dmeans2D, self.dL_dcolors = f(P, 3), f(P, 3)
+        self.write_all_outputs = write_all_outputs
+        self.dL_dcov3D = f(P, 6) if write_all_outputs else None
         self.geom, self.binning, self.img, self.work = (_Arena(self.dev) for _ in range(4))
         self.radii = torch.empty(P, dtype=torch.int32, device=self.dev)
         self.out_color = None
@@ -375,9 +453,8 @@ class ViewParallelRasterizer:
                             _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
                             _p(self.dL_dmeans2D), None, _p(g["opacities"]),
                             # deferred SH rows: dL_dcolor receives the masked colour gradient = the exchange payload
-                            # (dL_dcolors is an intermediate: only the factored SH exchange reads it; dL_dcov3D likewise -- NULL)
-                            _p(ex.own_drgb) if defer_sh else (_p(self.dL_dcolors) if ex.factor_sh else None),
-                            _p(g["means3D"]), None, None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
+                            _p(ex.own_drgb) if defer_sh else (_p(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
+                            _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
                             _p(work), work.numel(), 0, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
@@ -391,6 +468,13 @@ class ViewParallelRasterizer:
             # the caching allocator placed at the previous one's address from the previous one
             ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
         return g
+
+    def exchange_in_step(self, slot: int = 0):
+        """start_exchange + GradientExchange.finish_in_step: the gradients of buffer `slot` are the sums over ranks
+        when this returns (stream-ordered) -- the form a step with an optimizer update between views needs."""
+        ex = self.exchanges[slot]
+        ex.start()
+        return ex.finish_in_step()
 
     def allreduce_grads(self, slot: int = 0):
         """Synchronous form: SUM over ranks, stream-ordered."""

@@ -71,10 +71,12 @@ class _NativeOps:
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, debug, keep_mask=None):
+                            campos, prefiltered, debug, keep_mask=None, modes=None):
         """keep_mask (extension, optional bool/uint8 [P]): Gaussians with a zero entry are left out of this
         view as if culled -- Frosting's occlusion culling without the boolean compaction of every
-        per-Gaussian tensor (frosting_scene/frosting_model.py:1564-1586)."""
+        per-Gaussian tensor (frosting_scene/frosting_model.py:1564-1586).
+        modes (extension, optional dict): per-call forward modes {'exact_blend', 'tight_binning', 'async_sh'} that
+        override the process-wide frg_set_option values for THIS call (frg_forward_args)."""
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
         if not means3D.is_cuda:
@@ -91,7 +93,7 @@ class _NativeOps:
                      opac=_f32c(opacity, dev), scales=_f32c(scales, dev), rots=_f32c(rotations, dev),
                      cov=_f32c(cov3D_precomp, dev), view=_f32c(viewmatrix, dev), proj=_f32c(projmatrix, dev),
                      sh=_f32c(sh, dev), campos=_f32c(campos, dev))
-            if keep_mask is None:
+            if keep_mask is None and modes is None:
                 rc = L.frg_forward(bufs.cb_geom, bufs.cb_binning, bufs.cb_img, None,
                                    P, int(degree), M, _ptr(t["bg"]), W, H,
                                    _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]), _ptr(t["opac"]),
@@ -100,9 +102,10 @@ class _NativeOps:
                                    float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                    _ptr(out_color), _ptr(radii) if P else None, int(bool(debug)), _stream_ptr(dev))
             else:
-                if keep_mask.shape != (P,) or keep_mask.device != dev or keep_mask.dtype not in (torch.bool, torch.uint8):
+                if keep_mask is not None and (keep_mask.shape != (P,) or keep_mask.device != dev or
+                                              keep_mask.dtype not in (torch.bool, torch.uint8)):
                     raise RuntimeError("keep_mask must be a bool / uint8 tensor of shape (num_points,) on the Gaussians' device")
-                mask = keep_mask.contiguous()
+                mask = None if keep_mask is None else keep_mask.contiguous()
 
                 def vp(x):
                     return None if x is None else x.value
@@ -115,7 +118,8 @@ class _NativeOps:
                     projmatrix=vp(_ptr(t["proj"])), cam_pos=vp(_ptr(t["campos"])), tan_fovx=float(tan_fovx),
                     tan_fovy=float(tan_fovy), prefiltered=int(bool(prefiltered)), out_color=out_color.data_ptr(),
                     radii=radii.data_ptr() if P else None, debug=int(bool(debug)), hip_stream=_stream_ptr(dev).value,
-                    instance_capacity=0, keep_mask=mask.data_ptr() if P else None)
+                    instance_capacity=0, keep_mask=mask.data_ptr() if (P and mask is not None) else None,
+                    **_lib.mode_fields(modes))
                 rc = L.frg_forward_ex(C.byref(a))
         if rc < 0:
             raise RuntimeError(f"frg_forward failed ({rc}): {_lib.last_error()}")

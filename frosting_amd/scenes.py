@@ -172,27 +172,43 @@ def make_shell_scene(P: int, seed: int, n_lat: int = 224, n_lon: int = 448) -> S
     return ShellScene(scene, verts, faces, cell.contiguous())
 
 
-def make_skew_scene(P: int, seed: int) -> Scene:
-    """Stress scene for the binning / sort / blend balance: half of the Gaussians in a few
+def make_skew_scene(P: int, seed: int, centres=None, cluster_sigma: float = 0.03, cluster_frac: float = 0.5,
+                    n_big: int | None = None, big_scale: float = 0.05) -> Scene:
+    """Stress scene for the binning / sort / blend balance: a fraction of the Gaussians in a few
     tight clusters (tile lists of 10^4-10^5 entries next to empty tiles), a few hundred large near-camera
-    Gaussians (tile rectangles of hundreds of tiles), the rest a thin uniform ball."""
+    Gaussians (tile rectangles of hundreds of tiles), the rest a thin uniform ball.  The defaults are the scene
+    bench.py reports as `skew_scene` (unchanged since round 2); the keyword arguments shape the small-image variants
+    of the parity tests."""
     g = torch.Generator().manual_seed(seed)
     base = make_scene(P, seed + 1)
     f64 = torch.float64
-    n_cl = P // 2
-    centres = torch.tensor([[0.0, 0.0, 0.0], [0.9, 0.3, 0.2], [-0.8, -0.4, 0.5], [0.2, 0.7, -0.6]], dtype=f64)
+    n_cl = int(P * cluster_frac)
+    if centres is None:
+        centres = [[0.0, 0.0, 0.0], [0.9, 0.3, 0.2], [-0.8, -0.4, 0.5], [0.2, 0.7, -0.6]]
+    centres = torch.tensor(centres, dtype=f64)
     which = torch.randint(0, centres.shape[0], (n_cl,), generator=g)
     means = base.means3D.double().clone()
-    means[:n_cl] = centres[which] + 0.03 * torch.randn(n_cl, 3, generator=g, dtype=f64)
+    means[:n_cl] = centres[which] + cluster_sigma * torch.randn(n_cl, 3, generator=g, dtype=f64)
     scales = base.scales.double().clone()
-    n_big = min(400, P // 100)
+    n_big = min(400, P // 100) if n_big is None else n_big
     if n_big:
         # large and close to camera 0 (which sits at (0, 0, -4) looking at the origin)
         means[n_cl:n_cl + n_big] = torch.tensor([0.0, 0.0, -2.8], dtype=f64) + torch.tensor([0.8, 0.5, 0.3], dtype=f64) * \
             torch.randn(n_big, 3, generator=g, dtype=f64)
-        scales[n_cl:n_cl + n_big] = 0.05 * torch.exp(0.5 * torch.randn(n_big, 3, generator=g, dtype=f64))
+        scales[n_cl:n_cl + n_big] = big_scale * torch.exp(0.5 * torch.randn(n_big, 3, generator=g, dtype=f64))
     return Scene(means.float().contiguous(), scales.float().contiguous(), base.rotations, base.opacities, base.shs,
                  base.sh_degree)
+
+
+def long_list_scene(P: int = 2_000_000, seed: int = SEED_BASE + 31):
+    """(Scene, Camera, bg) of the small-image stress case of the parity tests: 320x240 (300 tiles), two very tight
+    clusters (one tile list of more than 250 000 entries each), a dense ball behind them (more than a hundred lists
+    beyond the 8192-entry LDS capacity of the tile sort) and 200 Gaussians that each cover the whole image (their
+    64-Gaussian waves own ~19 000 backward slots)."""
+    scene = make_skew_scene(P, seed, centres=[[0.0, 0.0, 0.0], [0.5, 0.3, 0.2]], cluster_sigma=0.01, cluster_frac=0.3,
+                            n_big=200, big_scale=0.3)
+    cam = ring_camera(0, 320, 240, 267.0, 267.0)
+    return scene, cam, torch.zeros(3)
 
 
 def config_scene(name: str, view: int = 0, P: int | None = None):

@@ -137,6 +137,16 @@ typedef struct frg_forward_args {
     const float *raw_opacities, *raw_scales, *raw_rotations;
     const float *shell_logits, *shell_cell_verts;
     const long long* shell_cells;
+    /* ---- per-call modes (third generation of the struct; struct_size tells) ---------------------------------------
+     * 0 = whatever frg_set_option says at the time of the call (the process-wide default), k + 1 = value k for THIS
+     * call only: two rasterizers in two threads may hold different forward modes.  exact_blend 1 | 2 = fast | exact
+     * blend arithmetic; tight_binning 1 | 2 = off | on; async_sh 1 .. 4 = modes 0 .. 3.
+     *   shell_bary_mode  how shell_logits become barycentric weights (frosting_model.py:713-719): 0 softmax
+     *                    (use_softmax_for_bary_coords = True, the default of the reference) | 1 relu + renormalise:
+     *                    w = relu(x) / max(sum relu(x), 1e-8) ... exactly torch.nn.functional.relu + the division the
+     *                    reference writes, gradient zero where x <= 0 */
+    int exact_blend, tight_binning, async_sh;
+    int shell_bary_mode;
 } frg_forward_args;
 int frg_forward_ex(const frg_forward_args* args);
 
@@ -197,6 +207,10 @@ typedef struct frg_backward_args {
     const float *shell_logits, *shell_cell_verts;
     const long long* shell_cells;
     float *dL_dshell_logits, *dL_dshell_cell_verts;
+    /* second generation (struct_size tells): exact_blend 0 = frg_set_option's value, 1 | 2 = fast | exact arithmetic
+     * of THIS backward's blend pass; shell_bary_mode as in frg_forward_args (must equal the forward's) */
+    int exact_blend;
+    int shell_bary_mode;
 } frg_backward_args;
 int frg_backward_ex(const frg_backward_args* args);
 

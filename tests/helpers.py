@@ -61,8 +61,8 @@ GRAD_FLOOR_FAST = {"dL_dmeans2D": 6e-5, "dL_dcolors": 8e-6, "dL_dopacity": 1.2e-
                    "dL_dsh": 8e-6, "dL_dscales": 1.5e-4, "dL_drotations": 4e-4}
 
 
-def grad_bar(name, noise=0.0, fast=False):
-    return max(5.0 * noise, (GRAD_FLOOR_FAST if fast else GRAD_FLOOR)[name])
+def grad_bar(name, noise=0.0, fast=False, floor_scale=1.0):
+    return max(5.0 * noise, floor_scale * (GRAD_FLOOR_FAST if fast else GRAD_FLOOR)[name])
 
 
 def reference_runs(backward_fn, n=4):

@@ -168,3 +168,140 @@ def test_factored_exchange_needs_gpu_reducer():
     ex.gathered = torch.zeros(1, ex.payload_numel)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ex.sh_reducer(ex)
+
+
+# ---- a training step with a parameter update between views --------------------------------------------------
+# (exchange -> Adam -> next forward) on N ranks must equal the single-process accumulation of the same N views, bit
+# for bit: the in-step schedule leaves nothing of step k in flight when step k+1 reads the parameters.
+
+def _view_gradient(params, view, deg, K):
+    """A deterministic stand-in for one view's backward: depends on the CURRENT parameters (so a stale exchange would
+    show), dense part arbitrary, SH part rank one per Gaussian as the rasterizer's is (basis(view dir) x dRGB)."""
+    from frosting_amd.sh import sh_basis
+    P = params["means3D"].shape[0]
+    campos = 4.0 * torch.nn.functional.normalize(torch.tensor([1.0 + view, 0.5 - view, 2.0]), dim=0)
+    dense = {k: torch.sin(params[k] * (1.5 + view)) * (0.1 + 0.01 * view) for k in ("means3D", "scales", "rotations", "opacities")}
+    drgb = torch.cos(params["shs"][:, 0, :] * (2.0 + view)) * 0.05
+    drgb[(torch.arange(P) + view) % 4 == 0] = 0.0                      # culled / clamped rows of this view
+    d = params["means3D"] - campos
+    basis = sh_basis(deg, d / d.norm(dim=1, keepdim=True))
+    shs = torch.zeros(P, K, 3)
+    shs[:, : basis.shape[1]] = basis[:, :, None] * drgb[:, None, :]
+    return campos, drgb, dense, shs
+
+
+def _initial_params(P, K):
+    g = torch.Generator().manual_seed(321)
+    shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
+    return shapes, {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+
+
+def _train_worker(rank, world, port, P, K, deg, steps, factored, reduce, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes, init = _initial_params(P, K)
+    params = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.Adam([params[k] for k in PARAM_ORDER], lr=0.01, eps=1e-15)
+    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=factored, sh_reducer=torch_sh_reducer, reduce=reduce)
+    for it in range(steps):
+        with torch.no_grad():
+            campos, drgb, dense, shs = _view_gradient({k: v.detach() for k, v in params.items()}, rank, deg, K)
+            for k, v in dense.items():
+                ex.views[k].copy_(v)
+            ex.views["shs"].copy_(shs)
+            if factored:
+                ex.set_sh_context(params["means3D"].detach(), deg)
+                ex.own_drgb.copy_(drgb)
+                ex.own_campos.copy_(campos)
+        ex.start()
+        ex.finish_in_step()                  # complete here: nothing is waited for in a later step
+        assert not ex._works
+        for k in PARAM_ORDER:
+            params[k].grad = ex.views[k].clone()
+        opt.step()
+    q.put((rank, {k: params[k].detach().numpy().copy() for k in PARAM_ORDER}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("factored,reduce", [(False, "allreduce"), (True, "allreduce"), (True, "direct")])
+def test_exchange_then_adam_then_next_forward_equals_single_process_accumulation_gloo(factored, reduce):
+    world, P, K, deg, steps = 2, 131, 16, 3, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, P, K, deg, steps, factored, reduce, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    # one process: the same views accumulated in view order, then the same optimizer
+    shapes, init = _initial_params(P, K)
+    params = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.Adam([params[k] for k in PARAM_ORDER], lr=0.01, eps=1e-15)
+    for it in range(steps):
+        acc = None
+        with torch.no_grad():
+            for v in range(world):
+                _, _, dense, shs = _view_gradient({k: t.detach() for k, t in params.items()}, v, deg, K)
+                cur = dict(dense, shs=shs)
+                acc = cur if acc is None else {k: acc[k] + cur[k] for k in cur}
+        for k in PARAM_ORDER:
+            params[k].grad = acc[k].clone()
+        opt.step()
+    for r in range(world):
+        for k in PARAM_ORDER:
+            assert (torch.from_numpy(res[r][k]) == params[k].detach()).all(), (r, k)     # bit for bit
+
+
+def _densify_worker(rank, world, port, P, steps, q):
+    import torch.distributed as dist
+    from frosting_amd.parallel import DensificationStats
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = DensificationStats(P, "cpu", dist.group.WORLD)
+    for it in range(steps):
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        radii = torch.randint(-2, 30, (P,), generator=g, dtype=torch.int32).clamp_min(0)
+        grad = torch.randn(P, 3, generator=g)
+        st.update(radii, grad)
+    q.put((rank, (st.max_radii2D.numpy().copy(), st.xyz_gradient_accum.numpy().copy(), st.denom.numpy().copy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_densification_statistics_over_a_view_parallel_batch_gloo():
+    """radii MAX and viewspace-gradient-norm / visibility-count SUM across ranks == the reference's per-view updates
+    (gaussian_model.py:404-407, train.py:116-117) applied view after view in one process."""
+    world, P, steps = 2, 97, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_densify_worker, args=(r, world, port, P, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    max_r, accum, denom = torch.zeros(P), torch.zeros(P, 1), torch.zeros(P, 1)
+    for it in range(steps):
+        for v in range(world):
+            g = torch.Generator().manual_seed(1000 * it + v)
+            radii = torch.randint(-2, 30, (P,), generator=g, dtype=torch.int32).clamp_min(0)
+            grad = torch.randn(P, 3, generator=g)
+            vis = radii > 0
+            max_r[vis] = torch.max(max_r[vis], radii[vis].float())                      # train.py:116
+            accum[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)              # gaussian_model.py:405-406
+            denom[vis] += 1
+    for r in range(world):
+        assert (torch.from_numpy(res[r][0]) == max_r).all()
+        torch.testing.assert_close(torch.from_numpy(res[r][1]), accum, rtol=1e-6, atol=1e-6)
+        assert (torch.from_numpy(res[r][2]) == denom).all()

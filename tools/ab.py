@@ -16,11 +16,15 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--view", type=int, default=0)
 ap.add_argument("--order", default="input", choices=["input", "yrow", "morton"],
                 help="memory order of the Gaussians: as generated | by the 16-pixel screen row of the projected centre | Morton order of the pixel")
+ap.add_argument("--scene", default="config", choices=["config", "skew"], help="skew: scenes.make_skew_scene (bench.py's skew_scene)")
+ap.add_argument("--deferred", action="store_true", help="frg_forward_deferred (no host synchronisation inside the step)")
 ap.add_argument("settings", nargs="*", default=[""])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = scenes.CONFIGS[a.config]
 scene, cam, bg = scenes.config_scene(a.config, a.view, P=a.points or cfg["P"])
+if a.scene == "skew":
+    scene = scenes.make_skew_scene(a.points or cfg["P"], cfg["seed"] + 77)
 if a.order != "input":
     # what spatial coherence of the caller's array would be worth to the binning stages (timing experiment)
     ph = torch.cat([scene.means3D.double(), torch.ones(scene.P, 1, dtype=torch.float64)], 1) @ cam.projmatrix.double()
@@ -39,13 +43,15 @@ if a.order != "input":
     perm = torch.argsort(key, stable=True)
     scene = scenes.Scene(scene.means3D[perm].contiguous(), scene.scales[perm].contiguous(), scene.rotations[perm].contiguous(),
                          scene.opacities[perm].contiguous(), scene.shs[perm].contiguous(), scene.sh_degree)
-vpr = ViewParallelRasterizer(scene.to(dev), dev)
+vpr = ViewParallelRasterizer(scene.to(dev), dev, deferred_counters=a.deferred)
 cam_d, bg_d = cam.to(dev), bg.to(dev)
 img, radii = vpr.forward(cam_d, bg_d)
 gpix, _ = scenes.l1_target_grad(img.cpu(), 1)
 gpix = gpix.to(dev)
 def step():
     vpr.forward(cam_d, bg_d); vpr.backward(gpix, 0)
+    if a.deferred and not vpr.finish():
+        vpr.forward(cam_d, bg_d, deferred=False); vpr.backward(gpix, 0)
 for _ in range(100): step()
 base = None
 defaults = {}
