@@ -120,6 +120,9 @@ def lib():
     L.frg_backward_workspace_bytes.restype = sz
     L.frg_backward_workspace_bytes.argtypes = [i, i]
     L.frg_geometry_layout.argtypes = [i, vp]
+    if hasattr(L, "frg_geometry_layout_n"):        # (absent from a version-1 library loaded through FROSTING_LIB for an A/B)
+        L.frg_geometry_layout_n.restype = i
+        L.frg_geometry_layout_n.argtypes = [i, vp, i]
     L.frg_image_layout.argtypes = [i, i, vp]
     L.frg_binning_layout.argtypes = [i, i, vp]
     L.frg_mark_visible.restype = i
@@ -176,6 +179,9 @@ def lib():
     L.frg_mesh_raster_workspace_bytes.argtypes = [i, i, i]
     L.frg_mesh_rasterize.restype = i
     L.frg_mesh_rasterize.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
+    if hasattr(L, "frg_mesh_visible_faces"):
+        L.frg_mesh_visible_faces.restype = i
+        L.frg_mesh_visible_faces.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
     L.frg_sh_color_grad.restype = i
     L.frg_sh_color_grad.argtypes = [i, vp, vp, vp, vp, vp]
     L.frg_sh_grad_from_views.restype = i
@@ -209,8 +215,8 @@ def stage_times() -> dict:
 EXPORTED_SYMBOLS = [
     "frg_version", "frg_last_error", "frg_mark_visible", "frg_forward", "frg_backward_workspace_bytes",
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
-    "frg_binning_bytes", "frg_geometry_layout", "frg_image_layout", "frg_binning_layout",
-    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_sh_color_grad", "frg_sh_grad_from_views",
+    "frg_binning_bytes", "frg_geometry_layout", "frg_geometry_layout_n", "frg_image_layout", "frg_binning_layout",
+    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_mesh_visible_faces", "frg_sh_color_grad", "frg_sh_grad_from_views",
     "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_backward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",
     "frg_knn_workspace_bytes", "frg_knn_mean_dist2", "frg_shell_points", "frg_shell_points_backward",

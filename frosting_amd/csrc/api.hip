@@ -204,6 +204,29 @@ struct ProbeSide {
     }
 };
 thread_local ProbeSide g_probe_side;
+// side stream of the per-Gaussian backward's 16-wave launch (one per host thread, re-created when the thread's
+// current device changes)
+struct BwdSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+    bool ensure()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev == device) return true;
+        if (stream) (void)hipStreamDestroy(stream);
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        stream = nullptr; fork = nullptr; join = nullptr; device = -1;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        device = dev;
+        return true;
+    }
+};
+thread_local BwdSide g_bwd_side;
 
 #define FRG_HIP(call)                                                                              \
     do {                                                                                           \
@@ -249,7 +272,7 @@ FwdModes default_modes() { return FwdModes{exact_blend(), g_tight_binning.load()
 
 extern "C" {
 
-int frg_version(void) { return 1; }
+int frg_version(void) { return 2; }
 const char* frg_last_error(void) { return g_err; }
 
 int frg_set_option(const char* name, int value)
@@ -264,9 +287,17 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
-    if (name && strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
-    if (name && strcmp(name, "probe") == 0) return g_probe.exchange(value);
-    if (name && strcmp(name, "rows_grid") == 0) { const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old; }
+    // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
+    // stray call must not be able to switch them on -- they exist only in processes started with FROSTING_EXPERIMENTS=1
+    if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0)) {
+        static const bool experiments = [] { const char* e = getenv("FROSTING_EXPERIMENTS"); return e && e[0] == '1'; }();
+        if (!experiments)
+            return fail(FRG_EINVAL, "option '%s' is a timing experiment (results are wrong by design): start the process with "
+                                    "FROSTING_EXPERIMENTS=1 to use it", name);
+        if (strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
+        if (strcmp(name, "probe") == 0) return g_probe.exchange(value);
+        const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old;
+    }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -312,16 +343,20 @@ size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nu
 size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count).bytes; }
 size_t frg_backward_workspace_bytes(int P, int R)
 {
-    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256) + frg::bwd_heavy_bytes(P);
+    (void)P;
+    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256);
 }
 
-void frg_geometry_layout(int P, long long* out)
+int frg_geometry_layout_n(int P, long long* out, int n)
 {
     frg::GeomState s = frg::GeomState::carve(nullptr, P);
-    out[0] = (long long)(size_t)s.xydr; out[1] = (long long)(size_t)s.conic_opacity; out[2] = (long long)(size_t)s.rgb_clamped;
-    out[3] = (long long)(size_t)s.tiles_touched; out[4] = (long long)(size_t)s.point_offsets;
-    out[5] = (long long)(16 * FRG_REC);   // byte stride between consecutive Gaussians' float4 of out[0..2]
+    const long long v[6] = {(long long)(size_t)s.xydr, (long long)(size_t)s.conic_opacity, (long long)(size_t)s.rgb_clamped,
+                            (long long)(size_t)s.tiles_touched, (long long)(size_t)s.point_offsets,
+                            (long long)(16 * FRG_REC)};   // [5]: byte stride between consecutive Gaussians' float4 of out[0..2]
+    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    return 6;
 }
+void frg_geometry_layout(int P, long long* out) { (void)frg_geometry_layout_n(P, out, 5); }   // the five values of version 1 callers
 void frg_image_layout(int width, int height, long long* out)
 {
     frg::ImageState s = frg::ImageState::carve(nullptr, width, height, g_global_bins.load() != 0);
@@ -633,7 +668,6 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, false);
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
-    uint32_t* heavy = reinterpret_cast<uint32_t*>(workspace + frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256));
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
@@ -645,18 +679,29 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
         FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, heavy, g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, g_probe_side.stream));
         FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
     }
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), heavy, stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), heavy, stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
-    { StageScope sc_(ST_PREPROCESS_BWD, stream); FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, heavy, stream), "preprocess_bwd"); }
+    {
+        // the 16-wave form for the Gaussians that own thousands of slots runs on a side stream beside the plain kernel
+        // (usually its workgroups find an empty list and leave)
+        StageScope sc_(ST_PREPROCESS_BWD, stream);
+        const bool side = !debug && g_bwd_side.ensure();
+        hipStream_t hs = side ? g_bwd_side.stream : stream;
+        if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, hs), "preprocess_bwd (long runs)");
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, stream), "preprocess_bwd");
+        if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
+    }
     return FRG_OK;
 }
 

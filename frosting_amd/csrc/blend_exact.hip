@@ -16,10 +16,10 @@ hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, cons
 }
 
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                const float* bg, const float* dL_dpix, float* slots, int batch, uint32_t* heavy, hipStream_t s)
+                                const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
-    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, xcd_grid_blocks(T), img.tile_work, img.bwd_order, heavy);
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, xcd_grid_blocks(T), img.tile_work, img.bwd_order);
 #define FRG_BWD(B)                                                                                                         \
     hipLaunchKernelGGL((blend_bwd_kernel<FRG_EXACT, B>), dim3(xcd_grid_blocks(T)), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \

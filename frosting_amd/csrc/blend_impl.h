@@ -214,10 +214,8 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
 // bucket, deepest first) inside their XCD band -- neighbouring tiles still share an L2 -- and dealt
 // to workgroups band-major, so workgroup b (XCD b % 8) takes the (b / 8)-th deepest tile of its band.
 static __global__ void __launch_bounds__(1024)
-bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order,
-                 uint32_t* __restrict__ heavy_count)
+bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order)
 {
-    if (threadIdx.x == 0 && heavy_count) *heavy_count = 0;   // hand-over list of the per-Gaussian backward (preprocess_bwd.hip)
     __shared__ uint32_t base[FRG_NUM_XCD * 64], cur[FRG_NUM_XCD * 64];
     const int tid = threadIdx.x;
     if (tid < FRG_NUM_XCD * 64) { base[tid] = 0; cur[tid] = 0; }

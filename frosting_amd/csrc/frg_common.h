@@ -13,10 +13,15 @@
 #ifndef FRG_SLOT_STRIDE
 #define FRG_SLOT_STRIDE 9   // floats from one instance's slot to the next in the backward workspace
 #endif
+#define FRG_BWD_HEAVY_SLOTS (4 * 896)   // four slot windows of the per-Gaussian backward (preprocess_bwd.hip)
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
 #define FRG_BIN_SEGS 8           // row segments of the column scan
-#define FRG_BIN_MAX_LDS_TILES 10176  // LDS bins of the preprocess (tiles + record cells): 4 bytes each beside 53 KiB of SH staging, 48 KiB of record assembly and the scan scratch (160 KiB per CU)
+// LDS bins of the preprocess (tiles + record cells), 4 bytes each, beside its static arrays -- 52 KiB of SH staging, 48 KiB
+// of record assembly, 20.25 KiB of walk scratch = 123 136 B -- in the CU's 163 840 B, with 256 B to spare for whatever the
+// compiler or the runtime may want (preprocess.hip asserts the sum)
+#define FRG_BIN_STATIC_LDS 123136
+#define FRG_BIN_MAX_LDS_TILES 10112
 #define FRG_MAX_TILE_ROWS 1024       // cells (tile row x band of tile columns) of the scatter's record order; also the largest number of tile rows it handles
 
 namespace frg {
@@ -55,6 +60,10 @@ struct GeomState {
     // d(colour)/d(view direction) of every visible Gaussian, 9 floats {ddx[3], ddy[3], ddz[3]} (ShDir, gauss_math.h):
     // written by the forward's SH pass, read by the per-Gaussian backward instead of the SH rows
     float* sh_dir;
+    // [0] number of, [1 ..] wave numbers of the 64-Gaussian waves whose Gaussians own more than FRG_BWD_HEAVY_SLOTS
+    // instances (near-camera Gaussians of hundreds of tiles): found where point_offsets is finished (reorder_kernel /
+    // scatter_kernel), read by the per-Gaussian backward, which gives each of them a 16-wave workgroup
+    uint32_t* heavy_waves;
     size_t bytes;
     __host__ static GeomState carve(char* base, int P)
     {
@@ -71,6 +80,7 @@ struct GeomState {
         s.internal_radii = (int*)(base + o); o = align_up(o + Pp * 4, 256);
         s.row_records = (uint4*)(base + o); o = align_up(o + Pp * 16, 256);
         s.sh_dir = (float*)(base + o); o = align_up(o + Pp * 36, 256);
+        s.heavy_waves = (uint32_t*)(base + o); o = align_up(o + (Pp / 64 + 2) * 4, 256);
         s.bytes = o;
         return s;
     }

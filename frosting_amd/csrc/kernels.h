@@ -43,9 +43,9 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
                                  const float* bg, float* out_color, hipStream_t s);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, const float* dL_dpix, float* slots, int batch, uint32_t* heavy, hipStream_t s);
+                                  const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, int batch, uint32_t* heavy, hipStream_t s);
+                                 const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
@@ -54,13 +54,12 @@ struct BwdOutputs {
     // [F,6,3] is ACCUMULATED into (caller zeroes it): the learnable shell of learn_shell = True
     float *dL_dshell_logits = nullptr, *dL_dshell_verts = nullptr;
 };
-// tile_moments: the slots hold moments about the tile centre (fast blend backward); heavy: bwd_heavy_bytes(P) of
-// the backward workspace behind the slots -- hand-over list of the waves whose Gaussians own too many slots, zeroed by
-// the blend backward's launch (bwd_order_kernel)
+// tile_moments: the slots hold moments about the tile centre (fast blend backward).  heavy_only: false = every wave of
+// 64 Gaussians that is not on GeomState::heavy_waves (the plain kernel), true = the listed waves (the 16-wave form; any
+// stream ordered after the blend backward)
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int tile_moments,
-                                 uint32_t* heavy, hipStream_t s);
-size_t bwd_heavy_bytes(int P);
+                                 bool heavy_only, hipStream_t s);
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);

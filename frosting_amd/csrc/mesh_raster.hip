@@ -206,9 +206,52 @@ mesh_resolve_kernel(int V, const float4* __restrict__ pos, const int* __restrict
     rast[i] = out;
 }
 
+// visible-face form: no attributes, only "is this face the nearest surface of some pixel"
+__global__ void __launch_bounds__(256)
+mesh_mark_kernel(size_t n, const unsigned long long* __restrict__ depth, unsigned char* __restrict__ face_visible)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = depth[i];
+    if (key != ~0ull) face_visible[(uint32_t)key] = 1;      // (several pixels store the same byte: benign)
+}
+
+// the z-buffer pass shared by both entry points
+static void launch_depth_pass(int V, int F, const float4* p4, const int* tri, int width, int height, char* workspace, hipStream_t s,
+                              unsigned long long*& depth)
+{
+    const size_t N = (size_t)width * height;
+    depth = reinterpret_cast<unsigned long long*>(workspace);
+    uint32_t* big_list = reinterpret_cast<uint32_t*>(workspace + align_up(N * 8, 256));
+    uint32_t* big_count = reinterpret_cast<uint32_t*>(workspace + align_up(N * 8, 256) + align_up((size_t)(F > 0 ? F : 1) * 4, 256));
+    hipLaunchKernelGGL(mesh_clear_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, big_count);
+    if (F > 0) {
+        hipLaunchKernelGGL(mesh_raster_small_kernel, dim3((F + 255) / 256), dim3(256), 0, s, V, F, p4, tri, width, height,
+                           depth, big_list, big_count);
+        hipLaunchKernelGGL(mesh_raster_big_kernel, dim3(2048), dim3(256), 0, s, V, p4, tri, width, height, depth,
+                           big_list, big_count);
+    }
+}
+
 }  // namespace frg
 
 extern "C" {
+
+int frg_mesh_visible_faces(int V, int F, const float* pos, const int* tri, int width, int height, unsigned char* face_visible,
+                           char* workspace, size_t workspace_bytes, void* hip_stream)
+{
+    if (V < 0 || F < 0 || width <= 0 || height <= 0) return FRG_EINVAL;
+    if (F == 0) return FRG_OK;
+    if (!pos || !tri || !face_visible) return FRG_EINVAL;
+    if (!workspace || workspace_bytes < frg_mesh_raster_workspace_bytes(F, width, height)) return FRG_EALLOC;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (hipMemsetAsync(face_visible, 0, (size_t)F, s) != hipSuccess) return FRG_EHIP;
+    unsigned long long* depth = nullptr;
+    frg::launch_depth_pass(V, F, reinterpret_cast<const float4*>(pos), tri, width, height, workspace, s, depth);
+    const size_t N = (size_t)width * height;
+    hipLaunchKernelGGL(frg::mesh_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, face_visible);
+    return hipGetLastError() == hipSuccess ? FRG_OK : FRG_EHIP;
+}
 
 size_t frg_mesh_raster_workspace_bytes(int F, int width, int height)
 {
@@ -223,17 +266,9 @@ int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width
     if (F > 0 && (!pos || !tri)) return FRG_EINVAL;
     hipStream_t s = (hipStream_t)hip_stream;
     const size_t N = (size_t)width * height;
-    unsigned long long* depth = reinterpret_cast<unsigned long long*>(workspace);
-    uint32_t* big_list = reinterpret_cast<uint32_t*>(workspace + frg::align_up(N * 8, 256));
-    uint32_t* big_count = reinterpret_cast<uint32_t*>(workspace + frg::align_up(N * 8, 256) + frg::align_up((size_t)(F > 0 ? F : 1) * 4, 256));
     const float4* p4 = reinterpret_cast<const float4*>(pos);
-    hipLaunchKernelGGL(frg::mesh_clear_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, big_count);
-    if (F > 0) {
-        hipLaunchKernelGGL(frg::mesh_raster_small_kernel, dim3((F + 255) / 256), dim3(256), 0, s, V, F, p4, tri, width, height,
-                           depth, big_list, big_count);
-        hipLaunchKernelGGL(frg::mesh_raster_big_kernel, dim3(2048), dim3(256), 0, s, V, p4, tri, width, height, depth,
-                           big_list, big_count);
-    }
+    unsigned long long* depth = nullptr;
+    frg::launch_depth_pass(V, F, p4, tri, width, height, workspace, s, depth);
     hipLaunchKernelGGL(frg::mesh_resolve_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, V, p4, tri, width, height,
                        depth, reinterpret_cast<float4*>(rast));
     return hipGetLastError() == hipSuccess ? FRG_OK : FRG_EHIP;

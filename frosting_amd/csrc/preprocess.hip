@@ -168,6 +168,14 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* wsum, 
     return off + inc;
 }
 
+// A wave of 64 consecutive Gaussians whose instances number more than FRG_BWD_HEAVY_SLOTS goes on the list of the
+// per-Gaussian backward's 16-wave launch (GeomState::heavy_waves).  inc: the block-inclusive scan of tiles_touched.
+__device__ __forceinline__ void note_heavy_wave(uint32_t inc, uint32_t touched, int first_gaussian, uint32_t* __restrict__ heavy_waves)
+{
+    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64) - ((uint32_t)__shfl((int)inc, 0, 64) - (uint32_t)__shfl((int)touched, 0, 64));
+    if ((threadIdx.x & 63) == 0 && total > (uint32_t)FRG_BWD_HEAVY_SLOTS) heavy_waves[1 + atomicAdd(&heavy_waves[0], 1u)] = (uint32_t)(first_gaussian >> 6);
+}
+
 // Persistent workgroups of 1024 threads walk chunks of 1024 Gaussians (chunk c is
 // always handled by workgroup c % gridDim.x -- the scatter kernel relies on the same
 // map).  Per-tile instance counts are accumulated in an LDS histogram private to the
@@ -289,7 +297,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float4* __restrict__ rgb_clamped, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_rect,
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered,
-                      uint32_t* __restrict__ row_matrix, int band_w, int nbands, float* __restrict__ sh_dir)
+                      uint32_t* __restrict__ row_matrix, int band_w, int nbands, float* __restrict__ sh_dir,
+                      uint32_t* __restrict__ heavy_waves)
 {
     constexpr bool SH16 = SHMODE == SH_STREAM;
     constexpr bool TIGHT = BINMODE == BIN_TIGHT, CELLS = BINMODE == BIN_CELLS;
@@ -301,6 +310,9 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // the chunk's 48-byte records are assembled in LDS (centre / conic first, colour after the SH sum) and leave as
     // one contiguous, fully written block per wave: piecewise 16-byte stores at a 48-byte stride cost 10 % of the kernel
     __shared__ float4 rec_lds[FRG_BIN_THREADS * FRG_REC];
+    static_assert(sizeof(sh_lds) + sizeof(emit_start) + sizeof(emit_info) + sizeof(rec_lds) <= FRG_BIN_STATIC_LDS,
+                  "static LDS of preprocess_fwd_kernel grew: lower FRG_BIN_MAX_LDS_TILES");
+    static_assert(FRG_BIN_STATIC_LDS + 4 * FRG_BIN_MAX_LDS_TILES + 256 <= 160 * 1024, "LDS bins + static arrays exceed the CU's 160 KiB");
     const int T = vp.gx * vp.gy;
     ViewMats vmx;
     load_view_mats(viewmatrix, projmatrix, cam_pos, vmx);
@@ -311,6 +323,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     const int nbins = T + ncells;
     if (LDS_BINS)
         for (int t = threadIdx.x; t < nbins; t += FRG_BIN_THREADS) lds_bins[t] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) heavy_waves[0] = 0;   // (filled where point_offsets is finished)
     // the chunk totals of this workgroup's chunks are accumulated with atomics below
     for (int c = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; c < nchunks; c += FRG_BIN_THREADS * (int)gridDim.x) block_sums[c] = 0;
     __threadfence_block();
@@ -728,7 +741,7 @@ scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ depth_rect, c
                const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ chunk_prefix,
                uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ bin_matrix,
                const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs,
-               const Counters* __restrict__ counters, const float4* __restrict__ conic_opacity)
+               const Counters* __restrict__ counters, const float4* __restrict__ conic_opacity, uint32_t* __restrict__ heavy_waves)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     // wave-uniform: the binning buffer is too small for this frame.  Nothing is scattered (every tile list
@@ -753,6 +766,7 @@ scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ depth_rect, c
         uint32_t total;
         const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
         if (idx < P) point_offsets[idx] = chunk_prefix[c] + inc;
+        note_heavy_wave(inc, touched, c * FRG_BIN_THREADS + (int)(threadIdx.x & ~63u), heavy_waves);
         if (overflow) continue;
         int x0 = 0, y0 = 0, x1 = 1, y1 = 0;
         uint32_t dbits = 0;
@@ -800,7 +814,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
                const uint32_t* __restrict__ row_matrix, const uint32_t* __restrict__ row_total, uint4* __restrict__ row_records,
                Counters* __restrict__ counters,
                int T, int gx, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
-               uint32_t* __restrict__ class_tiles, uint32_t tight)
+               uint32_t* __restrict__ class_tiles, uint32_t tight, uint32_t* __restrict__ heavy_waves)
 {
     const int my_block = (int)blockIdx.x;     // this workgroup's row of the count matrices
     if (my_block == nblocks) {
@@ -832,6 +846,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
         uint32_t total;
         const uint32_t inc = block_incl_scan<FRG_BIN_THREADS / 64>(touched, wsum, &total);
         if (idx < P) point_offsets[idx] = chunk_prefix[c] + inc;
+        note_heavy_wave(inc, touched, c * FRG_BIN_THREADS + (int)(threadIdx.x & ~63u), heavy_waves);
         if (touched) {
             const uint32_t pos = atomicAdd(&cursor[(dr.y >> 16) * nbands + (dr.y & 0xFFFFu) / band_w], 1u);     // ds_add_rtn_u32
             row_records[pos] = make_uint4(dr.x, (uint32_t)idx, dr.y, dr.z);
@@ -980,7 +995,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
-                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir);
+                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves);
     return hipGetLastError();
 }
 
@@ -1029,7 +1044,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,
                            g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
-                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight);
+                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g.heavy_waves);
         return hipGetLastError();
     }
     // the tile totals sit in LDS (T words) when they fit
@@ -1066,7 +1081,7 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
 #define FRG_SCATTER(L, TI, LDS)                                                                                          \
     hipLaunchKernelGGL((scatter_kernel<L, TI>), dim3(nb), dim3(FRG_BIN_THREADS), LDS, s, P, vp.gx, vp.gy, g.depth_rect, g.xydr,    \
                        g.tiles_touched, g.block_sums, g.point_offsets, img.bin_matrix, img.ranges, img.tile_fill, b.pairs,  \
-                       img.counters, g.conic_opacity)
+                       img.counters, g.conic_opacity, g.heavy_waves)
     if (img.lds_bins) {
         const size_t lds = (size_t)T * 4;
         hipError_t e = vp.tight ? allow_big_lds(scatter_kernel<true, true>, lds) : allow_big_lds(scatter_kernel<true, false>, lds);

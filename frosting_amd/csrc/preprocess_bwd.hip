@@ -30,12 +30,12 @@ namespace frg {
 #define BWD_ROW_F4 13                    // 12 float4 of SH + 1 pad (odd stride: conflict-free b128)
 #define BWD_LDS_WORDS (68 + 256 + 576 + BWD_SUB * BWD_ROW_F4 * 4)
 // Slots are reduced in WINDOWS of BWD_WIN slots of the wave's run; a wave whose 64 Gaussians own more than
-// BWD_HEAVY_WINDOWS windows (a handful of near-camera Gaussians covering hundreds of tiles each: one wave walked
-// 38 000 slots while the average wave has 400, and the kernel waited for it -- 0.99 instead of 0.28 ms on the
-// clustered scene) hands its Gaussians to a second launch in which a whole 16-wave workgroup takes the windows
-// 16 at a time.  Per-window sums are added in window order in both forms: the same bits either way.
+// four windows (a handful of near-camera Gaussians covering hundreds of tiles each: one wave walked 38 000 slots while
+// the average wave has 400, and the kernel waited for it -- 0.99 instead of 0.28 ms on the clustered scene) leaves its
+// Gaussians to a second launch, beside this one, in which a whole 16-wave workgroup takes the windows 16 at a time.
+// Per-window sums are added in window order in both forms: the same bits either way.
 #define BWD_WIN 896u                     // 10 bits of position, 6 bits of owner
-#define BWD_HEAVY_WINDOWS 4u
+static_assert(FRG_BWD_HEAVY_SLOTS == 4 * BWD_WIN, "hand-over threshold: four windows");
 #define BWD_HEAVY_WAVES 16
 
 __device__ __forceinline__ void wave_fence()
@@ -60,7 +60,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
-                      const float* __restrict__ sh_dir, int tile_moments, uint32_t* __restrict__ heavy)
+                      const float* __restrict__ sh_dir, int tile_moments, const uint32_t* __restrict__ heavy)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -70,7 +70,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     float* wacc = reinterpret_cast<float*>(lds + 68 + 256);      // [64][9] per-owner sums of the current window
     float4* shbuf = reinterpret_cast<float4*>(lds + 68 + 256 + 576);  // [BWD_SUB][BWD_ROW_F4]
 
-    // heavy[0] = number of handed-over waves, heavy[1 + k] = their wave numbers (zeroed by bwd_order_kernel)
+    // heavy[0] = number of listed waves, heavy[1 + k] = their wave numbers (GeomState::heavy_waves, left by the forward)
   uint32_t heavy_item = HEAVY ? blockIdx.x : 0u;
   if (HEAVY && heavy_item >= heavy[0]) return;                  // (usually: nothing was handed over)
   do {   // HEAVY: the workgroup strides over the handed-over waves; otherwise once
@@ -129,10 +129,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     uint16_t* live = reinterpret_cast<uint16_t*>(shbuf + 96);           // [BWD_WIN] behind own_co / own_xy
     if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
     const uint32_t nwin = (S + BWD_WIN - 1) / BWD_WIN;                   // wave-uniform
-    if (!HEAVY && nwin > BWD_HEAVY_WINDOWS && heavy) {                   // hand the 64 Gaussians to the second launch
-        if (lane == 0) heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)(idx0 >> 6);
-        return;
-    }
+    if (!HEAVY && S > (uint32_t)FRG_BWD_HEAVY_SLOTS) return;             // on the forward's list: the 16-wave launch has it
     // HEAVY: round r gives window 16 r + wave to this wave; non-heavy: window after window
     for (uint32_t wr = 0; wr < (HEAVY ? (nwin + BWD_HEAVY_WAVES - 1) / BWD_HEAVY_WAVES : nwin); wr++) {
         const uint32_t w0 = (HEAVY ? wr * BWD_HEAVY_WAVES + (uint32_t)wave : wr) * BWD_WIN;
@@ -551,7 +548,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int tile_moments,
-                                 uint32_t* heavy, hipStream_t s)
+                                 bool heavy_only, hipStream_t s)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
@@ -562,15 +559,13 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, heavy)
-    if (sh16) FRG_PBW(true, false, grid, block); else FRG_PBW(false, false, grid, block);
-    // the waves that handed their Gaussians over (usually none: the workgroups read the count and leave)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, g.heavy_waves)
+    // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(64), hblock(BWD_HEAVY_WAVES * 64);
-    if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock);
+    if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }
+    else { if (sh16) FRG_PBW(true, false, grid, block); else FRG_PBW(false, false, grid, block); }
 #undef FRG_PBW
     return hipGetLastError();
 }
-
-size_t bwd_heavy_bytes(int P) { return align_up(((size_t)(P > 0 ? P : 1) / 64 + 2) * 4, 256); }
 
 }  // namespace frg

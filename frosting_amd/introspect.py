@@ -18,11 +18,12 @@ class State:
     def __init__(self, P, W, H, R, geom, binning, img):
         L = _lib.lib()
         off = (C.c_longlong * 8)()
+        L.frg_geometry_layout_n.argtypes = [C.c_int, C.c_void_p, C.c_int]
         self.P, self.W, self.H, self.R = P, W, H, R
         T = ((W + 15) // 16) * ((H + 15) // 16)
         N = W * H
-        L.frg_geometry_layout(P, off)
-        stride = int(off[5]) // 4                      # floats between consecutive Gaussians (64-byte records)
+        L.frg_geometry_layout_n(P, off, 6)
+        stride = int(off[5]) // 4                      # floats between consecutive Gaussians (48-byte records)
         rec = _view(geom, off[0], torch.float32, stride * P).view(P, stride)
         self.xydr = rec[:, 0:4]
         self.conic_opacity = rec[:, 4:8]

@@ -86,13 +86,27 @@ def visible_faces(verts, faces, full_proj_transform, height, width, glctx=None):
 
 
 def visible_face_mask(verts, faces, full_proj_transform, height, width, glctx=None):
-    """bool [F]: the face is the nearest surface in at least one pixel.  Same set as visible_faces(),
-    without the sort inside torch.unique: one index_put of the rasterizer's id plane (the per-frame
-    path of frosting_model.py:1524-1539 only needs the mask, :1564-1566)."""
-    rast, _ = rasterize(glctx, clip_space_vertices(verts, full_proj_transform), faces, [height, width])
-    mask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool, device=faces.device)
-    mask[rast[..., 3].reshape(-1).long()] = True          # id + 1, 0 = empty
-    return mask[1:]
+    """bool [F]: the face is the nearest surface in at least one pixel.  Same set as visible_faces(), through
+    frg_mesh_visible_faces: the z-buffer pass + one byte store per covered pixel, without the attribute resolve, the
+    [H,W,4] plane, the sort inside torch.unique or an index_put (the per-frame path of frosting_model.py:1524-1539
+    only needs the mask, :1564-1566)."""
+    pos = clip_space_vertices(verts, full_proj_transform)[0].detach().to(torch.float32).contiguous()
+    if not pos.is_cuda:
+        raise RuntimeError("frosting_amd.mesh.visible_face_mask needs ROCm device tensors (no CPU path)")
+    dev = pos.device
+    t = faces.detach().to(device=dev, dtype=torch.int32).contiguous()
+    V, F, H, W = pos.shape[0], t.shape[0], int(height), int(width)
+    L = _lib.lib()
+    mask = torch.empty(F, dtype=torch.bool, device=dev)
+    ctx = glctx if isinstance(glctx, RasterizeGLContext) else RasterizeGLContext()
+    work = ctx.workspace(int(L.frg_mesh_raster_workspace_bytes(F, W, H)), dev)
+    with torch.cuda.device(dev):
+        rc = L.frg_mesh_visible_faces(V, F, C.c_void_p(pos.data_ptr()) if V else None, C.c_void_p(t.data_ptr()) if F else None, W, H,
+                                      C.c_void_p(mask.data_ptr()) if F else None, C.c_void_p(work.data_ptr()), work.numel(),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(f"frg_mesh_visible_faces failed ({rc}): {_lib.last_error()}")
+    return mask
 
 
 def occlusion_mask_from_face_mask(point_cell_indices, face_mask, n_background=0):

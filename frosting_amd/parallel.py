@@ -332,11 +332,15 @@ class ViewParallelRasterizer:
 
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
                  deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce",
-                 write_all_outputs: bool = True):
+                 write_all_outputs: bool = True, raw_params: bool = False):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
         self.dev = torch.device(device)
+        # raw_params: scene.opacities / scales / rotations hold the model's RAW parameters (logit, log, unnormalised
+        # quaternion); the activations run inside the per-Gaussian kernels (frg_forward_ex / frg_backward_ex) and the
+        # gradients written to the flat buffer are those of the raw parameters -- straight into the optimizer
+        self.raw_params = raw_params
         self.deferred_counters = deferred_counters
         self.capacity_slack = capacity_slack
         self.capacity = 0            # instances the binning arena is sized for (deferred forwards)
@@ -378,16 +382,20 @@ class ViewParallelRasterizer:
             self.out_color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         use_deferred = (self.deferred_counters if deferred is None else deferred) and self.capacity > 0
-        if keep_mask is not None:
+        if keep_mask is not None or self.raw_params:
             v = lambda t: None if t is None else t.data_ptr()
+            rawkw = {}
+            if self.raw_params:
+                rawkw = dict(raw_opacities=v(s.opacities), raw_scales=v(s.scales), raw_rotations=v(s.rotations))
             a = _lib.ForwardArgs(
                 struct_size=C.sizeof(_lib.ForwardArgs), geometry_alloc=self.geom.cb, binning_alloc=self.binning.cb,
                 image_alloc=self.img.cb, user=None, P=self.P, D=s.sh_degree, M=self.K, background=v(bg), width=W, height=H,
-                means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, opacities=v(s.opacities), scales=v(s.scales),
-                scale_modifier=1.0, rotations=v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix),
+                means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, opacities=None if self.raw_params else v(s.opacities),
+                scales=None if self.raw_params else v(s.scales),
+                scale_modifier=1.0, rotations=None if self.raw_params else v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix),
                 projmatrix=v(cam.projmatrix), cam_pos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy),
                 prefiltered=0, out_color=v(self.out_color), radii=v(self.radii), debug=0, hip_stream=stream.value,
-                instance_capacity=self.capacity if use_deferred else 0, keep_mask=v(keep_mask))
+                instance_capacity=self.capacity if use_deferred else 0, keep_mask=v(keep_mask), **rawkw)
             self._keep_alive = keep_mask
             rc = L.frg_forward_ex(C.byref(a))
         else:
@@ -445,17 +453,22 @@ class ViewParallelRasterizer:
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        rc = L.frg_backward(self.P, s.sh_degree, self.K, self.num_rendered, _p(bg), W, H,
-                            _p(s.means3D), _p(s.shs), None,
-                            _p(s.scales), 1.0, _p(s.rotations), None,
-                            _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
-                            float(cam.tanfovx), float(cam.tanfovy), _p(self.radii),
-                            _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
-                            _p(self.dL_dmeans2D), None, _p(g["opacities"]),
-                            # deferred SH rows: dL_dcolor receives the masked colour gradient = the exchange payload
-                            _p(ex.own_drgb) if defer_sh else (_p(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
-                            _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
-                            _p(work), work.numel(), 0, stream)
+        if self.raw_params:
+            v = lambda t: None if t is None else t.data_ptr()
+            a = _lib.BackwardArgs(
+                struct_size=C.sizeof(_lib.BackwardArgs), P=self.P, D=s.sh_degree, M=self.K, R=self.num_rendered, background=v(bg),
+                width=W, height=H, means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, scales=None, scale_modifier=1.0,
+                rotations=None, cov3D_precomp=None, viewmatrix=v(cam.viewmatrix), projmatrix=v(cam.projmatrix),
+                campos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy), radii=v(self.radii),
+                geom_buffer=v(self.geom.buf), binning_buffer=v(self.binning.buf), image_buffer=v(self.img.buf),
+                dL_dpix=v(dL_dimage), dL_dmean2D=v(self.dL_dmeans2D), dL_dconic=None, dL_dopacity=v(g["opacities"]),
+                dL_dcolor=v(ex.own_drgb) if defer_sh else (v(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
+                dL_dmean3D=v(g["means3D"]), dL_dcov3D=v(self.dL_dcov3D), dL_dsh=None if defer_sh else v(g["shs"]),
+                dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), workspace=v(work), workspace_bytes=work.numel(), debug=0,
+                hip_stream=stream.value, raw_opacities=v(s.opacities), raw_scales=v(s.scales), raw_rotations=v(s.rotations))
+            rc = L.frg_backward_ex(C.byref(a))
+        else:
+            rc = self._backward_plain(L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
         if ex.factor_sh and (ex._active() if payload is None else payload):
@@ -468,6 +481,19 @@ class ViewParallelRasterizer:
             # the caching allocator placed at the previous one's address from the previous one
             ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
         return g
+
+    def _backward_plain(self, L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream):
+        return L.frg_backward(self.P, s.sh_degree, self.K, self.num_rendered, _p(bg), W, H,
+                            _p(s.means3D), _p(s.shs), None,
+                            _p(s.scales), 1.0, _p(s.rotations), None,
+                            _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
+                            float(cam.tanfovx), float(cam.tanfovy), _p(self.radii),
+                            _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
+                            _p(self.dL_dmeans2D), None, _p(g["opacities"]),
+                            # deferred SH rows: dL_dcolor receives the masked colour gradient = the exchange payload
+                            _p(ex.own_drgb) if defer_sh else (_p(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
+                            _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
+                            _p(work), work.numel(), 0, stream)
 
     def exchange_in_step(self, slot: int = 0):
         """start_exchange + GradientExchange.finish_in_step: the gradients of buffer `slot` are the sums over ranks

@@ -48,7 +48,11 @@ extern "C" {
  * backward has run (replaces std::function<char*(size_t)>, rasterizer.h:32-34). */
 typedef char* (*frg_alloc_fn)(void* user, size_t bytes);
 
-/* API / ABI version of this header. */
+/* API / ABI version of this header: 2.  (1 -> 2: the geometry chunk interleaves its three float4 arrays into one
+ * 48-byte record per Gaussian -- frg_geometry_layout_n reports the stride; frg_forward_args / frg_backward_args grew
+ * per-call modes, struct_size-gated; frg_backward_workspace_bytes grew by a hand-over list; everything version 1
+ * callers could call keeps its signature.) */
+#define FRG_VERSION 2
 int frg_version(void);
 const char* frg_last_error(void);
 
@@ -208,7 +212,7 @@ typedef struct frg_backward_args {
     const long long* shell_cells;
     float *dL_dshell_logits, *dL_dshell_cell_verts;
     /* second generation (struct_size tells): exact_blend 0 = frg_set_option's value, 1 | 2 = fast | exact arithmetic
-     * of THIS backward's blend pass; shell_bary_mode as in frg_forward_args (must equal the forward's) */
+     * of THIS backward's blend pass; shell_bary_mode as in frg_forward_args, and equal to the forward's */
     int exact_blend;
     int shell_bary_mode;
 } frg_backward_args;
@@ -221,7 +225,7 @@ int frg_backward_ex(const frg_backward_args* args);
  * tile counts and sort keys never depend on this switch.  "profile": see
  * frg_stage_times; "profile_stage": k in 0..6 restricts the events to stage k (each event
  * record costs a few microseconds of stream time), -1 (default) = every stage.  "global_bins": 1 forces the binning path used for images with
- * more than 9216 tiles (global atomics instead of LDS histograms; test hook).
+ * more than 10112 tiles (global atomics instead of LDS histograms; test hook).
  * "tight_binning": 1 = a (Gaussian, tile) instance is only put on the tile's list if the Gaussian can
  * reach alpha >= 1/255 somewhere in the tile (the closed-form bound the blend kernels use per 8x8
  * quadrant, taken over the 16x16 tile); the reference lists every tile of the 3-sigma square
@@ -250,13 +254,16 @@ size_t frg_binning_bytes(int R, int max_tile_count);
  * geometry: out[0]=xy_depth_radius (float4[P]: pixel x, pixel y, view depth, radius)
  *           out[1]=conic_opacity (float4[P]) out[2]=rgb_clamped (float4[P]: r,g,b, clamp bits)
  *           out[3]=tiles_touched (u32[P])    out[4]=point_offsets (u32[P], inclusive scan)
- *           out[5]=byte stride between consecutive Gaussians' float4 of out[0..2] (they are interleaved in one
- *           48-byte record per Gaussian); `out` needs room for 6 values
+ *           out[5]=byte stride between consecutive Gaussians' float4 of out[0..2] (since library version 2 they are
+ *           interleaved in one 48-byte record per Gaussian: element i of each lives at out[k] + i * out[5]);
+ *           frg_geometry_layout_n only -- frg_geometry_layout keeps writing the five values version 1 callers
+ *           made room for
  * image:    out[0]=final_T (f32[H*W]) out[1]=n_contrib (u32[H*W]) out[2]=ranges (uint2[tiles])
  *           out[3]=tile_count (u32[tiles])
  * binning:  out[0]=point_list (u32[R], sorted by (tile, depth, index))
  *           out[1]=pairs_unsorted (uint2[R]: depth bits, index; tile-major, unsorted) */
-void frg_geometry_layout(int P, long long* out);
+void frg_geometry_layout(int P, long long* out);               /* writes out[0..4] only (the form of library version 1) */
+int frg_geometry_layout_n(int P, long long* out, int n);       /* writes min(n, 6) values, returns 6 = how many there are */
 void frg_image_layout(int width, int height, long long* out);
 void frg_binning_layout(int R, int max_tile_count, long long* out);
 
@@ -272,6 +279,12 @@ void frg_binning_layout(int R, int max_tile_count, long long* out);
 size_t frg_mesh_raster_workspace_bytes(int F, int width, int height);
 int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width, int height,
                        float* rast, char* workspace, size_t workspace_bytes, void* hip_stream);
+/* The same z-buffer pass reduced to what Frosting's occlusion culling consumes (frosting_model.py:1534-1539,
+ * 1564-1566: pix_to_face -> the set of visible faces): face_visible[f] (one byte per triangle, fully written) = 1 iff
+ * triangle f is the nearest surface at some pixel centre -- exactly the ids of frg_mesh_rasterize's fourth plane --
+ * without the attribute resolve and the [H,W,4] plane (same workspace size). */
+int frg_mesh_visible_faces(int V, int F, const float* pos, const int* tri, int width, int height,
+                           unsigned char* face_visible, char* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* ---- view-parallel gradient exchange helpers ---------------------------------------
  * No counterpart in the (single-GPU) reference; SURVEY.md 8(e).  The per-view SH gradient

@@ -20,6 +20,7 @@ import os
 import subprocess
 
 from setuptools import find_packages, setup
+from setuptools.command.build_py import build_py
 from torch.utils.cpp_extension import BuildExtension, CppExtension
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,11 +28,24 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 CSRC = os.path.join("frosting_amd", "csrc")
 
 
+def make_hip_library():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, CSRC), "-j8", "ARCH=gfx950"])
+
+
 class BuildHipThenBinding(BuildExtension):
     """hipcc (Makefile) first: the binding links against the library it produces."""
 
     def run(self):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, CSRC), "-j8", "ARCH=gfx950"])
+        make_hip_library()
+        super().run()
+
+
+class BuildPyWithHipLibrary(build_py):
+    """`pip install .` runs build_py BEFORE build_ext: package_data's lib/*.so is collected here, so the HIP library
+    must exist by now -- otherwise a non-editable install ships _C without the library its rpath points at."""
+
+    def run(self):
+        make_hip_library()
         super().run()
 
 
@@ -54,6 +68,6 @@ setup(
     packages=find_packages(include=["diff_gaussian_rasterization", "frosting_amd", "frosting_amd.*"]),
     package_data={"frosting_amd": ["lib/*.so"]},
     ext_modules=[binding],
-    cmdclass={"build_ext": BuildHipThenBinding.with_options(use_ninja=False)},
+    cmdclass={"build_ext": BuildHipThenBinding.with_options(use_ninja=False), "build_py": BuildPyWithHipLibrary},
     zip_safe=False,
 )

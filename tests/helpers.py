@@ -47,21 +47,35 @@ def native_ops(binding: str):
 # Per-tensor bars for gradients against the reference's own backward (rel. L2 over the whole tensor).
 # Ours is bit-reproducible; the reference sums 9 float atomics per (pixel, Gaussian) pair in scheduling order, so
 # it differs from ITSELF run to run by 5e-8 (colour) .. 3e-4 (quaternion) at the C2 / C3 / C4 sizes.  A comparison
-# passes within max(5 x that measured spread, floor).  Floors = ~3-4x the largest difference measured at full
-# size (profiles/r02_pytest_gpu.log, 3 M Gaussians):
-#   EXACT arithmetic (the reference's operation order): 7e-7 means2D (4.6e-6 on the thin shell of C4), 2e-7 colour / opacity / SH, 6e-6 means3D,
-#     2e-5 cov3D; scales / quaternion sit at the reference's own noise (1e-5 .. 3e-4);
+# against the live reference passes within max(5 x that measured spread, floor).  Floors = at most ~3x the largest
+# difference measured at full size where the spread term does not cover it (3 M Gaussians, round 3:
+# gpurun_out/s1_pytest.log, profiles/r03_pytest_gpu.log):
+#   EXACT arithmetic (the reference's operation order): 6.1e-7 means2D, 2.3e-7 colour / SH, 2.6e-7 opacity, 1.5e-6 means3D,
+#     1.6e-5 cov3D, 1.2e-5 scales, 4.1e-5 quaternions;
 #   default (fast) arithmetic -- falloff as exp2 of a pre-scaled quadratic form in fused multiply-adds: alpha
 #     agrees with the reference's to ~5e-7, which the strongly cancelling sums behind dL_dmeans2D / dL_dmeans3D
-#     turn into 2.7e-5 at 3 M Gaussians.
-# (Round 1 used a blanket 3e-4.)
-GRAD_FLOOR = {"dL_dmeans2D": 8e-6, "dL_dcolors": 2e-6, "dL_dopacity": 2e-6, "dL_dmeans3D": 2e-5, "dL_dcov3D": 6e-5,
-              "dL_dsh": 2e-6, "dL_dscales": 1e-4, "dL_drotations": 3e-4}
-GRAD_FLOOR_FAST = {"dL_dmeans2D": 6e-5, "dL_dcolors": 8e-6, "dL_dopacity": 1.2e-5, "dL_dmeans3D": 6e-5, "dL_dcov3D": 1e-4,
-                   "dL_dsh": 8e-6, "dL_dscales": 1.5e-4, "dL_drotations": 4e-4}
+#     turn into 2.7e-5 / 2.5e-5; 2.6e-6 colour / SH, 4.5e-6 opacity, 2.5e-5 cov3D, 2.4e-5 scales, 5.7e-5 quaternions.
+# Scenes whose sums are much longer than the uniform scene's (near-camera Gaussians of hundreds of tiles, cluster tiles
+# of 10^5 entries, the thin shell of C4 seen edge-on) pass floor_scale = 3: two valid float32 summation orders drift apart
+# with the length of the sum.  (Round 1 used a blanket 3e-4; round 2 floors 2-7x above the measurements.)
+GRAD_FLOOR = {"dL_dmeans2D": 2e-6, "dL_dcolors": 8e-7, "dL_dopacity": 8e-7, "dL_dmeans3D": 5e-6, "dL_dcov3D": 3e-5,
+              "dL_dsh": 8e-7, "dL_dscales": 3e-5, "dL_drotations": 1.5e-4}
+GRAD_FLOOR_FAST = {"dL_dmeans2D": 6e-5, "dL_dcolors": 8e-6, "dL_dopacity": 1.2e-5, "dL_dmeans3D": 6e-5, "dL_dcov3D": 7e-5,
+                   "dL_dsh": 8e-6, "dL_dscales": 7e-5, "dL_drotations": 1.7e-4}
+# Comparisons WITHOUT a spread estimate: against the committed golden fixtures (ONE stored run of the reference: its
+# atomic-order noise is frozen into the fixture) and against the C oracle's sequential summation at small sizes, where
+# single Gaussians dominate a tensor's norm.  Round 2's floors, unchanged.
+FIXTURE_FLOOR = {"dL_dmeans2D": 8e-6, "dL_dcolors": 2e-6, "dL_dopacity": 2e-6, "dL_dmeans3D": 2e-5, "dL_dcov3D": 6e-5,
+                 "dL_dsh": 2e-6, "dL_dscales": 1e-4, "dL_drotations": 3e-4}
+FIXTURE_FLOOR_FAST = {"dL_dmeans2D": 6e-5, "dL_dcolors": 8e-6, "dL_dopacity": 1.2e-5, "dL_dmeans3D": 6e-5, "dL_dcov3D": 1e-4,
+                      "dL_dsh": 8e-6, "dL_dscales": 1.5e-4, "dL_drotations": 4e-4}
 
 
-def grad_bar(name, noise=0.0, fast=False, floor_scale=1.0):
+def grad_bar(name, noise=None, fast=False, floor_scale=1.0):
+    """noise given (the reference's measured run-to-run spread): max(5 x noise, floor_scale x floor);
+    noise None: the fixture / oracle floors."""
+    if noise is None:
+        return (FIXTURE_FLOOR_FAST if fast else FIXTURE_FLOOR)[name]
     return max(5.0 * noise, floor_scale * (GRAD_FLOOR_FAST if fast else GRAD_FLOOR)[name])
 
 

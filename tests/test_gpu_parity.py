@@ -58,7 +58,7 @@ def ops(request):
 
 def test_native_library_is_loaded(gpu_device):
     L = _lib.lib()
-    assert L.frg_version() == 1
+    assert L.frg_version() == 2
     with open("/proc/self/maps") as f:
         assert "libfrosting_rasterizer.so" in f.read()
 
@@ -574,7 +574,8 @@ def test_per_call_modes_of_two_rasterizers_on_two_threads(gpu_device):
             _lib.set_option(k, v)
         out = _C.rasterize_gaussians(*args)
         st = State(scene.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
-        want.append((out[1].clone(), out[2].clone(), st.point_list.clone()))
+        # (tight lists are shorter than num_rendered: only point_list[: end of the last range] is written)
+        want.append((out[1].clone(), out[2].clone(), st.point_list[: int(st.ranges.max())].clone(), st.ranges.clone()))
         for k in md:
             _lib.set_option(k, 0)
     _lib.set_option("exact_blend", 0); _lib.set_option("tight_binning", 0); _lib.set_option("async_sh", 0)
@@ -589,7 +590,8 @@ def test_per_call_modes_of_two_rasterizers_on_two_threads(gpu_device):
                     st = State(scene.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
                     torch.cuda.current_stream().synchronize()
                     if not (torch.equal(out[1], want[which][0]) and torch.equal(out[2], want[which][1]) and
-                            torch.equal(st.point_list, want[which][2])):
+                            torch.equal(st.ranges, want[which][3]) and
+                            torch.equal(st.point_list[: want[which][2].numel()], want[which][2])):
                         errors.append((which, it))
         except Exception as ex:      # noqa: BLE001
             errors.append((which, repr(ex)))
@@ -672,13 +674,14 @@ def test_deferred_forward_overflow_then_backward_before_finish(gpu_device):
 
 @pytest.mark.parametrize("tight", [0, 1])
 def test_full_size_image_every_binning_mode_fits_the_lds(gpu_device, tight):
-    """The LDS budget of the binning kernels depends on the number of tiles: run the full 1600x1056 grid (6600 tiles),
-    the largest square grid whose tile bins AND record cells fit the LDS (1536^2: 9216 tiles + 960 cells = the limit,
-    cell-ordered scatter), one whose tile bins alone fit (1600^2: 10000 tiles, scatter in the caller's order) and one
-    beyond the LDS (1664^2: 10816 tiles, global-atomic binning), in both binning modes, against the C oracle."""
+    """The LDS budget of the binning kernels depends on the number of tiles (FRG_BIN_MAX_LDS_TILES = 10112 bins): run
+    the full 1600x1056 grid (6600 tiles), the largest grid of 1536 columns whose tile bins AND record cells fit the LDS
+    (1536x1520: 9120 tiles + 950 cells = 10070, cell-ordered scatter), one with both just beyond (1536^2: 9216 + 960 =
+    10176: scatter in the caller's order), the largest whose tile bins alone fit (1616x1600: 101 x 100 = 10100 tiles) and
+    one beyond the LDS (1664^2: 10816 tiles, global-atomic binning), in both binning modes, against the C oracle."""
     scene, _, bg = scenes.config_scene("c2", 0, P=20_000)
     _lib.set_option("tight_binning", tight)
-    for (w, h) in [(1600, 1056), (1536, 1536), (1600, 1600), (1664, 1664)]:
+    for (w, h) in [(1600, 1056), (1536, 1520), (1536, 1536), (1616, 1600), (1664, 1664)]:
         cam = scenes.ring_camera(2, w, h, 1334.0, 1334.0)
         out, _ = Hh.run_ours_native(scene, cam, bg, gpu_device)
         o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.frg_version() == 1
+    assert L.frg_version() == 2
 
 
 def test_state_size_queries_and_options():
@@ -39,6 +39,10 @@ def test_state_size_queries_and_options():
     assert _lib.get_option("exact_blend") == 1
     _lib.set_option("exact_blend", old)
     assert _lib.set_option("no_such_option", 1) < 0 and "unknown option" in _lib.last_error()
+    # the timing-experiment knobs (kernels skip work: wrong results) only exist under FROSTING_EXPERIMENTS=1
+    if os.environ.get("FROSTING_EXPERIMENTS") != "1":
+        for knob in ("ablate", "probe", "rows_grid"):
+            assert _lib.set_option(knob, 1) < 0 and "FROSTING_EXPERIMENTS" in _lib.last_error()
 
 
 def test_settings_fields_match_reference_order():

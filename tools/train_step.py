@@ -2,8 +2,10 @@
 exp / normalize of the raw parameters) -> rasterizer forward -> fused photometric loss (value + dL/dimage)
 -> rasterizer backward (gradients straight into the flat buffer) -> activations backward, in place on that
 buffer -> fused Adam over it (features_dc / features_rest rates on one SH tensor).  The raw parameters live
-in FlatAdam's flat buffer.  Prints the time of each part and of the whole step.  (Frosting's shell
-parameterisation of the means, SURVEY 8(f) rank 3, is not built.)"""
+in FlatAdam's flat buffer.  Prints the time of each part and of the whole step, twice: with the two activation
+launches (round 2's step), and with the activations evaluated inside the per-Gaussian kernels (SURVEY 8(f) rank 3:
+ViewParallelRasterizer(raw_params=True) -> frg_forward_ex / frg_backward_ex on the raw parameters, gradients w.r.t.
+the raw parameters straight into the optimizer's buffer, no activated tensor in memory)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,9 +43,19 @@ vpr = ViewParallelRasterizer(live, dev)
 cam_d, bg_d = cam.to(dev), bg.to(dev)
 img, _ = vpr.forward(cam_d, bg_d)
 target = (img + 0.05 * torch.randn_like(img)).clamp(0, 1)
+# the same model, raw: the rasterizer reads the optimizer's buffers directly
+raw_scene = scenes.Scene(opt.params["means3D"], opt.params["scales"], opt.params["rotations"], opt.params["opacities"],
+                         opt.params["shs"], scene.sh_degree)
+vpr_raw = ViewParallelRasterizer(raw_scene, dev, raw_params=True)
 
 
-def step():
+def step(raw):
+    if raw:
+        image, _ = vpr_raw.forward(cam_d, bg_d)
+        loss, dimg = photometric_loss_and_grad(image, target)
+        vpr_raw.backward(dimg, 0)
+        opt.step(vpr_raw.exchange.flat)
+        return loss
     activations()
     image, _ = vpr.forward(cam_d, bg_d)
     loss, dimg = photometric_loss_and_grad(image, target)
@@ -53,30 +65,36 @@ def step():
     return loss
 
 
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
-n, acc = 20, [0.0] * 6
-t0 = time.perf_counter()
-losses = []
-for _ in range(n):
-    ev[0].record(); activations()
-    ev[1].record(); image, _ = vpr.forward(cam_d, bg_d)
-    ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
-    ev[3].record(); g = vpr.backward(dimg, 0)
-    ev[4].record(); activations_backward(g)
-    ev[5].record(); opt.step(vpr.exchange.flat)
-    ev[6].record(); torch.cuda.synchronize()
-    for k in range(6):
-        acc[k] += ev[k].elapsed_time(ev[k + 1])
-    losses.append(float(loss))
-t_sync = (time.perf_counter() - t0) / n
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(n):
-    step()
-torch.cuda.synchronize()
-t = (time.perf_counter() - t0) / n
-print(f"C3 native training step, P={scene.P}: activations {acc[0]/n:.3f} ms, forward {acc[1]/n:.3f} ms, loss fwd+bwd "
-      f"{acc[2]/n:.3f} ms, backward {acc[3]/n:.3f} ms, activations backward {acc[4]/n:.3f} ms, Adam {acc[5]/n:.3f} ms")
-print(f"whole step {1e3*t:.3f} ms = {1/t:.0f} steps/s (loss {losses[0]:.5f} -> {losses[-1]:.5f} over {n} steps of the same view)")
+for raw in (False, True):
+    for _ in range(8):
+        step(raw)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+    n, acc = 20, [0.0] * 6
+    losses = []
+    for _ in range(n):
+        if raw:
+            ev[0].record(); ev[1].record(); image, _ = vpr_raw.forward(cam_d, bg_d)
+            ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
+            ev[3].record(); vpr_raw.backward(dimg, 0)
+            ev[4].record(); ev[5].record(); opt.step(vpr_raw.exchange.flat)
+        else:
+            ev[0].record(); activations()
+            ev[1].record(); image, _ = vpr.forward(cam_d, bg_d)
+            ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
+            ev[3].record(); g = vpr.backward(dimg, 0)
+            ev[4].record(); activations_backward(g)
+            ev[5].record(); opt.step(vpr.exchange.flat)
+        ev[6].record(); torch.cuda.synchronize()
+        for k in range(6):
+            acc[k] += ev[k].elapsed_time(ev[k + 1])
+        losses.append(float(loss))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        step(raw)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / n
+    what = "raw parameters into the rasterizer (activations inside the per-Gaussian kernels)" if raw else "activation launches around the rasterizer"
+    print(f"C3 native training step, P={scene.P}, {what}: activations {acc[0]/n:.3f} ms, forward {acc[1]/n:.3f} ms, loss fwd+bwd "
+          f"{acc[2]/n:.3f} ms, backward {acc[3]/n:.3f} ms, activations backward {acc[4]/n:.3f} ms, Adam {acc[5]/n:.3f} ms")
+    print(f"    whole step {1e3*t:.3f} ms = {1/t:.0f} steps/s (loss {losses[0]:.5f} -> {losses[-1]:.5f} over {n} steps of the same view)")
