@@ -37,6 +37,8 @@ std::atomic<int> g_global_bins{0};    // test hook: force the large-image (globa
 std::atomic<int> g_ablate{0};         // TIMING EXPERIMENTS ONLY: kernels skip parts of their work (results are wrong)
 std::atomic<int> g_async_sh{0};       // SH colours on a side stream beside the binning stages (0: inside preprocess)
 std::atomic<int> g_bwd_batch{3};      // tuning: instances per reduction step of the backward blend (2 | 3)
+// backward blend: quadrant form at or below this many active tiles (-1: FRG_BWD_QUAD_TILES; 0: never); FROSTING_BWD_QUAD_TILES presets it
+std::atomic<int> g_bwd_quad{[] { const char* e = getenv("FROSTING_BWD_QUAD_TILES"); return e ? atoi(e) : -1; }()};
 std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
 // TIMING EXPERIMENTS ONLY (results are those of the previous frame's lists / slots): bit 0 launches the forward blend
 // beside the sort, bit 1 the per-Gaussian backward beside the backward blend -- an upper bound on what overlapping
@@ -287,6 +289,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
+    if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
     // stray call must not be able to switch them on -- they exist only in processes started with FROSTING_EXPERIMENTS=1
     if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0)) {
@@ -334,6 +337,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.load();
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
+    if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -686,9 +690,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
     {

@@ -213,17 +213,43 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
 // run alone (makespan ~1.9x the balanced one).  Tiles are bucketed by processed depth (32 entries per
 // bucket, deepest first) inside their XCD band -- neighbouring tiles still share an L2 -- and dealt
 // to workgroups band-major, so workgroup b (XCD b % 8) takes the (b / 8)-th deepest tile of its band.
+// Few active tiles (a mesh-bound shell seen from outside covers a fifth of the image; BASELINE configs[3]): one wave per
+// tile then leaves most of the chip idle while every wave walks its tile's 10^3 .. 10^4 entries alone -- 0.77 ms for 5 M
+// instances on 1 400 tiles, twice the time of the 16 M instances of C3.  At or below FRG_BWD_QUAD_TILES active tiles
+// (tiles in which the forward blended anything: the same number in both binning modes) the QUADRANT form runs instead:
+// four waves per tile, one pixel per lane (blend_bwd_quad_kernel), tiles dealt deepest first over the whole chip
+// instead of per XCD band (the active tiles of such a scene sit in a few bands).  Measured crossover (tools/ab.py --shrink,
+// the C3 scene scaled to cover part of the 6600-tile image): 2 142 active tiles (C4) 0.79 -> 0.56 ms with the quadrant
+// form, ~3 000 equal (0.57 / 0.60), 5 600 and up the tile form wins (0.50 / 0.78; C3 itself 0.39 / 0.81).
+#define FRG_BWD_QUAD_TILES 2560
 static __global__ void __launch_bounds__(1024)
-bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order)
+bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order,
+                 uint32_t* __restrict__ bwd_mode, uint32_t quad_tiles, uint2* __restrict__ cutoff)
 {
     __shared__ uint32_t base[FRG_NUM_XCD * 64], cur[FRG_NUM_XCD * 64];
+    __shared__ uint32_t n_active;
     const int tid = threadIdx.x;
     if (tid < FRG_NUM_XCD * 64) { base[tid] = 0; cur[tid] = 0; }
+    if (tid == 0) n_active = 0;
     for (int b = tid; b < nblocks; b += 1024) order[b] = 0xFFFFFFFFu;   // padding workgroups
     __syncthreads();
+    // A tile in which the forward blended nothing processes no instance: its cutoff key says so HERE -- the quadrant
+    // form only launches workgroups for the active tiles, and the per-Gaussian backward must not find the key an
+    // earlier frame left for such a tile.
+    uint32_t mine = 0;
     for (int t = tid; t < T; t += 1024) {
-        const uint32_t k = 63u - min(63u, tile_work[t] >> 5);
-        atomicAdd(&base[xcd_of_tile(t, T) * 64 + k], 1u);
+        if (tile_work[t]) mine++;
+        else cutoff[t] = make_uint2(0u, 0u);
+    }
+    if (mine) atomicAdd(&n_active, mine);
+    __syncthreads();
+    const bool quad = n_active <= quad_tiles;
+    if (tid == 0) *bwd_mode = quad ? 1u : 0u;
+    // 63 buckets of 32 entries of processed depth, deepest first; the tiles where nothing was blended come last (bucket 63),
+    // so that the active tiles are exactly the first n_active of the order
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t wk = tile_work[t], k = wk ? 62u - min(62u, wk >> 5) : 63u;
+        atomicAdd(&base[(quad ? 0 : xcd_of_tile(t, T)) * 64 + k], 1u);
     }
     __syncthreads();
     if (tid < FRG_NUM_XCD) {
@@ -232,10 +258,10 @@ bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uin
     }
     __syncthreads();
     for (int t = tid; t < T; t += 1024) {
-        const int x = xcd_of_tile(t, T);
-        const uint32_t k = 63u - min(63u, tile_work[t] >> 5);
+        const int x = quad ? 0 : xcd_of_tile(t, T);
+        const uint32_t wk = tile_work[t], k = wk ? 62u - min(62u, wk >> 5) : 63u;
         const uint32_t pos = base[x * 64 + k] + atomicAdd(&cur[x * 64 + k], 1u);
-        order[pos * FRG_NUM_XCD + x] = (uint32_t)t;
+        order[quad ? pos : pos * FRG_NUM_XCD + x] = (uint32_t)t;
     }
 }
 
@@ -283,9 +309,11 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order)
+                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order,
+                 const uint32_t* __restrict__ bwd_mode)
 {
     using M = BlendMath<EXACT>;
+    if (*bwd_mode != 0u) return;     // few active tiles: blend_bwd_quad_kernel has this frame (wave-uniform scalar load)
     const int tile = order ? (int)order[blockIdx.x] : xcd_tile_of_block(blockIdx.x, T);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
@@ -503,6 +531,193 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             sum = dpp_step<0xB1, 0xf>(sum);                      // quad_perm [1,0,3,2]: the row's other half
             if (writer) *dst = sum;
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// The backward blend with FOUR waves per tile (one per 8x8 quadrant, one pixel per lane), for frames with few active
+// tiles (bwd_order_kernel decides).  Same mathematics, same slots: each wave reduces the nine partial sums of its
+// quadrant's pixels exactly as the tile-per-wave form reduces a tile's (through its own LDS matrix), leaves them in a
+// [entry][quadrant][9] table, and after a workgroup barrier per round of 64 list entries the table is summed over the
+// quadrants in a fixed order ((q0 + q1) + q2) + q3 and stored: deterministic, no atomics, one store per slot value.
+// The per-wave critical path -- what bounds such a frame -- is a quarter of the tile-per-wave form's.
+template <bool EXACT, int BWD_BATCH>
+__global__ void __launch_bounds__(BLEND_THREADS)
+blend_bwd_quad_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
+                      const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
+                      const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
+                      const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
+                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                      const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff,
+                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ bwd_mode)
+{
+    using M = BlendMath<EXACT>;
+    if (*bwd_mode == 0u) return;
+    const int tile = (int)order[blockIdx.x];
+    if (tile < 0) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const uint2 rg = ranges[tile];
+
+    __shared__ float4 s_a_all[4][64];      // x, y, entry of the round (0 = deepest), 0-based list position
+    __shared__ float4 s_co_all[4][64];
+    __shared__ float4 s_rgb_all[4][64];
+    __shared__ __attribute__((aligned(16))) float s_red_all[4][BWD_BATCH * FRG_SLOT_FLOATS * 64];
+    __shared__ float s_res[64][4][FRG_SLOT_FLOATS];   // per entry of the round and quadrant: the reduced partials
+    __shared__ uint32_t s_slot[64];
+    __shared__ uint32_t s_qmax[4];
+    float4* s_a = s_a_all[q];
+    float4* s_co = s_co_all[q];
+    float4* s_rgb = s_rgb_all[q];
+    float* s_red = s_red_all[q];
+
+    const int qx0 = tx * FRG_TILE + (q & 1) * 8, qy0 = ty * FRG_TILE + (q >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const float pu = (float)(px - tx * FRG_TILE) - 7.5f, pw = (float)(py - ty * FRG_TILE) - 7.5f;   // offset from the tile centre
+    const float puu = pu * pu, puw = pu * pw, pww = pw * pw;
+    const bool inside = px < W && py < H;
+    const size_t plane = (size_t)H * W, pid = (size_t)py * W + px;
+    float Tr = inside ? final_T[pid] : 0.0f;
+    const uint32_t lastcon = inside ? n_contrib[pid] : 0u;
+    float dLp[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) dLp[ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
+    float S = Tr * M::mad(bg[2], dLp[2], M::mad(bg[1], dLp[1], bg[0] * dLp[0]));
+    uint32_t qmax = lastcon;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, d, 64));
+    if (lane == 0) s_qmax[q] = qmax;
+    __syncthreads();
+    const uint32_t maxc = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
+    if (maxc == 0) {                       // workgroup-uniform
+        if (threadIdx.x == 0) cutoff[tile] = make_uint2(0u, 0u);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t id = point_list[rg.x + maxc - 1];
+        cutoff[tile] = make_uint2(__float_as_uint(xydr[FRG_REC * id].z), id);
+    }
+
+    uint32_t id_n = 0, off_n = 0;
+    float4 a_n, co_n, col_n;
+    auto fetch = [&](int hi) {
+        id_n = point_list[rg.x + max(hi - lane, 0)];
+        a_n = xydr[FRG_REC * id_n];
+        co_n = conic_opacity[FRG_REC * id_n];
+        col_n = rgb_clamped[FRG_REC * id_n];
+        off_n = point_offsets[max(id_n, 1u) - 1u];
+    };
+    fetch((int)maxc - 1);
+    for (int hi = (int)maxc - 1; hi >= 0; hi -= 64) {
+        const int cnt = min(64, hi + 1);
+        const uint32_t id = id_n;
+        const float4 a = a_n, co = co_n, col = col_n;
+        const uint32_t off = id == 0 ? 0u : off_n;
+        if (hi >= 64) fetch(hi - 64);             // workgroup-uniform
+        bool hit = false;
+        if (lane < cnt) {
+            const uint32_t mypos = (uint32_t)(hi - lane);
+            hit = mypos < qmax && quadrant_hit(a.x, a.y, co, qx0, qy0);
+            if (q == 0) {   // Gaussian-major slot of this (Gaussian, tile) instance (rasterizer_impl.cu:98-108 emission order)
+                int x0, y0, x1, y1;
+                tile_rect(a.x, a.y, (int)a.w, gx, gy, x0, y0, x1, y1);
+                s_slot[lane] = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            }
+        }
+        // this quadrant's column of the round's table starts at zero: entries it culls or never blends contribute nothing
+#pragma unroll
+        for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_res[lane][q][c] = 0.0f;
+        const uint64_t keep = wave_ballot(hit);
+        const int nkeep = __popcll(keep);
+        wave_lds_sync();                          // (the previous round's readers passed the workgroup barrier below)
+        if (hit) {
+            const int d = lanes_before(keep, lane);
+            s_a[d] = make_float4(a.x, a.y, __uint_as_float((uint32_t)lane), __uint_as_float((uint32_t)(hi - lane)));
+            s_co[d] = M::stage(co);
+            s_rgb[d] = col;
+        }
+        wave_lds_sync();
+        for (int k = 0; k < nkeep; k += BWD_BATCH) {
+            float acc[BWD_BATCH][FRG_SLOT_FLOATS];
+#pragma unroll
+            for (int h = 0; h < BWD_BATCH; h++)
+#pragma unroll
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) { acc[h][c] = 0.0f; asm volatile("" : "+v"(acc[h][c])); }
+            bool any = false;
+#pragma unroll
+            for (int h = 0; h < BWD_BATCH; h++) {
+                const int kk = k + h;
+                if (kk >= nkeep) break;
+                float* part = acc[h];
+                const float4 ca = s_a[kk], cco = s_co[kk];
+                const uint32_t pos = __float_as_uint(ca.w);
+                const float4 gc = s_rgb[kk];
+                float dx, dy;
+                const float power = M::power(ca.x, ca.y, cco, pxf, pyf, dx, dy);
+                const float G = M::expo(power);
+                const float alpha = fminf(0.99f, cco.w * G);
+                const bool ok = pos < lastcon && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (wave_ballot(ok) == 0ull) continue;       // wave-uniform
+                any = true;
+                const float a_eff = ok ? alpha : 0.0f, g_eff = ok ? G : 0.0f;
+                const float rinv = M::recip(1.f - a_eff);
+                Tr = Tr * rinv;
+                const float w = a_eff * Tr;
+                const float cdot = M::mad(gc.z, dLp[2], M::mad(gc.y, dLp[1], gc.x * dLp[0]));
+                part[0] = M::mad(w, dLp[0], part[0]);
+                part[1] = M::mad(w, dLp[1], part[1]);
+                part[2] = M::mad(w, dLp[2], part[2]);
+                const float dL_dalpha = M::mad(Tr, cdot, -(S * rinv));
+                S = M::mad(w, cdot, S);
+                const float v = g_eff * dL_dalpha;
+                if (EXACT) {
+                    const float vx = v * dx, vy = v * dy;
+                    part[3] += vx;
+                    part[4] += vy;
+                    part[5] = M::mad(vx, dx, part[5]);
+                    part[6] = M::mad(vx, dy, part[6]);
+                    part[7] = M::mad(vy, dy, part[7]);
+                } else {
+                    part[3] = __builtin_fmaf(v, pu, part[3]);
+                    part[4] = __builtin_fmaf(v, pw, part[4]);
+                    part[5] = __builtin_fmaf(v, puu, part[5]);
+                    part[6] = __builtin_fmaf(v, puw, part[6]);
+                    part[7] = __builtin_fmaf(v, pww, part[7]);
+                }
+                part[8] += v;
+            }
+            if (!any) continue;                   // nothing blended in this batch: the table keeps its zeros
+            const int row = lane >> 1, half = lane & 1;
+            const int inst = row / FRG_SLOT_FLOATS;
+            const int comp = row - inst * FRG_SLOT_FLOATS;
+            const bool writer = half == 0 && row < BWD_BATCH * FRG_SLOT_FLOATS && k + inst < nkeep;
+            wave_lds_sync();         // the previous batch's readers are done with s_red
+#pragma unroll
+            for (int h = 0; h < BWD_BATCH; h++)
+#pragma unroll
+                for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_red[(h * FRG_SLOT_FLOATS + c) * 64 + lane] = acc[h][c];
+            wave_lds_sync();
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (row < BWD_BATCH * FRG_SLOT_FLOATS) {
+                const float4* src = reinterpret_cast<const float4*>(s_red + row * 64 + half * 32);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float4 v = src[(j + comp) & 7];
+                    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+                }
+            }
+            float sum = (s0 + s1) + (s2 + s3);
+            sum = dpp_step<0xB1, 0xf>(sum);
+            if (writer) s_res[__float_as_uint(s_a[k + inst].z)][q][comp] = sum;
+        }
+        __syncthreads();             // the four quadrants' columns are complete
+        for (int t = threadIdx.x; t < cnt * FRG_SLOT_FLOATS; t += BLEND_THREADS) {
+            const int e = t / FRG_SLOT_FLOATS, c = t - e * FRG_SLOT_FLOATS;
+            slots[(size_t)s_slot[e] * FRG_SLOT_STRIDE + c] = ((s_res[e][0][c] + s_res[e][1][c]) + s_res[e][2][c]) + s_res[e][3][c];
+        }
+        __syncthreads();             // before the next round rewrites the table and the slot numbers
     }
 }
 

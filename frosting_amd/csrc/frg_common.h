@@ -124,6 +124,7 @@ struct ImageState {
     uint32_t* tile_fill;     // zeroed every forward; scatter cursor
     uint32_t* tile_work;     // zeroed every forward; list entries the forward blend walked (max over the tile's pixels)
     uint32_t* bwd_order;     // [xcd_grid_blocks(T)] workgroup -> tile map of the backward blend (longest tiles first)
+    uint32_t* bwd_mode;      // 1: few active tiles, the quadrant form of the backward blend has this frame (bwd_order_kernel)
     Counters* counters;      // zeroed every forward
     uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
     uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts (-> scatter bases when !row_order)
@@ -154,6 +155,7 @@ struct ImageState {
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
         s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
+        s.bwd_mode = (uint32_t*)(base + o); o = align_up(o + 4, 256);
         s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
         const size_t gy = (size_t)((H + FRG_TILE - 1) / FRG_TILE);
         s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;

@@ -43,9 +43,9 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
                                  const float* bg, float* out_color, hipStream_t s);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
+                                  const float* bg, const float* dL_dpix, float* slots, int batch, int quad_tiles, hipStream_t s);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, int batch, hipStream_t s);
+                                 const float* bg, const float* dL_dpix, float* slots, int batch, int quad_tiles, hipStream_t s);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;

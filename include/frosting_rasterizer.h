@@ -232,6 +232,10 @@ int frg_backward_ex(const frg_backward_args* args);
  * (forward.cu:236-255), about twice as many.  num_rendered, radii, the image and all gradients are
  * bit-identical either way; the tile lists become order-preserving sub-lists of the reference's.
  * Default 0: lists identical to the reference's, entry for entry.
+ * "bwd_quad_tiles": the backward blend runs four waves per tile (one per 8x8 quadrant) instead of one when at most
+ * this many tiles blended anything in the forward -- sparsely covered frames are bound by the longest tile's wave;
+ * -1 (default) = the built-in 2560, 0 = never.  The two forms add the same partial sums in different orders (both
+ * fixed): gradients agree to rounding, each is bit-reproducible.
  * Returns the previous value or FRG_EINVAL for an unknown name. */
 int frg_set_option(const char* name, int value);
 int frg_get_option(const char* name);

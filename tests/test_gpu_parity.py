@@ -43,6 +43,7 @@ GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dco
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
+    _lib.set_option("bwd_quad_tiles", -1)
     _lib.set_option("exact_blend", 0)
     _lib.set_option("profile", 0)
     _lib.set_option("tight_binning", 0)
@@ -554,6 +555,53 @@ def test_backward_follows_the_forwards_modes_not_the_process_options(gpu_device)
         _lib.set_option("global_bins", 0)
     for a, c in zip(want[0], want[1]):                       # and the two modes agree with each other
         assert torch.equal(a, c)
+
+
+@pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("exact", [1, 0])
+def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
+    """Few active tiles -> four waves per tile (blend_bwd_quad_kernel), many -> one (blend_bwd_kernel): the same
+    partial sums in two fixed orders.  Both forms forced on the same forward (option bwd_quad_tiles): each is
+    bit-reproducible and within the usual bars of the reference's own backward; the automatic choice picks the tile form
+    for a fully covered frame and the quadrant form for a sparsely covered one."""
+    scene, cam, bg = scenes.config_scene("c2", 3, P=60_000)
+    _lib.set_option("exact_blend", exact)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 29)
+    gpix = gpix.to(gpu_device)
+    b = _bwd_args(args, out, gpix)
+    got = {}
+    for name, tiles in (("tile", 0), ("quad", 1 << 30)):
+        _lib.set_option("bwd_quad_tiles", tiles)
+        got[name] = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
+        again = _C.rasterize_gaussians_backward(*b)
+        assert all(torch.equal(x, y) for x, y in zip(got[name], again)), name
+    _lib.set_option("bwd_quad_tiles", -1)
+    auto = _C.rasterize_gaussians_backward(*b)       # 2500 tiles, all active: the tile-per-wave form
+    assert all(torch.equal(x, y) for x, y in zip(got["tile"], auto))
+    _, _, _, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
+    runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
+    for name, gt, gq in zip(GRAD_NAMES, got["tile"], got["quad"]):
+        noise = Hh.reference_noise(runs, name)
+        dt, dq = Hh.distance_to_reference(gt, runs, name), Hh.distance_to_reference(gq, runs, name)
+        print(f"{name}: tile form vs reference {dt:.1e}, quadrant form vs reference {dq:.1e} (reference vs itself {noise:.1e}), "
+              f"quadrant vs tile form {Hh.rel_l2(gq, gt):.1e}")
+        assert dt < Hh.grad_bar(name, noise, fast=not exact), (name, "tile", dt, noise)
+        assert dq < Hh.grad_bar(name, noise, fast=not exact), (name, "quad", dq, noise)
+    # a frame that covers a corner of the image only: few active tiles -> the automatic choice is the quadrant form
+    small = scenes.Scene(scene.means3D * 0.12 + torch.tensor([0.9, 0.6, 0.0]), scene.scales, scene.rotations, scene.opacities,
+                         scene.shs, scene.sh_degree)
+    out2, args2 = Hh.run_ours_native(small, cam, bg, gpu_device)
+    st = State(small.P, cam.image_width, cam.image_height, out2[0], out2[3], out2[4], out2[5])
+    assert 0 < int((st.tile_count > 0).sum()) < 1000
+    g2, _ = scenes.l1_target_grad(out2[1].cpu(), 31)
+    b2 = _bwd_args(args2, out2, g2.to(gpu_device))
+    auto2 = [g.clone() for g in _C.rasterize_gaussians_backward(*b2)]
+    _lib.set_option("bwd_quad_tiles", 1 << 30)
+    assert all(torch.equal(x, y) for x, y in zip(auto2, _C.rasterize_gaussians_backward(*b2)))
+    _lib.set_option("bwd_quad_tiles", 0)
+    tile2 = _C.rasterize_gaussians_backward(*b2)
+    assert not all(torch.equal(x, y) for x, y in zip(auto2, tile2))     # (the forms differ in the last bits)
 
 
 def test_per_call_modes_of_two_rasterizers_on_two_threads(gpu_device):

@@ -17,6 +17,7 @@ ap.add_argument("--view", type=int, default=0)
 ap.add_argument("--order", default="input", choices=["input", "yrow", "morton"],
                 help="memory order of the Gaussians: as generated | by the 16-pixel screen row of the projected centre | Morton order of the pixel")
 ap.add_argument("--scene", default="config", choices=["config", "skew"], help="skew: scenes.make_skew_scene (bench.py's skew_scene)")
+ap.add_argument("--shrink", type=float, default=1.0, help="scale the scene about the origin (positions and sizes): < 1 covers fewer tiles")
 ap.add_argument("--deferred", action="store_true", help="frg_forward_deferred (no host synchronisation inside the step)")
 ap.add_argument("settings", nargs="*", default=[""])
 a = ap.parse_args()
@@ -25,6 +26,8 @@ cfg = scenes.CONFIGS[a.config]
 scene, cam, bg = scenes.config_scene(a.config, a.view, P=a.points or cfg["P"])
 if a.scene == "skew":
     scene = scenes.make_skew_scene(a.points or cfg["P"], cfg["seed"] + 77)
+if a.shrink != 1.0:
+    scene = scenes.Scene((scene.means3D * a.shrink).contiguous(), (scene.scales * a.shrink).contiguous(), scene.rotations, scene.opacities, scene.shs, scene.sh_degree)
 if a.order != "input":
     # what spatial coherence of the caller's array would be worth to the binning stages (timing experiment)
     ph = torch.cat([scene.means3D.double(), torch.ones(scene.P, 1, dtype=torch.float64)], 1) @ cam.projmatrix.double()
@@ -69,6 +72,10 @@ for setting in a.settings:
     torch.cuda.synchronize()
     st = _lib.stage_times(); _lib.set_option("profile", 0)
     flat = vpr.exchange.flat.clone()
+    if setting == a.settings[0]:
+        from frosting_amd.introspect import State
+        st_ = State(scene.P, cam.image_width, cam.image_height, vpr.true_num_rendered, vpr.geom.buf, vpr.binning.buf, vpr.img.buf)
+        print(f"R {vpr.true_num_rendered}, tiles with a list {int((st_.tile_count > 0).sum())}, pixels with a contributor: tiles {int((st_.n_contrib.view(-1) > 0).sum())} px", flush=True)
     if base is None: base = flat
     d = float((flat.double() - base.double()).norm() / base.double().norm())
     print(f"[{setting or 'default':32s}] {ms:.4f} ms/step | " + " ".join(f"{k} {v:.3f}" for k, v in st.items() if v > 0) + f" | sum {sum(v for v in st.values() if v > 0):.3f} | grad diff vs first {d:.2e}", flush=True)
