@@ -51,6 +51,8 @@ def parse_args():
                     help="skip the informative passes after the timed region (tight binning, API path, reference on this GPU, "
                          "skewed scene); used under rocprofv3 so that per-kernel averages are those of the headline mode only")
     ap.add_argument("--exact", action="store_true", help="use the EXACT blend arithmetic")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="frg_set_option(NAME, VALUE) before anything runs (tuning experiments; repeatable)")
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
     ap.add_argument("--tight-binning", action="store_true",
                     help="time the whole run with frg_set_option('tight_binning', 1): instances that cannot reach alpha >= "
@@ -291,6 +293,10 @@ def main():
     else:
         scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
     do_backward = args.config != "c2"
+    for kv in args.option:
+        k, v = kv.split("=")
+        if _lib.set_option(k, int(v)) < 0 and "unknown option" in _lib.last_error():
+            raise SystemExit(f"--option {kv}: {_lib.last_error()}")
     _lib.set_option("exact_blend", 1 if args.exact else 0)
     _lib.set_option("profile", 0 if args.no_stage_timers else 1)
     _lib.set_option("tight_binning", 1 if args.tight_binning else 0)

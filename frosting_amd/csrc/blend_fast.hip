@@ -30,10 +30,12 @@ hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const
 #undef FRG_BWD
     // the quadrant form for frames with few active tiles: one of the two launches finds the mode word against it and leaves
     const int nquad = (uint32_t)T < qt ? T : (int)qt;   // (inactive tiles sort behind the active ones)
-    if (nquad > 0)
-    hipLaunchKernelGGL((blend_bwd_quad_kernel<FRG_EXACT, 3>), dim3(nquad), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.gy, vp.W, vp.H,
-                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,
-                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_mode);
+#define FRG_BWDQ(B)                                                                                                        \
+    hipLaunchKernelGGL((blend_bwd_quad_kernel<FRG_EXACT, B>), dim3(nquad), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
+                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
+                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_mode)
+    if (nquad > 0) { if (batch == 2) FRG_BWDQ(2); else FRG_BWDQ(3); }
+#undef FRG_BWDQ
     return hipGetLastError();
 }
 }  // namespace frg

@@ -18,15 +18,25 @@ namespace frg {
 // sign-extended to a mask sb (v_bfe_i32), one ballot, and peers &= ~(ballot ^ sb) per 32-bit half (v_xnor + v_and):
 // six vector instructions.  (`peers &= bit ? m : ~m` on 64-bit values compiled to nine: the ranking is the sort's
 // instruction-bound inner loop.)
+// `width` bits per digit (wave-uniform): the digits of a pass only have as many bits as the key range needs -- the ranking
+// costs four to six vector instructions per BIT.  Rolled, two bits per trip: their compare -> ballot -> mask chains are
+// independent, so the second hides the first's latency; one unrolled copy per digit width cost 20-40 registers.
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int width = 8)
 {
     const uint64_t v = __builtin_amdgcn_ballot_w64(valid);
     uint32_t plo = (uint32_t)v, phi = (uint32_t)(v >> 32);
-    // (width is wave-uniform: the digits of a pass only have as many bits as the key range needs -- the ranking costs
-    // six vector instructions per BIT)
+    int b = 0;
 #pragma unroll 1
-    for (int b = 0; b < width; b++) {
-        const uint32_t sb = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);   // 0 or 0xFFFFFFFF
+    for (; b + 1 < width; b += 2) {
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);       // 0 or 0xFFFFFFFF
+        const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)(b + 1), 1u);
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(s0 != 0u);
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(s1 != 0u);
+        plo &= ~((uint32_t)m0 ^ s0) & ~((uint32_t)m1 ^ s1);
+        phi &= ~((uint32_t)(m0 >> 32) ^ s0) & ~((uint32_t)(m1 >> 32) ^ s1);
+    }
+    if (b < width) {
+        const uint32_t sb = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
         const uint64_t m = __builtin_amdgcn_ballot_w64(sb != 0u);
         plo &= ~((uint32_t)m ^ sb);
         phi &= ~((uint32_t)(m >> 32) ^ sb);

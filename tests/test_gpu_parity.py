@@ -562,8 +562,8 @@ def test_backward_follows_the_forwards_modes_not_the_process_options(gpu_device)
 def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
     """Few active tiles -> four waves per tile (blend_bwd_quad_kernel), many -> one (blend_bwd_kernel): the same
     partial sums in two fixed orders.  Both forms forced on the same forward (option bwd_quad_tiles): each is
-    bit-reproducible and within the usual bars of the reference's own backward; the automatic choice picks the tile form
-    for a fully covered frame and the quadrant form for a sparsely covered one."""
+    bit-reproducible and within the usual bars of the reference's own backward; the choice follows the number of active
+    tiles (the full-size tests run the tile form: 6600 active tiles)."""
     scene, cam, bg = scenes.config_scene("c2", 3, P=60_000)
     _lib.set_option("exact_blend", exact)
     out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
@@ -577,8 +577,11 @@ def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
         again = _C.rasterize_gaussians_backward(*b)
         assert all(torch.equal(x, y) for x, y in zip(got[name], again)), name
     _lib.set_option("bwd_quad_tiles", -1)
-    auto = _C.rasterize_gaussians_backward(*b)       # 2500 tiles, all active: the tile-per-wave form
-    assert all(torch.equal(x, y) for x, y in zip(got["tile"], auto))
+    auto = _C.rasterize_gaussians_backward(*b)       # 2500 tiles: below the 2560 of the automatic choice -> the quadrant form
+    assert all(torch.equal(x, y) for x, y in zip(got["quad"], auto))
+    _lib.set_option("bwd_quad_tiles", 1000)          # a lower bar: all 2500 tiles are active -> the tile-per-wave form
+    assert all(torch.equal(x, y) for x, y in zip(got["tile"], _C.rasterize_gaussians_backward(*b)))
+    _lib.set_option("bwd_quad_tiles", -1)
     _, _, _, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
     runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
     for name, gt, gq in zip(GRAD_NAMES, got["tile"], got["quad"]):
