@@ -221,7 +221,12 @@ struct BwdSide {
         if (fork) (void)hipEventDestroy(fork);
         if (join) (void)hipEventDestroy(join);
         stream = nullptr; fork = nullptr; join = nullptr; device = -1;
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        // HIGHEST priority: the 16-wave workgroups need a whole CU's LDS each; both launches become ready when the blend
+        // backward ends, and unless the dispatcher places these first they wait until the plain kernel has drained
+        // (rocprofv3, round 3: 274 us "duration" for a launch whose workgroups found an empty list)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
         device = dev;

@@ -561,7 +561,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
                        in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, g.heavy_waves)
     // the listed waves (usually none: the workgroups read the count and leave)
-    const dim3 hgrid(64), hblock(BWD_HEAVY_WAVES * 64);
+    const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }
     else { if (sh16) FRG_PBW(true, false, grid, block); else FRG_PBW(false, false, grid, block); }
 #undef FRG_PBW
