@@ -166,6 +166,40 @@ struct PendingRing {
 };
 thread_local PendingRing g_pending;
 
+// The host thread's mailbox (frg::Mailbox, frg_common.h): pinned, mapped, written by the scan workgroups.
+struct HostMail {
+    frg::Mailbox* host = nullptr;
+    uint32_t seq = 0;
+    bool long_lists = false;     // the previous forward of this thread had tile lists beyond the LDS sort
+    bool failed = false;         // a post never arrived although the stream had drained: stay with the copy + synchronise
+    frg::Mailbox* get()
+    {
+        if (!host && !failed) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&host), sizeof(frg::Mailbox), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                host = nullptr; failed = true;
+                (void)hipGetLastError();
+            } else memset(host, 0, sizeof(frg::Mailbox));
+        }
+        return host;
+    }
+};
+thread_local HostMail g_mail;
+std::atomic<int> g_use_mailbox{1};
+
+// Spin until the kernel's post arrives.  false: the stream failed, or it drained without the post becoming visible.
+bool mailbox_wait(const uint32_t* flag, uint32_t seq, hipStream_t stream)
+{
+    for (unsigned spin = 1;; spin++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+        if ((spin & 0x7ffu) == 0) {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+            if (q != hipErrorNotReady) return false;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 // Side stream of the deferred SH colour kernel (one per host thread and device, like the sort's).
 struct ShSide {
     hipStream_t stream = nullptr;
@@ -295,6 +329,8 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
+    if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
     // stray call must not be able to switch them on -- they exist only in processes started with FROSTING_EXPERIMENTS=1
     if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0)) {
@@ -343,6 +379,8 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.load();
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
+    if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
+    if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -482,7 +520,12 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     };
     { StageScope sc_(ST_PREPROCESS, stream); FRG_STAGE(frg::launch_preprocess_fwd(P, vp, in, radii, g, img, prefiltered, defer_sh, stream), "preprocess"); }
     { const int rc_ = fork_sh(1); if (rc_ < 0) return rc_; }
-    { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, (uint32_t)capacity, stream), "scan"); }
+    // blocking form: the scan workgroups post the counters into this thread's pinned mailbox (frg_common.h) and the
+    // host polls it, instead of a copy kernel + stream synchronisation behind the scan
+    frg::Mailbox* mail = (capacity == 0 && !debug && g_use_mailbox.load(std::memory_order_relaxed)) ? g_mail.get() : nullptr;
+    uint32_t mail_seq = 0;
+    if (mail) { if (++g_mail.seq == 0) g_mail.seq = 1; mail_seq = g_mail.seq; }
+    { StageScope sc_(ST_SCAN, stream); FRG_STAGE(frg::launch_scan(P, vp, g, img, (uint32_t)capacity, stream, mail, mail_seq), "scan"); }
     { const int rc_ = fork_sh(2); if (rc_ < 0) return rc_; }
 
     int index_bits = 1;
@@ -512,26 +555,59 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     }
 
     // the single host synchronisation of the op (rasterizer_impl.cu:280-281)
-    frg::Counters* host = pinned_counters();
-    if (!host) return fail(FRG_EHIP, "hipHostMalloc failed");
-    FRG_HIP(hipMemcpyAsync(host, img.counters, sizeof(frg::Counters), hipMemcpyDeviceToHost, stream));
-    FRG_HIP(hipStreamSynchronize(stream));
-    const frg::Counters c = *host;
+    frg::Counters c;
+    frg::BinningState b;
+    bool have_counters = false, early = false;
+    if (mail) {
+        // Stage 1: the instance count (posted by the chunk scan, ~40 us before the scan stage ends at C3).  The binning
+        // buffer is sized for every sort path -- the longest tile list is not known yet -- and the scatter is enqueued
+        // while the reorder still runs.  Stage 2: the tile scan's counters (the sort's grids).
+        if (mailbox_wait(&mail->seq_r, mail_seq, stream)) {
+            const uint32_t r = mail->num_rendered;
+            if (r > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
+            if (r > 0) {
+                R = (int)r;
+                char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, FRG_SORT_LDS_CAP + 1));
+                if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
+                b = frg::BinningState::carve(bin_chunk, R, FRG_SORT_LDS_CAP + 1);
+                if (g_mail.long_lists)
+                    FRG_STAGE(frg::launch_sort_plan(T, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream, 1), "sort plan");
+                { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
+                { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
+                early = true;
+            }
+            if (mailbox_wait(&mail->seq_c, mail_seq, stream)) { c = mail->c; have_counters = true; }
+        }
+        if (!have_counters) g_mail.failed = true, g_mail.host = nullptr;    // (the pinned block is left to the process)
+    }
+    if (!have_counters) {
+        frg::Counters* host = pinned_counters();
+        if (!host) return fail(FRG_EHIP, "hipHostMalloc failed");
+        FRG_HIP(hipMemcpyAsync(host, img.counters, sizeof(frg::Counters), hipMemcpyDeviceToHost, stream));
+        FRG_HIP(hipStreamSynchronize(stream));
+        c = *host;
+    }
     if (prefiltered && c.filtered)
         return fail(FRG_EFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (c.num_rendered > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
     R = (int)c.num_rendered;
     const int max_tile = (int)c.max_tile_count;
 
-    char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, max_tile));
-    if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
-    const frg::BinningState b = frg::BinningState::carve(bin_chunk, R, max_tile);
+    if (!early) {
+        char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, max_tile));
+        if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
+        b = frg::BinningState::carve(bin_chunk, R, max_tile);
+    }
+    const bool forked_plan = early && g_mail.long_lists;
+    if (mail) g_mail.long_lists = c.class_count[4] > 0;
 
     const bool probe_fwd = (g_probe.load() & 1) && R > 0 && !exact && g_probe_side.ensure();
     if (R > 0) {
-        FRG_STAGE(frg::launch_sort_plan(T, c.class_count, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream), "sort plan");
-        { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
-        { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
+        FRG_STAGE(frg::launch_sort_plan(T, c.class_count, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream, forked_plan ? 2 : 0), "sort plan");
+        if (!early) {
+            { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
+            { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
+        }
         if (probe_fwd) {
             FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
             FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));

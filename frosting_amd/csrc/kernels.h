@@ -17,7 +17,9 @@ struct FwdInputs {
 hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& in, int* radii, const GeomState& g,
                                  const ImageState& img, int prefiltered, bool defer_sh, hipStream_t s);
 hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g, hipStream_t s);
-hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s);
+// mail (optional, pinned host memory): where the scan workgroups post the counters for the polling host thread
+hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s,
+                       Mailbox* mail = nullptr, uint32_t seq = 0);
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
                           const BinningState& b, hipStream_t s, int ablate = 0);
 extern int g_rows_grid;   // workgroups of the row-ordered scatter (tuning)
@@ -30,8 +32,9 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // count the binning chunk was carved with); max_tile_count: longest list (0: unknown, kernels stride); index_bits:
 // bits needed for a Gaussian index (tie order = ascending index)
 // to be called before launch_scatter (same arguments as launch_tile_sort's): plans the sort of the long lists
+extern int g_sort_heavy_on_caller;
 hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
-                            const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream);
+                            const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream, int fork_mode = 0);
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
                             const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
                             uint32_t* big_hist, uint32_t* big_plan, uint32_t R, int max_tile_count, int index_bits,

@@ -497,7 +497,7 @@ struct ScanShared {
 
 template <int NT>
 __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_t* __restrict__ block_sums,
-                                            Counters* __restrict__ counters, uint32_t capacity)
+                                            Counters* __restrict__ counters, uint32_t capacity, Mailbox* mail, uint32_t seq)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { sh.carry = 0; sh.ovf = 0; }
@@ -530,6 +530,7 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
         // more instances than the caller's binning buffer holds (deferred-counters forward):
         // every tile list is left empty, the frame renders as background and is redone
         if (capacity && sh.carry > capacity) { sh.ovf = 1; counters->overflow = 1; }
+        if (mail) { mail->num_rendered = sh.carry; mailbox_post(&mail->seq_r, seq); }
     }
     __syncthreads();
 }
@@ -542,7 +543,8 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
 template <int NT, int USE_SEGS>
 __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool ovf, int T, int gx, uint32_t* __restrict__ tile_count,
                                            uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
-                                           uint32_t* __restrict__ class_tiles, Counters* __restrict__ counters, uint32_t tight)
+                                           uint32_t* __restrict__ class_tiles, Counters* __restrict__ counters, uint32_t tight,
+                                           Mailbox* mail, uint32_t seq)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { sh.carry = 0; sh.maxc = 0; }
@@ -644,18 +646,32 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
     }
     if (tid == 0) { counters->max_tile_count = sh.maxc; counters->tight_binning = tight; }
     if (tid < FRG_SORT_CLASSES) counters->class_count[tid] = sh.cls[tid];
+    if (mail && tid == 0) {
+        // (num_rendered, filtered, overflow: written by earlier kernels or by this workgroup before a barrier)
+        Counters c;
+        c.num_rendered = __hip_atomic_load(&counters->num_rendered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.filtered = __hip_atomic_load(&counters->filtered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.overflow = __hip_atomic_load(&counters->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.max_tile_count = sh.maxc;
+        c.tight_binning = tight;
+        c.num_visible = 0;
+        c.pad2[0] = 0;
+        for (int k = 0; k < FRG_SORT_CLASSES; k++) c.class_count[k] = sh.cls[k];
+        mail->c = c;
+        mailbox_post(&mail->seq_c, seq);
+    }
 }
 
 __global__ void __launch_bounds__(1024)
 scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __restrict__ tile_count,
             uint32_t* __restrict__ seg_sums, int use_segs, uint2* __restrict__ ranges, uint32_t* __restrict__ class_tiles,
-            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight, int lds_tot)
+            Counters* __restrict__ counters, uint32_t capacity, uint32_t tight, int lds_tot, Mailbox* mail, uint32_t seq)
 {
     __shared__ ScanShared sh;
     extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (lds_tot)
-    scan_chunks<1024>(sh, nchunks, block_sums, counters, capacity);
-    if (use_segs) scan_tiles<1024, 1>(sh, scan_tot, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight);
-    else scan_tiles<1024, 0>(sh, lds_tot ? scan_tot : tile_count, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight);
+    scan_chunks<1024>(sh, nchunks, block_sums, counters, capacity, mail, seq);
+    if (use_segs) scan_tiles<1024, 1>(sh, scan_tot, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight, mail, seq);
+    else scan_tiles<1024, 0>(sh, lds_tot ? scan_tot : tile_count, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight, mail, seq);
 }
 
 // Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
@@ -669,12 +685,13 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
 __global__ void __launch_bounds__(256)
 colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums,
               uint32_t* __restrict__ row_matrix, uint32_t* __restrict__ row_total, int gy,
-              int nchunks, uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, uint32_t capacity)
+              int nchunks, uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, uint32_t capacity,
+              Mailbox* mail, uint32_t seq)
 {
     if (blockIdx.y == FRG_BIN_SEGS + 1) {
         if (blockIdx.x != 0) return;
         __shared__ ScanShared sh;
-        scan_chunks<256>(sh, nchunks, block_sums, counters, capacity);
+        scan_chunks<256>(sh, nchunks, block_sums, counters, capacity, mail, seq);
         return;
     }
     if (blockIdx.y == FRG_BIN_SEGS) {
@@ -814,7 +831,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
                const uint32_t* __restrict__ row_matrix, const uint32_t* __restrict__ row_total, uint4* __restrict__ row_records,
                Counters* __restrict__ counters,
                int T, int gx, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
-               uint32_t* __restrict__ class_tiles, uint32_t tight, uint32_t* __restrict__ heavy_waves)
+               uint32_t* __restrict__ class_tiles, uint32_t tight, uint32_t* __restrict__ heavy_waves, Mailbox* mail, uint32_t seq)
 {
     const int my_block = (int)blockIdx.x;     // this workgroup's row of the count matrices
     if (my_block == nblocks) {
@@ -823,7 +840,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
         // front of it.  Nothing in the reorder depends on it.
         __shared__ ScanShared sh;
         extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (dynamic LDS of this launch)
-        scan_tiles<FRG_BIN_THREADS, 2>(sh, scan_tot, counters->overflow != 0, T, gx, tile_count, seg_sums, ranges, class_tiles, counters, tight);
+        scan_tiles<FRG_BIN_THREADS, 2>(sh, scan_tot, counters->overflow != 0, T, gx, tile_count, seg_sums, ranges, class_tiles, counters, tight, mail, seq);
         return;
     }
     __shared__ uint32_t cursor[FRG_MAX_TILE_ROWS];
@@ -1030,7 +1047,8 @@ hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, con
     return hipGetLastError();
 }
 
-hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s)
+hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s,
+                       Mailbox* mail, uint32_t seq)
 {
     const int T = vp.gx * vp.gy;
     const int nchunks = (P + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS;
@@ -1039,12 +1057,12 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     if (img.lds_bins)
         hipLaunchKernelGGL(colsum_kernel, dim3(std::max((T + 255) / 256, cells ? (img.ncells + 3) / 4 : 0), FRG_BIN_SEGS + (cells ? 2 : 0)),
                            dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums, img.row_matrix, img.row_start, img.ncells,
-                           nchunks, g.block_sums, img.counters, capacity);
+                           nchunks, g.block_sums, img.counters, capacity, mail, seq);
     if (cells) {
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,
                            g.depth_rect, g.tiles_touched, g.block_sums, g.point_offsets, img.row_matrix, img.row_start, g.row_records,
-                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g.heavy_waves);
+                           img.counters, T, vp.gx, img.tile_count, img.seg_sums, img.ranges, img.class_tiles, (uint32_t)vp.tight, g.heavy_waves, mail, seq);
         return hipGetLastError();
     }
     // the tile totals sit in LDS (T words) when they fit
@@ -1054,7 +1072,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), lds_tot ? (size_t)T * 4 : 0, s, nchunks, g.block_sums, T, img.tile_count, img.seg_sums,
-                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity, (uint32_t)vp.tight, lds_tot ? 1 : 0);
+                       img.lds_bins ? 1 : 0, img.ranges, img.class_tiles, img.counters, capacity, (uint32_t)vp.tight, lds_tot ? 1 : 0, mail, seq);
     // per-workgroup scatter bases of the scatter in the caller's order
     if (img.lds_bins)
         hipLaunchKernelGGL(colbase_kernel, dim3((T + 255) / 256, FRG_BIN_SEGS), dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums);

@@ -655,7 +655,8 @@ static hipError_t launch_lds_class(int count, const uint32_t* tile_list, const u
 // early exits was dominated by dispatching ~6000 no-op 1024-thread workgroups.
 struct SortStreams {
     hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}, plan_fork = nullptr;
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}, plan_fork = nullptr, plan_done = nullptr;
+    bool plan_on_side = false;   // the last big_plan_kernel went to side[1] (plan_done says when it is through)
     int device = -1;
     bool ensure()
     {
@@ -670,7 +671,8 @@ struct SortStreams {
         }
         if (fork) (void)hipEventDestroy(fork);
         if (plan_fork) (void)hipEventDestroy(plan_fork);
-        fork = nullptr; plan_fork = nullptr;
+        if (plan_done) (void)hipEventDestroy(plan_done);
+        fork = nullptr; plan_fork = nullptr; plan_done = nullptr;
         device = -1;
         for (int i = 0; i < 2; i++) {
             if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return false;
@@ -678,6 +680,7 @@ struct SortStreams {
         }
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&plan_fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&plan_done, hipEventDisableTiming) != hipSuccess) return false;
         device = dev;
         return true;
     }
@@ -700,22 +703,28 @@ static hipError_t allow_sort_lds(K kernel, size_t lds)
 }
 
 static thread_local SortStreams g_sort_streams;
+int g_sort_heavy_on_caller = 1;   // frg_set_option("sort_heavy_on_caller")
 
 // The long lists' plan only needs the scan's outputs (ranges, the class lists): launched on the sort's second side
 // stream BEFORE the scatter is enqueued, its single workgroup's latency chain hides under the scatter.
+// fork_mode: 0 fork here and launch | 1 fork only (the caller does not know yet whether there are long lists: it enqueues
+// the scatter next and comes back with mode 2) | 2 launch behind the fork of an earlier mode-1 call.
 hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
-                            const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream)
+                            const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream, int fork_mode)
 {
     if (!big_plan || T <= 0 || (class_count && class_count[4] == 0)) return hipSuccess;
     SortStreams& ss = g_sort_streams;
     hipStream_t s2 = stream;
     hipError_t e;
     if (ss.ensure()) {
-        if ((e = hipEventRecord(ss.plan_fork, stream)) != hipSuccess) return e;
+        if (fork_mode != 2 && (e = hipEventRecord(ss.plan_fork, stream)) != hipSuccess) return e;
+        if (fork_mode == 1) return hipSuccess;
         if ((e = hipStreamWaitEvent(ss.side[1], ss.plan_fork, 0)) != hipSuccess) return e;
         s2 = ss.side[1];
-    }
+    } else if (fork_mode == 1) return hipSuccess;
     hipLaunchKernelGGL(big_plan_kernel, dim3(1), dim3(1024), 0, s2, class_tiles + (size_t)4 * T, class_count_dev + 4, ranges, big_plan, R);
+    ss.plan_on_side = s2 != stream;
+    if (ss.plan_on_side && (e = hipEventRecord(ss.plan_done, s2)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
@@ -740,18 +749,46 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
     SortStreams& ss = g_sort_streams;
     const bool big = (c2 + c3 + c4) > 0;
     const bool forked = big && ss.ensure();
-    hipStream_t s1 = stream, s2 = stream;
     hipError_t e;
-    // the (4096, 8192] class shares the second side stream with the long lists -- unless those are known to exist:
-    // their chain of four kernels then has that stream to itself and the class queues behind the (2048, 4096] one
-    const bool c3_on_s1 = class_count && c4 > 0;
-    const bool use_s1 = c2 > 0 || (c3 > 0 && c3_on_s1), use_s2 = c4 > 0 || (c3 > 0 && !c3_on_s1);
+    // Four groups of work -- the long lists' chain of kernels, the (4096, 8192] class, the (2048, 4096] class, the two
+    // small classes -- on three lanes: the caller's stream and two side streams.  A kernel on a side stream starts
+    // 15-30 us after the fork event (cross-queue signalling) and the caller's stream resumes ~10 us after the last join.
+    // Default: small classes on the caller's stream, (2048, 4096] on the first side stream, (4096, 8192] and the chain
+    // on the second.  When long lists are KNOWN to exist their chain of four kernels runs longest by far: it then goes
+    // on the caller's stream -- it starts right behind the scatter and the blend right behind it, the joins long
+    // satisfied -- and the other groups are spread over the side streams by their work (clustered scene: sort stage
+    // 0.478 -> 0.470 ms, step -0.02 ms).  Without long lists the same rule was measured SLOWER (C3: sort 0.204 ->
+    // 0.209 ms, in-process A/B): the small classes then start late on a side stream instead of at once.
+    hipStream_t lane[3] = {stream, stream, stream};
+    int on[4] = {2, 2, 1, 0};                    // lane of: chain, (4096,8192], (2048,4096], small classes
+    if (forked) { lane[1] = ss.side[0]; lane[2] = ss.side[1]; }
+    if (forked && class_count && c4 > 0 && g_sort_heavy_on_caller) {
+        const double w[4] = {c4 ? 1e30 : 0.0, c3 * 8192.0, c2 * 4096.0, c1 * 2048.0 + c0 * 512.0};
+        int order[4] = {0, 1, 2, 3};
+        for (int i = 1; i < 4; i++)
+            for (int j = i; j > 0 && w[order[j]] > w[order[j - 1]]; j--) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+        double load[3] = {0.0, 0.0, 0.0};
+        for (int i = 0; i < 4; i++) {
+            const int g = order[i];
+            int l = 0;
+            if (i > 0) { l = 1; if (load[2] < load[1]) l = 2; if (load[0] < load[l]) l = 0; }
+            on[g] = l;
+            load[l] += w[g];
+        }
+    }
+    const bool has[4] = {c4 > 0, c3 > 0, c2 > 0, c1 + c0 > 0};
+    bool use_lane[3] = {false, false, false};
+    for (int g = 0; g < 4; g++) if (has[g]) use_lane[on[g]] = true;
+    const bool use_s1 = forked && use_lane[1], use_s2 = forked && use_lane[2];
     if (forked) {
         if ((e = hipEventRecord(ss.fork, stream)) != hipSuccess) return e;
-        s1 = ss.side[0]; s2 = ss.side[1];
-        if (use_s1 && (e = hipStreamWaitEvent(s1, ss.fork, 0)) != hipSuccess) return e;
-        if (use_s2 && (e = hipStreamWaitEvent(s2, ss.fork, 0)) != hipSuccess) return e;
+        if (use_s1 && (e = hipStreamWaitEvent(lane[1], ss.fork, 0)) != hipSuccess) return e;
+        if (use_s2 && (e = hipStreamWaitEvent(lane[2], ss.fork, 0)) != hipSuccess) return e;
     }
+    const hipStream_t s4 = lane[on[0]], s3 = lane[on[1]], s2c = lane[on[2]], s10 = lane[on[3]];
+    // the chain follows its plan (launch_sort_plan: on the second side stream, forked before the scatter)
+    if (c4 && ss.plan_on_side && s4 != ss.side[1] && (e = hipStreamWaitEvent(s4, ss.plan_done, 0)) != hipSuccess) return e;
+    const hipStream_t s2 = s4;     // (name used by the chain's launches below)
     // size classes: (0,512] 1 wave, (512,2048] 4 waves, (2048,4096] 8 waves, (4096,8192] 8 waves x 16 elements,
     // >8192 sorted chunks + splitters (beyond FRG_SORT_MID_MAX: global LSD passes); longest-running classes first
     auto launch_global_class = [&]() -> hipError_t {
@@ -793,24 +830,24 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
         }
         return hipGetLastError();
     };
-    // a known non-empty >8192 class runs longest and goes first; when its length is only an estimate
-    // (usually zero tiles) it goes last on its stream: its 1024-thread workgroups would otherwise wait
-    // for a free CU while the class queued behind them sits idle
+    // within a lane: the longer-running group first.  (Sizes unknown: the chain's 1024-thread workgroups -- usually
+    // of an empty list -- go behind the (4096, 8192] class, or they would wait for a free CU while that class sits
+    // idle behind them.)
     if (class_count && (e = launch_global_class()) != hipSuccess) return e;
     // (4096,8192]: 8 waves x 16 staged elements rather than 16 x 8 -- two workgroups fit a CU and
     // one's barrier stalls overlap the other's ranking (0.286 -> 0.256 ms at C3)
-    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, len + 3, ranges, pairs, point_list, c3_on_s1 ? s1 : s2)) != hipSuccess) return e;
+    if ((e = launch_lds_class<8, FRG_SORT_LDS_CAP>(c3, class_tiles + (size_t)3 * T, len + 3, ranges, pairs, point_list, s3)) != hipSuccess) return e;
     if (!class_count && (e = launch_global_class()) != hipSuccess) return e;
-    if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, len + 2, ranges, pairs, point_list, s1)) != hipSuccess) return e;
-    if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, len + 1, ranges, pairs, point_list, stream)) != hipSuccess) return e;
-    if ((e = launch_lds_class<1, 512>(c0, class_tiles, len, ranges, pairs, point_list, stream)) != hipSuccess) return e;
+    if ((e = launch_lds_class<8, 4096>(c2, class_tiles + (size_t)2 * T, len + 2, ranges, pairs, point_list, s2c)) != hipSuccess) return e;
+    if ((e = launch_lds_class<4, 2048>(c1, class_tiles + (size_t)1 * T, len + 1, ranges, pairs, point_list, s10)) != hipSuccess) return e;
+    if ((e = launch_lds_class<1, 512>(c0, class_tiles, len, ranges, pairs, point_list, s10)) != hipSuccess) return e;
     if (forked) {
         if (use_s1) {
-            if ((e = hipEventRecord(ss.join[0], s1)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ss.join[0], lane[1])) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, ss.join[0], 0)) != hipSuccess) return e;
         }
         if (use_s2) {
-            if ((e = hipEventRecord(ss.join[1], s2)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ss.join[1], lane[2])) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, ss.join[1], 0)) != hipSuccess) return e;
         }
     }

@@ -236,6 +236,13 @@ int frg_backward_ex(const frg_backward_args* args);
  * this many tiles blended anything in the forward -- sparsely covered frames are bound by the longest tile's wave;
  * -1 (default) = the built-in 2560, 0 = never.  The two forms add the same partial sums in different orders (both
  * fixed): gradients agree to rounding, each is bit-reproducible.
+ * "counter_mailbox" (default 1): the blocking forward learns num_rendered and the sort's class sizes from a pinned
+ * host mailbox the scan workgroups post to with system-scope stores -- the scatter is enqueued while the scan stage
+ * still runs -- instead of a copy + stream synchronisation behind the scan (0).  The binning callback is then asked
+ * for frg_binning_bytes(num_rendered, FRG_SORT_LDS_CAP + 1) (scratch of every sort path: the longest tile list is not
+ * known yet), ~21 instead of 12 bytes per instance.  Not used with `debug`.  Same counters, same results.
+ * "sort_heavy_on_caller" (default 1): with tile lists beyond the LDS sort, their chain of kernels runs on the caller's
+ * stream and the size classes on the side streams (0: the chain on a side stream).  Scheduling only.
  * Returns the previous value or FRG_EINVAL for an unknown name. */
 int frg_set_option(const char* name, int value);
 int frg_get_option(const char* name);
