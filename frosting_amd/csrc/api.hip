@@ -186,6 +186,34 @@ struct HostMail {
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
 
+// Which mailbox post belongs to which forward, by geometry buffer (process-wide: autograd runs the backward on another
+// thread than the forward).  The pinned mailboxes are never freed.
+struct HeavyNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; };
+std::mutex g_heavy_mu;
+HeavyNote g_heavy_notes[16];
+unsigned g_heavy_next = 0;
+void note_heavy_post(const void* geom, const frg::Mailbox* mail, uint32_t seq)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (auto& n : g_heavy_notes) if (n.geom == geom) { n.mail = mail; n.seq = seq; return; }
+    g_heavy_notes[g_heavy_next++ % 16] = HeavyNote{geom, mail, seq};
+}
+// -> the number of heavy waves of the forward that last filled `geom`, or -1 when unknown (no post, not arrived yet,
+// the mailbox already belongs to a later forward)
+int heavy_waves_posted(const void* geom)
+{
+    HeavyNote n;
+    {
+        std::lock_guard<std::mutex> lk(g_heavy_mu);
+        for (const auto& x : g_heavy_notes) if (x.geom == geom) n = x;
+    }
+    if (!n.mail || !g_use_mailbox.load(std::memory_order_relaxed)) return -1;
+    if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) != n.seq) return -1;
+    const uint32_t h = __atomic_load_n(&n.mail->heavy, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) != n.seq) return -1;
+    return (int)(h > 0x7fffffffu ? 0x7fffffffu : h);
+}
+
 // Spin until the kernel's post arrives.  false: the stream failed, or it drained without the post becoming visible.
 bool mailbox_wait(const uint32_t* flag, uint32_t seq, hipStream_t stream)
 {
@@ -475,6 +503,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     char* geom_chunk = geometry_alloc(user, frg_geometry_bytes(P));
     char* img_chunk = image_alloc(user, frg_image_bytes(width, height));
     if (!geom_chunk || !img_chunk) return fail(FRG_EALLOC, "allocation callback returned null");
+    note_heavy_post(geom_chunk, nullptr, 0);      // whatever an earlier forward posted about this buffer is void now
     const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
     const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height, g_global_bins.load() != 0);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:228-231
@@ -572,8 +601,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
                 b = frg::BinningState::carve(bin_chunk, R, FRG_SORT_LDS_CAP + 1);
                 if (g_mail.long_lists)
                     FRG_STAGE(frg::launch_sort_plan(T, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream, 1), "sort plan");
-                { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
+                { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load(), mail, mail_seq), "scatter"); }
                 { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
+                note_heavy_post(geom_chunk, mail, mail_seq);
                 early = true;
             }
             if (mailbox_wait(&mail->seq_c, mail_seq, stream)) { c = mail->c; have_counters = true; }
@@ -780,10 +810,13 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         // the 16-wave form for the Gaussians that own thousands of slots runs on a side stream beside the plain kernel
         // (usually its workgroups find an empty list and leave)
         StageScope sc_(ST_PREPROCESS_BWD, stream);
-        const bool side = !debug && g_bwd_side.ensure();
+        // the forward's scatter posted how many waves of Gaussians need the 16-wave form (Mailbox::heavy): none, usually
+        const bool skip_heavy = !debug && heavy_waves_posted(geom_buffer) == 0;
+        const bool side = !skip_heavy && !debug && g_bwd_side.ensure();
         hipStream_t hs = side ? g_bwd_side.stream : stream;
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
-        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, hs), "preprocess_bwd (long runs)");
+        if (!skip_heavy)
+            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, hs), "preprocess_bwd (long runs)");
         FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, stream), "preprocess_bwd");
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
     }

@@ -109,6 +109,10 @@ struct Mailbox {
     uint32_t seq_r, num_rendered, pad0[14];      // one 64-byte line per stage
     uint32_t seq_c, pad1[3];
     Counters c;
+    // third post, by the scatter (not waited for): how many 64-Gaussian waves own more than FRG_BWD_HEAVY_SLOTS
+    // backward slots -- a backward that finds its forward's post here and reads 0 skips the 16-wave launch of the
+    // per-Gaussian backward and its fork / join (~11 us per step at C3)
+    uint32_t seq_h, heavy, pad2[14];
 };
 __device__ __forceinline__ void mailbox_post(uint32_t* flag, uint32_t seq)
 {

@@ -21,7 +21,7 @@ hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, con
 hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const ImageState& img, uint32_t capacity, hipStream_t s,
                        Mailbox* mail = nullptr, uint32_t seq = 0);
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
-                          const BinningState& b, hipStream_t s, int ablate = 0);
+                          const BinningState& b, hipStream_t s, int ablate = 0, Mailbox* mail = nullptr, uint32_t seq = 0);
 extern int g_rows_grid;   // workgroups of the row-ordered scatter (tuning)
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
 

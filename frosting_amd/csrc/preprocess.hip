@@ -875,12 +875,15 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
 #define FRG_ROWS_SUB 8
 __global__ void __launch_bounds__(FRG_BIN_THREADS)
 scatter_rows_kernel(int T, int gx, int gy, const uint4* __restrict__ row_records, const uint2* __restrict__ ranges,
-                    uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs, const Counters* __restrict__ counters, int ablate)
+                    uint32_t* __restrict__ tile_fill, uint2* __restrict__ pairs, const Counters* __restrict__ counters, int ablate,
+                    const uint32_t* __restrict__ heavy_waves, Mailbox* mail, uint32_t seq)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
     __shared__ uint32_t emit_start[(FRG_BIN_THREADS / 64) * 68];
     __shared__ int4 emit_info[FRG_BIN_THREADS];
     __shared__ int row_lo, row_hi;
+    // (the list of heavy waves was finished by reorder_kernel)
+    if (mail && blockIdx.x == 0 && threadIdx.x == 0) { mail->heavy = heavy_waves[0]; mailbox_post(&mail->seq_h, seq); }
     // the binning buffer is too small for this frame (deferred-counters forward): every tile list was left empty
     if (counters->overflow != 0) return;
     // Every workgroup takes one contiguous share of the records, a multiple of 1024 (a few cells: some dozens of
@@ -1080,7 +1083,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
 }
 
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
-                          const BinningState& b, hipStream_t s, int ablate)
+                          const BinningState& b, hipStream_t s, int ablate, Mailbox* mail, uint32_t seq)
 {
     const int T = vp.gx * vp.gy;
     const int nb = bin_blocks(P);
@@ -1093,7 +1096,7 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
         hipError_t e = allow_big_lds(scatter_rows_kernel, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(FRG_BIN_THREADS), lds, s, T, vp.gx, vp.gy, g.row_records,
-                           img.ranges, img.tile_fill, b.pairs, img.counters, ablate);
+                           img.ranges, img.tile_fill, b.pairs, img.counters, ablate, g.heavy_waves, mail, seq);
         return hipGetLastError();
     }
 #define FRG_SCATTER(L, TI, LDS)                                                                                          \

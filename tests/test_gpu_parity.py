@@ -696,6 +696,22 @@ def test_counter_mailbox_and_copy_read_back_agree(gpu_device, ops):
         assert all(torch.equal(x, y) for x, y in zip(a[6], b[6])), i
     assert results[(1, 3)][0] == 0 and results[(1, 1)][0] > 300_000
     assert int((results[(1, 1)][3][:, 1] - results[(1, 1)][3][:, 0]).max()) > 8192
+    # The scatter also posts how many 64-Gaussian waves need the 16-wave per-Gaussian backward; a backward that reads 0
+    # skips that launch.  A post must never outlive its forward: the same buffers (the caching allocator hands the freed
+    # blocks out again) filled by a forward WITHOUT mailbox, with giant Gaussians where the previous view had none.
+    big, cam_b, bg_b = scenes.long_list_scene(P=300_000)
+    tame = scenes.Scene(big.means3D, big.scales.clamp(max=0.02), big.rotations, big.opacities, big.shs, big.sh_degree)
+    def grads_of(sc, mailbox):
+        _lib.set_option("counter_mailbox", mailbox)
+        out, args = Hh.run_ours_native(sc, cam_b, bg_b, dev, ops=ops)
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 9)
+        return [g.clone() for g in ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(dev)))]
+    want = grads_of(big, 0)
+    for _ in range(3):
+        grads_of(tame, 1)                      # posts "no heavy waves" for its buffers, then frees them
+        got = grads_of(big, 0)                 # no post of its own
+        assert all(torch.equal(x, y) for x, y in zip(want, got))
+    assert all(torch.equal(x, y) for x, y in zip(want, grads_of(big, 1)))
     # the prefiltered assertion (auxiliary.h:154-162) is raised from the posted counters as well
     scene, cam, bg = scenes.config_scene("c2", 0, P=5_000)
     _lib.set_option("counter_mailbox", 1)
