@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 
 namespace {
@@ -185,6 +186,7 @@ struct HostMail {
 };
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
+std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
 
 // Which mailbox post belongs to which forward, by geometry buffer (process-wide: autograd runs the backward on another
 // thread than the forward).  The pinned mailboxes are never freed.
@@ -208,7 +210,15 @@ int heavy_waves_posted(const void* geom)
         for (const auto& x : g_heavy_notes) if (x.geom == geom) n = x;
     }
     if (!n.mail || !g_use_mailbox.load(std::memory_order_relaxed)) return -1;
-    if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) != n.seq) return -1;
+    // The forward returned when the scan stage was through; the scatter posts as its first act.  A backward called
+    // straight away may be a few microseconds early: it waits that long (the GPU has the rest of the forward ahead of
+    // it, the host nothing better to do), but not for a scatter stuck behind other work.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+        if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) == n.seq) break;
+        if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return -1;
+        __builtin_ia32_pause();
+    }
     const uint32_t h = __atomic_load_n(&n.mail->heavy, __ATOMIC_RELAXED);
     if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) != n.seq) return -1;
     return (int)(h > 0x7fffffffu ? 0x7fffffffu : h);
@@ -358,6 +368,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
     // stray call must not be able to switch them on -- they exist only in processes started with FROSTING_EXPERIMENTS=1
@@ -408,6 +419,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
+    if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.load();
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
@@ -517,7 +529,12 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         // that copy must have happened before the counters are cleared again
         if (reused) FRG_HIP(hipStreamWaitEvent(stream, pend->ev, 0));
     }
-    FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
+    // LDS-bins paths: nothing of the image chunk needs clearing in front of the forward -- colsum_kernel zeroes the
+    // scatter cursors and the blend's depth marks on its way, every counter is written unconditionally; only the flag
+    // of the prefiltered assertion is set-only.  Global bins (more tiles than the LDS holds): the per-tile counts are
+    // accumulated with atomics, the whole region is cleared.
+    if (!img.lds_bins || g_clear_image_state.load(std::memory_order_relaxed)) FRG_HIP(hipMemsetAsync(img_chunk + img.zero_begin, 0, img.zero_bytes, stream));
+    else if (prefiltered || capacity > 0) FRG_HIP(hipMemsetAsync(&img.counters->filtered, 0, sizeof(uint32_t), stream));   // (deferred: frg_forward_finish is told `prefiltered` again)
 
     frg::FwdInputs in{means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos};
     in.keep_mask = keep_mask;

@@ -529,7 +529,9 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
         counters->num_rendered = sh.carry;
         // more instances than the caller's binning buffer holds (deferred-counters forward):
         // every tile list is left empty, the frame renders as background and is redone
-        if (capacity && sh.carry > capacity) { sh.ovf = 1; counters->overflow = 1; }
+        // (written either way: in the LDS-bins paths nothing clears the counters before the forward)
+        const uint32_t ovf = (capacity && sh.carry > capacity) ? 1u : 0u;
+        sh.ovf = ovf; counters->overflow = ovf;
         if (mail) { mail->num_rendered = sh.carry; mailbox_post(&mail->seq_r, seq); }
     }
     __syncthreads();
@@ -686,7 +688,7 @@ __global__ void __launch_bounds__(256)
 colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums,
               uint32_t* __restrict__ row_matrix, uint32_t* __restrict__ row_total, int gy,
               int nchunks, uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, uint32_t capacity,
-              Mailbox* mail, uint32_t seq)
+              Mailbox* mail, uint32_t seq, uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ tile_work)
 {
     if (blockIdx.y == FRG_BIN_SEGS + 1) {
         if (blockIdx.x != 0) return;
@@ -721,6 +723,9 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
     }
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
+    // the scatter's fill cursor and the forward blend's depth mark of every tile start at zero: cleared here, on the way,
+    // instead of by a memset launch in front of every forward
+    if (blockIdx.y == 0) { tile_fill[t] = 0u; tile_work[t] = 0u; }
     // segment s = the workgroups the dispatcher places on XCD s (round robin, FRG_BIN_SEGS == 8):
     // a tile's runs written by one XCD are then adjacent in memory, so partially written lines
     // are completed inside that XCD's L2 instead of being written back piecemeal by eight L2s
@@ -1060,7 +1065,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     if (img.lds_bins)
         hipLaunchKernelGGL(colsum_kernel, dim3(std::max((T + 255) / 256, cells ? (img.ncells + 3) / 4 : 0), FRG_BIN_SEGS + (cells ? 2 : 0)),
                            dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums, img.row_matrix, img.row_start, img.ncells,
-                           nchunks, g.block_sums, img.counters, capacity, mail, seq);
+                           nchunks, g.block_sums, img.counters, capacity, mail, seq, img.tile_fill, img.tile_work);
     if (cells) {
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,

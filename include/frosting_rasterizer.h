@@ -241,6 +241,8 @@ int frg_backward_ex(const frg_backward_args* args);
  * still runs -- instead of a copy + stream synchronisation behind the scan (0).  The binning callback is then asked
  * for frg_binning_bytes(num_rendered, FRG_SORT_LDS_CAP + 1) (scratch of every sort path: the longest tile list is not
  * known yet), ~21 instead of 12 bytes per instance.  Not used with `debug`.  Same counters, same results.
+ * "clear_image_state" (default 0): 1 = clear the image chunk's per-tile cursors and counters with a memset in front of
+ * every forward even where the kernels initialise them on their way (images whose tiles fit the LDS bins).
  * "sort_heavy_on_caller" (default 1): with tile lists beyond the LDS sort, their chain of kernels runs on the caller's
  * stream and the size classes on the side streams (0: the chain on a side stream).  Scheduling only.
  * Returns the previous value or FRG_EINVAL for an unknown name. */
