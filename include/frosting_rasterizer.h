@@ -239,7 +239,7 @@ int frg_backward_ex(const frg_backward_args* args);
  * "counter_mailbox" (default 1): the blocking forward learns num_rendered and the sort's class sizes from a pinned
  * host mailbox the scan workgroups post to with system-scope stores -- the scatter is enqueued while the scan stage
  * still runs -- instead of a copy + stream synchronisation behind the scan (0).  The binning callback is then asked
- * for frg_binning_bytes(num_rendered, FRG_SORT_LDS_CAP + 1) (scratch of every sort path: the longest tile list is not
+ * for frg_binning_bytes(num_rendered, 8193) (8193 = "longest tile list unknown": scratch of every sort path, as it is not
  * known yet), ~21 instead of 12 bytes per instance.  Not used with `debug`.  Same counters, same results.
  * "clear_image_state" (default 0): 1 = clear the image chunk's per-tile cursors and counters with a memset in front of
  * every forward even where the kernels initialise them on their way (images whose tiles fit the LDS bins).
@@ -258,7 +258,8 @@ int frg_get_option(const char* name);
  * (7) or a negative error. */
 int frg_stage_times(float* ms, int n);
 
-/* Sizes of the three state chunks (what the callbacks will be asked for). */
+/* Sizes of the three state chunks (what the callbacks will be asked for).  max_tile_count: the longest tile list of the
+ * view (lists beyond 8192 entries need a second pair buffer); 8193 stands for "unknown" and sizes for every sort path. */
 size_t frg_geometry_bytes(int P);
 size_t frg_image_bytes(int width, int height);
 size_t frg_binning_bytes(int R, int max_tile_count);
