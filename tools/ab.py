@@ -60,13 +60,19 @@ base = None
 defaults = {}
 for setting in a.settings:
     pairs = [kv.split("=") for kv in setting.split(",") if kv]
+    timed_stage = None      # pseudo-option timedprof=K: hipEvents around stage K stay ON in the timed loop (what bench.py's roofline costs)
     for k, v in pairs:
+        if k == "timedprof":
+            timed_stage = int(v); continue
         old = _lib.set_option(k, int(v)); defaults.setdefault(k, old)
     for _ in range(10): step()
     _lib.set_option("profile", 0)
+    if timed_stage is not None:
+        _lib.set_option("profile", 1); _lib.set_option("profile_stage", timed_stage)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(a.steps): step()
     torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    _lib.set_option("profile_stage", -1)
     _lib.set_option("profile", 1); _lib.stage_times()
     for _ in range(10): step()
     torch.cuda.synchronize()
