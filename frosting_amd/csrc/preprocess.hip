@@ -796,6 +796,7 @@ scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ depth_rect, c
             dbits = depth_rect[3 * idx];
             const uint32_t lo = depth_rect[3 * idx + 1], hi = depth_rect[3 * idx + 2];
             x0 = (int)(lo & 0xFFFFu); y0 = (int)(lo >> 16); x1 = (int)(hi & 0xFFFFu); y1 = (int)(hi >> 16);
+            (void)y1;   // (the walk needs the rectangle's origin and width only)
             if (TIGHT) { const float4 g = xydr[FRG_REC * idx]; emit_xy[threadIdx.x] = make_float2(g.x, g.y); emit_co[threadIdx.x] = conic_opacity[FRG_REC * idx]; }
         }
         const int wave = threadIdx.x >> 6;
