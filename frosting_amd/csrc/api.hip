@@ -215,7 +215,9 @@ int heavy_waves_posted(const void* geom)
     // it, the host nothing better to do), but not for a scatter stuck behind other work.
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; spin++) {
-        if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) == n.seq) break;
+        const uint32_t cur = __atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE);
+        if (cur == n.seq) break;
+        if ((int32_t)(cur - n.seq) > 0) return -1;      // the mailbox already carries a later forward's post
         if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return -1;
         __builtin_ia32_pause();
     }

@@ -47,7 +47,7 @@ struct GeomState {
     uint32_t* tiles_touched;
     // what the scatter needs of a visible Gaussian, compact (12 bytes, streamed): depth bits, tile rectangle
     // x0 | y0 << 16, x1 | y1 << 16 -- the records above are laid out for the blend kernels' gathers
-    uint32_t* depth_rect;
+    uint32_t* depth_rect;    // three planes of P words: depth bits | rect min (x | y << 16) | rect max
     uint32_t* point_offsets; // inclusive scan of tiles_touched (rasterizer_impl.cu:277)
     uint32_t* block_sums;    // per-256-Gaussian block totals -> exclusive prefix
     int* internal_radii;     // used when the caller passes radii == NULL (rasterizer_impl.cu:228-231)
@@ -79,7 +79,7 @@ struct GeomState {
         s.block_sums = (uint32_t*)(base + o); o = align_up(o + ((Pp + 255) / 256 + 1) * 4, 256);  // per chunk
         s.internal_radii = (int*)(base + o); o = align_up(o + Pp * 4, 256);
         s.row_records = (uint4*)(base + o); o = align_up(o + Pp * 16, 256);
-        s.sh_dir = (float*)(base + o); o = align_up(o + Pp * 36, 256);
+        s.sh_dir = (float*)(base + o); o = align_up(o + ((Pp + 63) / 64 * 64) * 36, 256);   // whole waves: the SH pass stores 16-Gaussian blocks
         s.heavy_waves = (uint32_t*)(base + o); o = align_up(o + (Pp / 64 + 2) * 4, 256);
         s.bytes = o;
         return s;
