@@ -249,10 +249,11 @@ def test_skewed_scene_vs_reference_rasterizer(gpu_device):
     cfg = scenes.CONFIGS["c3"]
     scene = scenes.make_skew_scene(cfg["P"], cfg["seed"] + 77)
     _, cam, bg = scenes.config_scene("c3", 0, P=1000)
-    # floors x 3: a near-camera Gaussian sums its gradient over hundreds of tiles, a cluster tile over 10^5 entries --
+    # floors x 5: a near-camera Gaussian sums its gradient over hundreds of tiles, a cluster tile over 10^5 entries --
     # two valid float32 summation orders (the reference's atomics, our per-tile partials) drift apart with the length
-    # of the sums (measured: 2.0e-6 on dL_dopacity where the uniform scene has 2.6e-7)
-    list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops("ext"), "skew 3M", floor_scale=3.0)
+    # of the sums (measured: 1.9e-6 ... 2.0e-6 on dL_dopacity and 1.7e-6 on the colours, where the uniform scene has
+    # 2.6e-7 / 2.3e-7; the distance moves with the reference's realisation, so the bar keeps a factor 2 over it)
+    list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops("ext"), "skew 3M", floor_scale=5.0)
     assert int(list_len.max()) > 250_000 and int((list_len > 8192).sum()) >= 100
 
 
