@@ -186,6 +186,7 @@ struct HostMail {
 };
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
+std::atomic<int> g_bwd_heavy_first{1};
 std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
 
 // Which mailbox post belongs to which forward, by geometry buffer (process-wide: autograd runs the backward on another
@@ -370,6 +371,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.exchange(value ? 1 : 0);
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
@@ -421,6 +423,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
+    if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.load();
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.load();
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
@@ -830,13 +833,20 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         // (usually its workgroups find an empty list and leave)
         StageScope sc_(ST_PREPROCESS_BWD, stream);
         // the forward's scatter posted how many waves of Gaussians need the 16-wave form (Mailbox::heavy): none, usually
-        const bool skip_heavy = !debug && heavy_waves_posted(geom_buffer) == 0;
+        const int heavy = debug ? -1 : heavy_waves_posted(geom_buffer);
+        const bool skip_heavy = heavy == 0;
         const bool side = !skip_heavy && !debug && g_bwd_side.ensure();
+        // Known to exist: the few 16-wave workgroups go on the CALLER's stream and start at once on an empty GPU, the
+        // plain kernel follows on the side stream a cross-queue hop later and fills the rest -- behind the plain kernel's
+        // 47 k waves the 1024-thread workgroups waited for a whole free CU and ran mostly after it (clustered scene:
+        // 0.41 -> 0.33 ms).  Unknown (no post): the 16-wave form on the high-priority side stream, as before.
+        const bool heavy_first = side && heavy > 0 && g_bwd_heavy_first.load(std::memory_order_relaxed);
         hipStream_t hs = side ? g_bwd_side.stream : stream;
+        hipStream_t s_heavy = heavy_first ? stream : hs, s_plain = heavy_first ? hs : stream;
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
         if (!skip_heavy)
-            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, hs), "preprocess_bwd (long runs)");
-        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, stream), "preprocess_bwd");
+            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, s_heavy), "preprocess_bwd (long runs)");
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, s_plain), "preprocess_bwd");
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
     }
     return FRG_OK;
