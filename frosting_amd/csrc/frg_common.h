@@ -139,12 +139,12 @@ struct ImageState {
     float* final_T;          // accum_alpha in the reference (rasterizer_impl.h:47)
     uint32_t* n_contrib;
     uint2* ranges;           // per tile [start,end) into point_list; (0,0) when empty
-    uint32_t* tile_count;    // zeroed every forward; counted by preprocess
-    uint32_t* tile_fill;     // zeroed every forward; scatter cursor
-    uint32_t* tile_work;     // zeroed every forward; list entries the forward blend walked (max over the tile's pixels)
+    uint32_t* tile_count;    // instances per tile: written by the tile scan (LDS bins) | cleared by the forward's memset and counted with atomics (global bins)
+    uint32_t* tile_fill;     // scatter cursor; zero at the start of every forward (colsum_kernel, or the memset of the global-bins path)
+    uint32_t* tile_work;     // list entries the forward blend walked (max over the tile's pixels); zeroed like tile_fill
     uint32_t* bwd_order;     // [xcd_grid_blocks(T)] workgroup -> tile map of the backward blend (longest tiles first)
     uint32_t* bwd_mode;      // 1: few active tiles, the quadrant form of the backward blend has this frame (bwd_order_kernel)
-    Counters* counters;      // zeroed every forward
+    Counters* counters;      // every field written by the forward's kernels (filtered: set-only, cleared when the assertion is on)
     uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
     uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts (-> scatter bases when !row_order)
     uint32_t* seg_sums;      // [FRG_BIN_SEGS][T]
@@ -155,7 +155,7 @@ struct ImageState {
     // cells of the record order: tile row x band of band_w tile columns (nbands per row, at most FRG_MAX_TILE_ROWS cells)
     int band_w, nbands, ncells;
     uint32_t* class_tiles;   // [FRG_SORT_CLASSES][T] tile ids per sort size class (non-empty tiles only)
-    size_t zero_begin, zero_bytes;  // region [tile_count .. counters] cleared with one memset
+    size_t zero_begin, zero_bytes;  // region [tile_count .. counters]: one memset in the global-bins path (api.hip)
     size_t bytes;
     __host__ static ImageState carve(char* base, int W, int H, bool force_global_bins = false)
     {
