@@ -371,6 +371,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "fwd_prefetch") == 0) { const int old = frg::g_fwd_prefetch; frg::g_fwd_prefetch = value ? 1 : 0; return old; }
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.exchange(value ? 1 : 0);
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
@@ -423,6 +424,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
+    if (name && strcmp(name, "fwd_prefetch") == 0) return frg::g_fwd_prefetch;
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.load();
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.load();
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;

@@ -5,10 +5,16 @@
 #include "blend_impl.h"
 #include "kernels.h"
 namespace frg {
+int g_fwd_prefetch = 1;   // frg_set_option("fwd_prefetch"): forward blend requests round r + 1's records before it processes round r
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                 const float* bg, float* out_color, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
+    if (g_fwd_prefetch)
+        hipLaunchKernelGGL((blend_fwd_kernel<FRG_EXACT, true>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H,
+                           img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,
+                           out_color, img.tile_work);
+    else
     hipLaunchKernelGGL((blend_fwd_kernel<FRG_EXACT>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H,
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,
                        out_color, img.tile_work);

@@ -243,6 +243,8 @@ int frg_backward_ex(const frg_backward_args* args);
  * known yet), ~21 instead of 12 bytes per instance.  Not used with `debug`.  Same counters, same results.
  * "clear_image_state" (default 0): 1 = clear the image chunk's per-tile cursors and counters with a memset in front of
  * every forward even where the kernels initialise them on their way (images whose tiles fit the LDS bins).
+ * "fwd_prefetch" (default 1): the forward blend requests the next 64 list entries' records while it processes the
+ * current ones (0: plain loop).  Scheduling only, outputs bit-identical.
  * "bwd_heavy_first" (default 1): when the forward posted that some 64-Gaussian waves own thousands of backward slots,
  * their 16-wave workgroups run on the caller's stream and the plain per-Gaussian kernel beside them on a side stream
  * (0: the other way round).  Scheduling only.
