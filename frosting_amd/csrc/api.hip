@@ -172,6 +172,13 @@ struct HostMail {
     frg::Mailbox* host = nullptr;
     uint32_t seq = 0;
     bool long_lists = false;     // the previous forward of this thread had tile lists beyond the LDS sort
+    int last_P = 0; uint32_t last_seq = 0;      // the forward whose scatter post may still be in the mailbox
+    // the previous forward of this thread, on a model of the same size, saw less than three quarters of it
+    bool sparse_view(int P) const
+    {
+        if (!host || P != last_P || __atomic_load_n(&host->seq_h, __ATOMIC_ACQUIRE) != last_seq) return false;
+        return (uint64_t)host->visible * 4u < (uint64_t)P * 3u;
+    }
     bool failed = false;         // a post never arrived although the stream had drained: stay with the copy + synchronise
     frg::Mailbox* get()
     {
@@ -186,6 +193,7 @@ struct HostMail {
 };
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
+std::atomic<int> g_sparse_sh{1};            // option "sparse_sh": the SH pass over the visible Gaussians only, where a view sees a part of the model
 std::atomic<int> g_bwd_heavy_first{1};
 std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
 
@@ -345,6 +353,7 @@ frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_
     vp.gx = (width + FRG_TILE - 1) / FRG_TILE; vp.gy = (height + FRG_TILE - 1) / FRG_TILE;
     vp.D = D; vp.M = M;
     vp.tight = tight;
+    vp.sparse_sh = 0;
     return vp;
 }
 
@@ -371,6 +380,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.exchange(value ? 1 : 0);
     if (name && strcmp(name, "fwd_prefetch") == 0) { const int old = frg::g_fwd_prefetch; frg::g_fwd_prefetch = value ? 1 : 0; return old; }
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.exchange(value ? 1 : 0);
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
@@ -424,6 +434,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
     if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
+    if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.load();
     if (name && strcmp(name, "fwd_prefetch") == 0) return frg::g_fwd_prefetch;
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.load();
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.load();
@@ -516,7 +527,10 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         return fail(FRG_EINVAL, "SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(FRG_EINVAL, "null allocation callback");
 
-    const frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, md.tight);
+    frg::ViewParams vp = make_view(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier, md.tight);
+    // Will this view see only a part of the model?  With an occlusion mask: yes.  Otherwise: what the previous forward of
+    // this thread saw (posted by its scatter) -- the SH pass then streams the rows of the visible Gaussians only.
+    vp.sparse_sh = g_sparse_sh.load(std::memory_order_relaxed) && (keep_mask != nullptr || g_mail.sparse_view(P));
     const int T = vp.gx * vp.gy;
 
     char* geom_chunk = geometry_alloc(user, frg_geometry_bytes(P));
@@ -628,6 +642,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
                 { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load(), mail, mail_seq), "scatter"); }
                 { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
                 note_heavy_post(geom_chunk, mail, mail_seq);
+                g_mail.last_P = P; g_mail.last_seq = mail_seq;
                 early = true;
             }
             if (mailbox_wait(&mail->seq_c, mail_seq, stream)) { c = mail->c; have_counters = true; }

@@ -64,6 +64,7 @@ struct GeomState {
     // instances (near-camera Gaussians of hundreds of tiles): found where point_offsets is finished (reorder_kernel /
     // scatter_kernel), read by the per-Gaussian backward, which gives each of them a 16-wave workgroup
     uint32_t* heavy_waves;
+    uint32_t* sh_layout;     // one word: 1 = the SH pass stored sh_dir by slot (sh_slot_of), 0 = by lane
     size_t bytes;
     __host__ static GeomState carve(char* base, int P)
     {
@@ -81,10 +82,21 @@ struct GeomState {
         s.row_records = (uint4*)(base + o); o = align_up(o + Pp * 16, 256);
         s.sh_dir = (float*)(base + o); o = align_up(o + ((Pp + 63) / 64 * 64) * 36, 256);   // whole waves: the SH pass stores 16-Gaussian blocks
         s.heavy_waves = (uint32_t*)(base + o); o = align_up(o + (Pp / 64 + 2) * 4, 256);
+        s.sh_layout = (uint32_t*)(base + o); o = align_up(o + 4, 256);
         s.bytes = o;
         return s;
     }
 };
+
+// Rows of GeomState::sh_dir inside a wave's block of 64: by lane -- or, when the forward ran the SH pass that streams
+// only the visible Gaussians (GeomState::sh_layout = 1: views that see a part of the model) and less than three quarters
+// of the wave are visible, by rank among the visible ones.  The forward's SH pass and the per-Gaussian backward both
+// derive the slot from the wave's visibility ballot.
+__host__ __device__ inline bool sh_slot_dense(int nvis) { return nvis > 48; }   // four sub-batches of 16 either way
+__device__ __forceinline__ int sh_slot_of(uint64_t vis, int lane, bool sparse_layout)
+{
+    return (!sparse_layout || sh_slot_dense(__popcll(vis))) ? lane : __popcll(vis & ((1ull << lane) - 1ull));
+}
 
 // ---- image chunk ----------------------------------------------------------
 #define FRG_SORT_CLASSES 5    // tile-list size classes of the sort: <=512, <=2048, <=4096, <=8192, >8192
@@ -112,7 +124,7 @@ struct Mailbox {
     // third post, by the scatter (not waited for): how many 64-Gaussian waves own more than FRG_BWD_HEAVY_SLOTS
     // backward slots -- a backward that finds its forward's post here and reads 0 skips the 16-wave launch of the
     // per-Gaussian backward and its fork / join (~11 us per step at C3)
-    uint32_t seq_h, heavy, pad2[14];
+    uint32_t seq_h, heavy, visible, pad2[13];   // visible: Counters::num_visible (the next forward's sparse_sh hint)
 };
 __device__ __forceinline__ void mailbox_post(uint32_t* flag, uint32_t seq)
 {
@@ -278,6 +290,7 @@ struct ViewParams {
     int W, H, gx, gy;
     int D, M;   // active SH degree, coefficients per channel in memory
     int tight;  // 1: binning keeps only (Gaussian, tile) instances that can reach alpha >= 1/255 in the tile
+    int sparse_sh;  // 1: the view is expected to see a part of the model only (occlusion mask, last view's count): SH pass over the visible Gaussians
 };
 struct ViewMats {
     float view[16];

@@ -207,23 +207,32 @@ __device__ __forceinline__ void wave_sync_lds()
 // (the rows' pads, which hold the colour sums at that time)
 __device__ __forceinline__ int sh_dd_slot(int e) { const int q = e >> 2; return ((q + q / 12) << 2) + (e & 3); }
 
-__device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restrict__ src, int nvalid, bool touched, float3 dir,
-                                                 float4* shbuf, float4* dirs, int dir_stride, float* __restrict__ sh_dir_out)
+// The SH pass works on SLOTS of 16 (frg_common.h: sh_slot_dense / sh_slot_of).  DENSE -- most of the wave visible -- a
+// slot is a lane: the rows stream in as one contiguous block per sub-batch, sub-batches without a visible Gaussian are
+// skipped.  Otherwise only the VISIBLE Gaussians get slots, in rank order: a view that sees a third of the model (occlusion
+// or frustum culling) reads a third of the rows in a third of the sub-batches, each row still 192 contiguous bytes (C4:
+// per-Gaussian forward 0.175 -> 0.142 ms).  dirs[r].w then names the lane behind slot r (the rank permutation is pushed
+// through the LDS crossbar, the invisible lanes behind the visible ones); DENSE: the visibility flag of lane r.
+// Two instances of one body: the dense one is the code the uniform scene has always run.
+template <bool DENSE>
+__device__ __forceinline__ float4 sh_pass(int deg, const float4* __restrict__ src, int nvalid, bool touched, uint64_t vis, int my_slot,
+                                          float4* shbuf, const float4* dirs, int dir_stride, float* __restrict__ sh_dir_out)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t vis = __ballot(touched);
-    if (vis == 0ull) return make_float4(0.f, 0.f, 0.f, 0.f);
-    dirs[lane * dir_stride] = make_float4(dir.x, dir.y, dir.z, touched ? 1.0f : 0.0f);
-    uint32_t need = 0;
+    const int nvis = __popcll(vis);
+    uint32_t need = 0;                  // sub-batches with work
+    if (DENSE) {
 #pragma unroll
-    for (int h = 0; h < 64 / PRE_SUB; h++)
-        if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
+        for (int h = 0; h < 64 / PRE_SUB; h++)
+            if (vis & (0xFFFFull << (h * PRE_SUB))) need |= 1u << h;
+    } else need = (1u << ((nvis + PRE_SUB - 1) / PRE_SUB)) - 1u;
     float4 pre[PRE_SUB * 12 / 64];
     auto issue = [&](int h) {
 #pragma unroll
         for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
-            const int f = k * 64 + lane, gl = f / 12;
-            pre[k] = (h * PRE_SUB + gl < nvalid) ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12, r = h * PRE_SUB + gl;
+            if (DENSE) pre[k] = r < nvalid ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            else pre[k] = r < nvis ? src[(uint32_t)(__float_as_int(dirs[r * dir_stride].w) * 12 + j)] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     int h = __builtin_ctz(need);
@@ -242,8 +251,12 @@ __device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restri
         const int hn = rest ? h + 1 + __builtin_ctz(rest) : 64 / PRE_SUB;
         if (hn < 64 / PRE_SUB) issue(hn);
         wave_sync_lds();
-        const float4 dv = dirs[(h * PRE_SUB + g) * dir_stride];
-        if (ch < 3 && dv.w != 0.0f) {
+        const int r = h * PRE_SUB + g;                   // slot of this lane's Gaussian
+        float4 dv = dirs[r * dir_stride];
+        bool work = ch < 3;
+        if (DENSE) work = work && dv.w != 0.0f;
+        else { work = work && r < nvis; if (work) dv = dirs[__float_as_int(dv.w) * dir_stride]; }
+        if (work) {
             float w[16];
             const int ncoef = sh_weights(deg, dv.x, dv.y, dv.z, w);
             const ShDir sd(deg, dv.x, dv.y, dv.z);
@@ -261,16 +274,18 @@ __device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restri
             reinterpret_cast<float*>(shbuf + g * PRE_ROW_F4 + 12)[ch] = acc;    // the row's pad float4: raw colour sums
             // The sub-batch's derivative rows ([16][9] floats, contiguous in sh_dir) are assembled in the LDS rows just
             // consumed -- in the float4 slots that are not a pad -- and leave as 36 float4: stored straight from here
-            // they were 144 scattered 4-byte requests per sub-batch (22 M per view: 30 us of L2 request rate at C3).
+            // they were 144 scattered 4-byte requests per sub-batch.
             float* rowf = reinterpret_cast<float*>(shbuf);
             const int e = g * 9 + ch;
             rowf[sh_dd_slot(e)] = ddx; rowf[sh_dd_slot(e + 3)] = ddy; rowf[sh_dd_slot(e + 6)] = ddz;
         }
         wave_sync_lds();
-        if (lane < PRE_SUB * 9 / 4)      // (rows of invisible Gaussians carry whatever the slots held: never read)
+        // sh_dir holds the rows BY SLOT inside the wave's block of 64 (the per-Gaussian backward derives the slot from the
+        // same visibility ballot); empty slots carry whatever the LDS held: never read
+        if (lane < PRE_SUB * 9 / 4)
             reinterpret_cast<float4*>(sh_dir_out + (size_t)h * PRE_SUB * 9)[lane] = shbuf[lane + lane / 12];
-        if ((lane / PRE_SUB) == h && touched) {
-            const float4 c = shbuf[(lane % PRE_SUB) * PRE_ROW_F4 + 12];
+        if (touched && (my_slot / PRE_SUB) == h) {
+            const float4 c = shbuf[(my_slot % PRE_SUB) * PRE_ROW_F4 + 12];
             ShAccum sa;
             sa.acc[0] = c.x; sa.acc[1] = c.y; sa.acc[2] = c.z;
             mine = sa.finish();
@@ -281,12 +296,34 @@ __device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restri
     return mine;
 }
 
+// SPARSE: the kernel also carries the instance for waves of which less than three quarters are visible (launched when
+// the view is expected to see a part of the model; GeomState::sh_layout tells the backward).
+template <bool SPARSE>
+__device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restrict__ src, int nvalid, bool touched, float3 dir,
+                                                 float4* shbuf, float4* dirs, int dir_stride, float* __restrict__ sh_dir_out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t vis = __ballot(touched);
+    if (vis == 0ull) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nvis = __popcll(vis);
+    if (!SPARSE || sh_slot_dense(nvis)) {          // wave-uniform
+        dirs[lane * dir_stride] = make_float4(dir.x, dir.y, dir.z, touched ? 1.0f : 0.0f);
+        return sh_pass<true>(deg, src, nvalid, touched, vis, lane, shbuf, dirs, dir_stride, sh_dir_out);
+    }
+    const int rank = __popcll(vis & ((1ull << lane) - 1ull));
+    const int behind = __builtin_amdgcn_ds_permute((touched ? rank : nvis + (lane - rank)) << 2, lane);
+    dirs[lane * dir_stride] = make_float4(dir.x, dir.y, dir.z, __int_as_float(behind));
+    wave_sync_lds();
+    return sh_pass<false>(deg, src, nvalid, touched, vis, rank, shbuf, dirs, dir_stride, sh_dir_out);
+}
+
 // SHMODE: how the SH colour of a visible Gaussian is produced.
 //   SH_INLINE  in this kernel, one strided read per coefficient (any layout)
 //   SH_STREAM  in this kernel, coefficients streamed as float4 and transposed through LDS (M == 16)
 //   SH_DEFER   not here: sh_color_kernel computes it on a side stream while the binning stages (scan, scatter,
 //              sort -- LDS / latency bound, HBM nearly idle) run on the caller's; the blend waits for both
-enum { SH_INLINE = 0, SH_STREAM = 1, SH_DEFER = 2 };
+//   SH_STREAM_SPARSE  SH_STREAM with the instance for sparsely visible waves (sh_stream_wave<true>)
+enum { SH_INLINE = 0, SH_STREAM = 1, SH_DEFER = 2, SH_STREAM_SPARSE = 3 };
 // BINMODE: how the per-tile instance counts are formed.
 //   BIN_WALK   every (Gaussian, tile) instance bumps its tile's bin (walk over the wave's concatenated rectangles)
 //   BIN_TIGHT  the same walk, instances that provably touch no pixel of their tile dropped
@@ -308,9 +345,9 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered,
                       uint32_t* __restrict__ row_matrix, int band_w, int nbands, float* __restrict__ sh_dir,
-                      uint32_t* __restrict__ heavy_waves)
+                      uint32_t* __restrict__ heavy_waves, uint32_t* __restrict__ sh_layout)
 {
-    constexpr bool SH16 = SHMODE == SH_STREAM;
+    constexpr bool SH16 = SHMODE == SH_STREAM || SHMODE == SH_STREAM_SPARSE;
     constexpr bool TIGHT = BINMODE == BIN_TIGHT, CELLS = BINMODE == BIN_CELLS;
     static_assert(!CELLS || LDS_BINS, "the cell-ordered scatter needs the LDS bins");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_bins[];
@@ -333,7 +370,10 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     const int nbins = T + ncells;
     if (LDS_BINS)
         for (int t = threadIdx.x; t < nbins; t += FRG_BIN_THREADS) lds_bins[t] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) heavy_waves[0] = 0;   // (filled where point_offsets is finished)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        heavy_waves[0] = 0;   // (filled where point_offsets is finished)
+        if (SHMODE != SH_DEFER) *sh_layout = SHMODE == SH_STREAM_SPARSE ? 1u : 0u;    // (SH_DEFER: sh_color_kernel says)
+    }
     // the chunk totals of this workgroup's chunks are accumulated with atomics below
     for (int c = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; c < nchunks; c += FRG_BIN_THREADS * (int)gridDim.x) block_sums[c] = 0;
     __threadfence_block();
@@ -393,7 +433,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
                 const int idx0 = c * FRG_BIN_THREADS + wave * 64;
                 // the direction of every Gaussian of the wave waits in the (still empty) colour slot of its record
-                const float4 col = sh_stream_wave(vp.D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0),
+                const float4 col = sh_stream_wave<SHMODE == SH_STREAM_SPARSE>(vp.D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0),
                                                   touched != 0, dir, sh_lds + wave * (PRE_SUB * PRE_ROW_F4),
                                                   rec_lds + (wave * 64) * FRG_REC + 2, FRG_REC, sh_dir + (size_t)idx0 * 9);
                 (void)lane;
@@ -446,12 +486,13 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 // One wave = 64 consecutive Gaussians; nothing here depends on the binning, so the kernel runs on a side
 // stream beside scan / scatter / sort and only the blend joins it.
 #define SHC_THREADS 256
-template <bool SH16>
+template <bool SH16, bool SPARSE>
 __global__ void __launch_bounds__(SHC_THREADS)
 sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const float* __restrict__ means3D,
                 const int* __restrict__ radii, const float* __restrict__ shs, float4* __restrict__ rgb_clamped,
-                float* __restrict__ sh_dir)
+                float* __restrict__ sh_dir, uint32_t* __restrict__ sh_layout)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sh_layout = (SH16 && SPARSE) ? 1u : 0u;
     __shared__ float4 sh_lds[SH16 ? (SHC_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ float4 dir_lds[SH16 ? SHC_THREADS : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -468,7 +509,7 @@ sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const fl
         dir = make_float3(dx / len, dy / len, dz / len);
     }
     if (SH16) {
-        const float4 col = sh_stream_wave(D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0), touched, dir,
+        const float4 col = sh_stream_wave<SPARSE>(D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0), touched, dir,
                                           sh_lds + wave * (PRE_SUB * PRE_ROW_F4), dir_lds + wave * 64, 1, sh_dir + (size_t)idx0 * 9);
         if (touched) rgb_clamped[FRG_REC * idx] = col;
     } else if (touched) {
@@ -900,7 +941,7 @@ scatter_rows_kernel(int T, int gx, int gy, const uint4* __restrict__ row_records
     __shared__ int4 emit_info[FRG_BIN_THREADS];
     __shared__ int row_lo, row_hi;
     // (the list of heavy waves was finished by reorder_kernel)
-    if (mail && blockIdx.x == 0 && threadIdx.x == 0) { mail->heavy = heavy_waves[0]; mailbox_post(&mail->seq_h, seq); }
+    if (mail && blockIdx.x == 0 && threadIdx.x == 0) { mail->heavy = heavy_waves[0]; mail->visible = counters->num_visible; mailbox_post(&mail->seq_h, seq); }
     // the binning buffer is too small for this frame (deferred-counters forward): every tile list was left empty
     if (counters->overflow != 0) return;
     // Every workgroup takes one contiguous share of the records, a multiple of 1024 (a few cells: some dozens of
@@ -1032,7 +1073,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
-                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves);
+                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves, g.sh_layout);
     return hipGetLastError();
 }
 
@@ -1049,7 +1090,8 @@ hipError_t launch_preprocess_fwd(int P, const ViewParams& vp, const FwdInputs& i
 #define FRG_PRE(L, S) (vp.tight ? launch_pre_variant<L, S, BIN_TIGHT>(P, vp, in, radii, g, img, prefiltered, s) \
                                 : launch_pre_variant<L, S, BIN_WALK>(P, vp, in, radii, g, img, prefiltered, s))
 #define FRG_PRE_CELLS(S) launch_pre_variant<true, S, BIN_CELLS>(P, vp, in, radii, g, img, prefiltered, s)
-    if (cell_order(img, vp)) return mode == SH_DEFER ? FRG_PRE_CELLS(SH_DEFER) : mode == SH_STREAM ? FRG_PRE_CELLS(SH_STREAM) : FRG_PRE_CELLS(SH_INLINE);
+    // (the instance for sparsely visible views only with the cell-ordered scatter, the default path)
+    if (cell_order(img, vp)) return mode == SH_DEFER ? FRG_PRE_CELLS(SH_DEFER) : mode == SH_STREAM ? (vp.sparse_sh ? FRG_PRE_CELLS(SH_STREAM_SPARSE) : FRG_PRE_CELLS(SH_STREAM)) : FRG_PRE_CELLS(SH_INLINE);
     if (img.lds_bins) return mode == SH_DEFER ? FRG_PRE(true, SH_DEFER) : mode == SH_STREAM ? FRG_PRE(true, SH_STREAM) : FRG_PRE(true, SH_INLINE);
     return mode == SH_DEFER ? FRG_PRE(false, SH_DEFER) : mode == SH_STREAM ? FRG_PRE(false, SH_STREAM) : FRG_PRE(false, SH_INLINE);
 #undef FRG_PRE
@@ -1060,10 +1102,13 @@ hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, con
 {
     if (!in.shs || P <= 0) return hipSuccess;
     const dim3 grid((P + SHC_THREADS - 1) / SHC_THREADS), block(SHC_THREADS);
-    if (sh_streamable(in, vp))
-        hipLaunchKernelGGL((sh_color_kernel<true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir);
-    else
-        hipLaunchKernelGGL((sh_color_kernel<false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir);
+    if (sh_streamable(in, vp)) {
+        if (vp.sparse_sh)
+            hipLaunchKernelGGL((sh_color_kernel<true, true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout);
+        else
+            hipLaunchKernelGGL((sh_color_kernel<true, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout);
+    } else
+        hipLaunchKernelGGL((sh_color_kernel<false, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout);
     return hipGetLastError();
 }
 

@@ -60,7 +60,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
-                      const float* __restrict__ sh_dir, int tile_moments, const uint32_t* __restrict__ heavy)
+                      const float* __restrict__ sh_dir, int tile_moments, const uint32_t* __restrict__ heavy,
+                      const uint32_t* __restrict__ sh_layout)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,8 +95,9 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // d(colour)/d(direction) of this Gaussian, left by the forward's SH pass (GeomState::sh_dir): requested now, used
     // after the slot reduction.  The backward does not read the 192-byte SH rows at all.
     float shd[9];
+    const int sh_row = idx0 + sh_slot_of(__ballot(visible), lane, *sh_layout != 0u);     // (frg_common.h: by lane or by rank among the wave's visible Gaussians)
 #pragma unroll
-    for (int k = 0; k < 9; k++) shd[k] = (visible && shs) ? sh_dir[(size_t)idx * 9 + k] : 0.0f;
+    for (int k = 0; k < 9; k++) shd[k] = (visible && shs) ? sh_dir[(size_t)sh_row * 9 + k] : 0.0f;
     // ---- 1. slot reduction ------------------------------------------------------
     const uint32_t incl = valid ? point_offsets[idx] : 0u;
     const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
@@ -559,7 +561,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, g.heavy_waves)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, g.heavy_waves, g.sh_layout)
     // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }

@@ -243,6 +243,10 @@ int frg_backward_ex(const frg_backward_args* args);
  * known yet), ~21 instead of 12 bytes per instance.  Not used with `debug`.  Same counters, same results.
  * "clear_image_state" (default 0): 1 = clear the image chunk's per-tile cursors and counters with a memset in front of
  * every forward even where the kernels initialise them on their way (images whose tiles fit the LDS bins).
+ * "sparse_sh" (default 1): when a view is expected to see only a part of the model -- an occlusion mask (keep_mask) is
+ * given, or the previous forward of the calling thread saw less than three quarters of a model of the same size -- the SH
+ * pass streams the coefficient rows of the VISIBLE Gaussians only (0: always the rows of every 16-Gaussian block with a
+ * visible one).  Same arithmetic per Gaussian: every output bit-identical.
  * "fwd_prefetch" (default 1): the forward blend requests the next 64 list entries' records while it processes the
  * current ones (0: plain loop).  Scheduling only, outputs bit-identical.
  * "bwd_heavy_first" (default 1): when the forward posted that some 64-Gaussian waves own thousands of backward slots,

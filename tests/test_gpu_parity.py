@@ -45,6 +45,7 @@ def _reset_options():
     yield
     _lib.set_option("bwd_quad_tiles", -1)
     _lib.set_option("counter_mailbox", 1)
+    _lib.set_option("sparse_sh", 1)
     _lib.set_option("exact_blend", 0)
     _lib.set_option("profile", 0)
     _lib.set_option("tight_binning", 0)
@@ -722,6 +723,40 @@ def test_counter_mailbox_and_copy_read_back_agree(gpu_device, ops):
         ops.rasterize_gaussians(bg.to(dev), sc.means3D - torch.tensor([0.0, 0.0, 50.0], device=dev), e, sc.opacities, sc.scales, sc.rotations,
                                 1.0, e, cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, cam.image_height,
                                 cam.image_width, sc.shs, sc.sh_degree, cam.campos.to(dev), True, False)
+
+
+def test_sh_pass_over_the_visible_gaussians_only(gpu_device, ops):
+    """A view that sees a part of the model (here: half of it outside the image; with an occlusion mask:
+    test_gpu_mesh.py) runs the SH pass over the visible Gaussians of every wave only, their derivative rows stored by
+    rank -- chosen from what the previous forward of the thread saw, so the first forward of such a view takes the
+    plain pass and the second the sparse one: image, radii and every gradient of the two are identical bit for bit,
+    and identical to option sparse_sh = 0."""
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("c3", 0, P=300_000)
+    # the ball moved sideways by the half-width of the view at its distance: about half of it leaves the image
+    moved = scenes.Scene(scene.means3D + torch.tensor([2.4, 0.0, 0.0]), scene.scales, scene.rotations, scene.opacities, scene.shs,
+                         scene.sh_degree)
+    def run(sc):
+        out, args = Hh.run_ours_native(sc, cam, bg, dev, ops=ops)
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 13)
+        grads = ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(dev)))
+        return out[0], out[1].clone(), out[2].clone(), [g.clone() for g in grads]
+    _lib.set_option("sparse_sh", 0)
+    want = run(moved)
+    vis = float((want[2] > 0).float().mean())
+    assert 0.1 < vis < 0.7, vis
+    _lib.set_option("sparse_sh", 1)
+    run(scene)                       # a view that sees (nearly) everything: the next one starts with the plain pass
+    for i in range(3):               # first: plain pass; then the pass over the visible ones
+        got = run(moved)
+        assert got[0] == want[0] and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), i
+        assert all(torch.equal(a, b) for a, b in zip(got[3], want[3])), i
+    # and back: a fully visible view after sparse ones
+    full_want = None
+    for i in range(2):
+        got = run(scene)
+        full_want = full_want or got
+        assert all(torch.equal(a, b) for a, b in zip(got[3], full_want[3]))
 
 
 def test_radii_may_be_null_like_the_reference(gpu_device):
