@@ -651,23 +651,32 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
         }
         __syncthreads();
     }
-    // every thread owns `per` consecutive tiles
-    const int per = (T + NT - 1) / NT, lo = tid * per, hi = min(T, lo + per);
+    // Wave w owns the tiles [w * span, (w + 1) * span), span a multiple of 64, LANE = TILE: the totals are read and
+    // ranges / tile_count stored 64 consecutive tiles at a time, and a tile's start is one DPP scan away (every thread
+    // owning ~7 consecutive tiles walked two dependent per-thread loops: scan stage 0.061 -> 0.057 ms at C3).
+    constexpr int NW = NT / 64;
+    const int span = ((T + NW - 1) / NW + 63) / 64 * 64;
+    const int w_lo = min(T, wave * span), w_hi = min(T, w_lo + span);
     uint32_t sum = 0, local_max = 0;
 #pragma unroll 1
-    for (int i = lo; i < hi; i++) { const uint32_t c = tot[i]; sum += c; local_max = max(local_max, c); }
-    const uint32_t inc = wave_incl_scan(sum, lane);
-    if (lane == 63) sh.wtot[wave] = inc;
+    for (int t = w_lo + lane; t < w_hi; t += 64) { const uint32_t c = tot[t]; sum += c; local_max = max(local_max, c); }
+    const uint32_t wsum = wave_incl_scan_dpp(sum);
+    if (lane == 63) sh.wtot[wave] = wsum;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) local_max = max(local_max, (uint32_t)__shfl_xor((int)local_max, d, 64));
     if (lane == 0) atomicMax(&sh.maxc, local_max);
     __syncthreads();
-    uint32_t run = inc - sum;
-    for (int w = 0; w < wave; w++) run += sh.wtot[w];
+    uint32_t carry = 0;
+    for (int w = 0; w < wave; w++) carry += sh.wtot[w];
 #pragma unroll 1
-    for (int i = lo; i < hi; i++) {
-        const uint32_t c = tot[i], excl = run;
-        run += c;
+    for (int t0 = w_lo; t0 < w_hi; t0 += 64) {          // wave-uniform trip count
+        const int i = t0 + lane;
+        const bool mine = i < w_hi;
+        const uint32_t c = mine ? tot[i] : 0u;
+        const uint32_t inc = wave_incl_scan_dpp(c);
+        const uint32_t excl = carry + inc - c;
+        carry += (uint32_t)__shfl((int)inc, 63, 64);
+        if (!mine) continue;
         if (USE_SEGS || ovf) tile_count[i] = c;
         ranges[i] = c ? make_uint2(excl, excl + c) : make_uint2(0u, 0u);
         if (c) atomicAdd(&sh.sub[sort_subclass_of(c)], 1u);
