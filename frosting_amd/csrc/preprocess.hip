@@ -203,6 +203,14 @@ __device__ __forceinline__ void wave_sync_lds()
 //   dirs[k * dir_stride]  a float4 per Gaussian k of the wave in LDS, written here: unit direction + visible flag
 //   sh_dir_out            global, this wave's first Gaussian: [64][9]
 // Returns this lane's own colour record (only meaningful for a visible Gaussian).
+// 16-byte load with the non-temporal hint (a stream that is read once)
+__device__ __forceinline__ float4 load_stream(const float4* p)
+{
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // float e of a sub-batch's [16][9] derivative block -> float index in the wave's row buffer, skipping every 13th float4
 // (the rows' pads, which hold the colour sums at that time)
 __device__ __forceinline__ int sh_dd_slot(int e) { const int q = e >> 2; return ((q + q / 12) << 2) + (e & 3); }
@@ -231,8 +239,9 @@ __device__ __forceinline__ float4 sh_pass(int deg, const float4* __restrict__ sr
 #pragma unroll
         for (int k = 0; k < PRE_SUB * 12 / 64; k++) {
             const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12, r = h * PRE_SUB + gl;
-            if (DENSE) pre[k] = r < nvalid ? src[(size_t)h * PRE_SUB * 12 + f] : make_float4(0.f, 0.f, 0.f, 0.f);
-            else pre[k] = r < nvis ? src[(uint32_t)(__float_as_int(dirs[r * dir_stride].w) * 12 + j)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (read once per view, 576 MB at C3: non-temporal, so that the stream does not push the records and pairs out of the caches)
+            if (DENSE) pre[k] = r < nvalid ? load_stream(src + (size_t)h * PRE_SUB * 12 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            else pre[k] = r < nvis ? load_stream(src + (uint32_t)(__float_as_int(dirs[r * dir_stride].w) * 12 + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     int h = __builtin_ctz(need);

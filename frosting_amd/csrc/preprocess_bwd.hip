@@ -25,6 +25,7 @@
 
 namespace frg {
 
+
 #define BWD_THREADS 256
 #define BWD_SUB 16                       // Gaussians per SH transpose step
 #define BWD_ROW_F4 13                    // 12 float4 of SH + 1 pad (odd stride: conflict-free b128)
@@ -437,7 +438,12 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
                 for (int k = 0; k < BWD_SUB * 12 / 64; k++) {
                     const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                    if (h * BWD_SUB + gl < nvalid) dst[(size_t)h * BWD_SUB * 12 + f] = shbuf[gl * BWD_ROW_F4 + j];
+                    if (h * BWD_SUB + gl < nvalid) {
+                        // written once, read by nobody in this op: past the L2 (576 MB per view that would push the slots out)
+                        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                        const float4 v = shbuf[gl * BWD_ROW_F4 + j];
+                        __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(dst + (size_t)h * BWD_SUB * 12 + f));
+                    }
                 }
                 wave_fence();
             }

@@ -14,6 +14,14 @@
 
 namespace frg {
 
+// 8-byte load with the non-temporal hint: the scatter's pairs are dead once their tile is sorted
+__device__ __forceinline__ uint2 load_pair_stream(const uint2* p)
+{
+    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
+    return make_uint2(v.x, v.y);
+}
+
 // Lanes of the wave holding the same 8-bit digit as this lane (invalid lanes excluded).  Per bit: the lane's bit
 // sign-extended to a mask sb (v_bfe_i32), one ballot, and peers &= ~(ballot ^ sb) per 32-bit half (v_xnor + v_and):
 // six vector instructions.  (`peers &= bit ? m : ~m` on 64-bit values compiled to nine: the ranking is the sort's
@@ -281,7 +289,7 @@ sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_list, const uint32_t* __
 #pragma unroll
         for (int it = 0; it < SORT_ITEMS; it++) {
             const int i = begin + it * 64 + lane;
-            e[it] = i < end ? pairs[rg.x + i] : make_uint2(0u, 0u);
+            e[it] = i < end ? load_pair_stream(pairs + rg.x + i) : make_uint2(0u, 0u);   // (read once: non-temporal)
         }
         sort_block_lds<NWAVES, SORT_ITEMS>(e, n, begin, end, buf, whist, scratch);   // (opens with a barrier: the previous tile's LDS contents are dead)
         for (int i = tid; i < n; i += NT) point_list[rg.x + i] = buf[i].y;
