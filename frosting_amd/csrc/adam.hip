@@ -18,6 +18,14 @@
 
 namespace frg {
 
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float* p)
+{
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(float* p, float4 v) { __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p)); }
+
 __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, float step_size, float w1,
                                           float beta2, float omb2, float inv_bc2_sqrt, float eps)
 {
@@ -55,10 +63,11 @@ adam_step_kernel(long long n, float* __restrict__ params, const float* __restric
     auto step_at = [&](int k, int phase) { return (seg.period[k] > 0 && phase < seg.head[k]) ? seg.head_step_size[k] : seg.step_size[k]; };
     auto step_of = [&](long long i) { const int k = seg_of(i); return step_at(k, phase_of(i, k)); };
     if (base + 4 <= n) {
-        float4 p = *reinterpret_cast<const float4*>(params + base);
-        float4 g = *reinterpret_cast<const float4*>(grads + base);
-        float4 m = *reinterpret_cast<const float4*>(exp_avg + base);
-        float4 v = *reinterpret_cast<const float4*>(exp_avg_sq + base);
+        // four streams in, three out, each touched once per step: non-temporal (nothing of them is worth a cache line)
+        float4 p = ld_stream(params + base);
+        float4 g = ld_stream(grads + base);
+        float4 m = ld_stream(exp_avg + base);
+        float4 v = ld_stream(exp_avg_sq + base);
         g.x *= grad_scale; g.y *= grad_scale; g.z *= grad_scale; g.w *= grad_scale;
         // a group of four may straddle a segment boundary: per-element step size
         // a group of four may straddle a segment boundary or a period: one segment search and one
@@ -79,9 +88,9 @@ adam_step_kernel(long long n, float* __restrict__ params, const float* __restric
         adam_one(p.y, g.y, m.y, v.y, s1, w1, beta2, omb2, inv_bc2_sqrt, eps);
         adam_one(p.z, g.z, m.z, v.z, s2, w1, beta2, omb2, inv_bc2_sqrt, eps);
         adam_one(p.w, g.w, m.w, v.w, s3, w1, beta2, omb2, inv_bc2_sqrt, eps);
-        *reinterpret_cast<float4*>(params + base) = p;
-        *reinterpret_cast<float4*>(exp_avg + base) = m;
-        *reinterpret_cast<float4*>(exp_avg_sq + base) = v;
+        st_stream(params + base, p);
+        st_stream(exp_avg + base, m);
+        st_stream(exp_avg_sq + base, v);
     } else {
         for (long long i = base; i < n; i++) {
             float p = params[i], m = exp_avg[i], v = exp_avg_sq[i];
