@@ -115,7 +115,11 @@ sh_grad_from_views_kernel(int P, int D, int M, int n_views, const float* __restr
 #pragma unroll
             for (int k = 0; k < VX_SUB * 12 / 64; k++) {
                 const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-                if (h * VX_SUB + gl < nvalid) dst[(size_t)h * VX_SUB * 12 + f] = shbuf[gl * VX_ROW_F4 + j];
+                if (h * VX_SUB + gl < nvalid) {     // (576 MB written once: non-temporal, like the per-view rows of preprocess_bwd.hip)
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    const float4 v = shbuf[gl * VX_ROW_F4 + j];
+                    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(dst + (size_t)h * VX_SUB * 12 + f));
+                }
             }
             vx_wave_fence();
         }
