@@ -291,8 +291,11 @@ __device__ __forceinline__ float4 sh_pass(int deg, const float4* __restrict__ sr
         wave_sync_lds();
         // sh_dir holds the rows BY SLOT inside the wave's block of 64 (the per-Gaussian backward derives the slot from the
         // same visibility ballot); empty slots carry whatever the LDS held: never read
-        if (lane < PRE_SUB * 9 / 4)
-            reinterpret_cast<float4*>(sh_dir_out + (size_t)h * PRE_SUB * 9)[lane] = shbuf[lane + lane / 12];
+        if (lane < PRE_SUB * 9 / 4) {     // (read again only by the per-Gaussian backward, a millisecond and gigabytes later)
+            typedef float nt_f4 __attribute__((ext_vector_type(4)));
+            const float4 v = shbuf[lane + lane / 12];
+            __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(sh_dir_out + (size_t)h * PRE_SUB * 9) + lane);
+        }
         if (touched && (my_slot / PRE_SUB) == h) {
             const float4 c = shbuf[(my_slot % PRE_SUB) * PRE_ROW_F4 + 12];
             ShAccum sa;
