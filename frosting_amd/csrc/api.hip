@@ -176,7 +176,7 @@ struct HostMail {
     // the previous forward of this thread, on a model of the same size, saw less than three quarters of it
     bool sparse_view(int P) const
     {
-        if (!host || P != last_P || __atomic_load_n(&host->seq_h, __ATOMIC_ACQUIRE) != last_seq) return false;
+        if (!host || P != last_P || (uint32_t)(__atomic_load_n(&host->heavy_post, __ATOMIC_ACQUIRE) >> 32) != last_seq) return false;
         return (uint64_t)host->visible * 4u < (uint64_t)P * 3u;
     }
     bool failed = false;         // a post never arrived although the stream had drained: stay with the copy + synchronise
@@ -224,15 +224,13 @@ int heavy_waves_posted(const void* geom)
     // it, the host nothing better to do), but not for a scatter stuck behind other work.
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; spin++) {
-        const uint32_t cur = __atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE);
-        if (cur == n.seq) break;
+        const unsigned long long post = __atomic_load_n(&n.mail->heavy_post, __ATOMIC_ACQUIRE);    // (sequence << 32) | count, one word
+        const uint32_t cur = (uint32_t)(post >> 32);
+        if (cur == n.seq) return (int)((uint32_t)post > 0x7fffffffu ? 0x7fffffffu : (uint32_t)post);
         if ((int32_t)(cur - n.seq) > 0) return -1;      // the mailbox already carries a later forward's post
         if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return -1;
         __builtin_ia32_pause();
     }
-    const uint32_t h = __atomic_load_n(&n.mail->heavy, __ATOMIC_RELAXED);
-    if (__atomic_load_n(&n.mail->seq_h, __ATOMIC_ACQUIRE) != n.seq) return -1;
-    return (int)(h > 0x7fffffffu ? 0x7fffffffu : h);
 }
 
 // Spin until the kernel's post arrives.  false: the stream failed, or it drained without the post becoming visible.

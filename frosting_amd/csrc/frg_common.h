@@ -124,7 +124,10 @@ struct Mailbox {
     // third post, by the scatter (not waited for): how many 64-Gaussian waves own more than FRG_BWD_HEAVY_SLOTS
     // backward slots -- a backward that finds its forward's post here and reads 0 skips the 16-wave launch of the
     // per-Gaussian backward and its fork / join (~11 us per step at C3)
-    uint32_t seq_h, heavy, visible, pad2[13];   // visible: Counters::num_visible (the next forward's sparse_sh hint)
+    // ONE 8-byte word, stored at once -- (sequence number << 32) | heavy waves: the scatters of two forwards that a
+    // thread put on different streams may post in any order, and a torn pair would hand one forward's count to the other
+    unsigned long long heavy_post;
+    uint32_t visible, pad2[13];                 // visible: Counters::num_visible (the next forward's sparse_sh hint only)
 };
 __device__ __forceinline__ void mailbox_post(uint32_t* flag, uint32_t seq)
 {

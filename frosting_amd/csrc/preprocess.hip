@@ -962,7 +962,11 @@ scatter_rows_kernel(int T, int gx, int gy, const uint4* __restrict__ row_records
     __shared__ int4 emit_info[FRG_BIN_THREADS];
     __shared__ int row_lo, row_hi;
     // (the list of heavy waves was finished by reorder_kernel)
-    if (mail && blockIdx.x == 0 && threadIdx.x == 0) { mail->heavy = heavy_waves[0]; mail->visible = counters->num_visible; mailbox_post(&mail->seq_h, seq); }
+    if (mail && blockIdx.x == 0 && threadIdx.x == 0) {
+        mail->visible = counters->num_visible;
+        __threadfence_system();
+        __hip_atomic_store(&mail->heavy_post, ((unsigned long long)seq << 32) | heavy_waves[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // the binning buffer is too small for this frame (deferred-counters forward): every tile list was left empty
     if (counters->overflow != 0) return;
     // Every workgroup takes one contiguous share of the records, a multiple of 1024 (a few cells: some dozens of
