@@ -45,6 +45,10 @@ def parse_args():
                     help="untimed steps before the W warm-up steps: the process spends seconds on the host building the "
                          "scene, the idle GPU drops its clocks, and a short warm-up can end before they are back up")
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "mini"])
+    ap.add_argument("--views", type=int, default=8,
+                    help="cameras of the 8-camera ring the timed loop cycles through (step i of rank r renders view (r + i) %% views "
+                         "-- a trainer draws a new camera per step: refine.py:464-571); 1 = one fixed camera (round 1-3's loop, "
+                         "still timed after the timed region as 'fixed_view')")
     ap.add_argument("--points", type=int, default=0, help="override the number of Gaussians (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -118,30 +122,44 @@ def stage_bytes(P, V, R, N, T):
 
 
 def pmc_traffic(stage: str, cfg_name: str, P: int):
-    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes of this very
-    workload (profiles/r0N_pmc_traffic.json, newest round first; counters cannot be read from inside
-    the process).  None when the run is not the profiled configuration."""
-    from frosting_amd import scenes
+    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes of this very workload
+    (profiles/r0N_pmc_traffic.json, newest round first; counters cannot be read from inside the process).
+    None when the run is not the profiled configuration; the string "stale" when the newest committed passes were taken
+    with other kernels than the ones running now (their file carries the sha256 of the kernel sources it was measured
+    with, tools/collect_traffic.py; a file without one counts as stale)."""
+    from frosting_amd import _lib, scenes
     if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"]:
         return None
-    for rnd in ("r03", "r02", "r01"):
+    mine = _lib.build_fingerprint()["kernel_sources_sha256"]
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         try:
-            per = json.load(open(path))["per_launch"]
-            if stage == "*":      # the whole op: every stage of one view
-                return {"bytes": sum(v["hbm_bytes_corrected"] for v in per.values()), "source": f"profiles/{rnd}_pmc_traffic.json"}
-            return per[stage]["hbm_bytes_corrected"]
+            doc = json.load(open(path))
         except Exception:
             continue
+        if doc.get("build", {}).get("kernel_sources_sha256") != mine:
+            return "stale"
+        per = doc["per_launch"]
+        if stage == "*":      # the whole op: every stage of one view
+            return {"bytes": sum(v["hbm_bytes_corrected"] for v in per.values()), "source": f"profiles/{rnd}_pmc_traffic.json"}
+        return per[stage]["hbm_bytes_corrected"]
     return None
 
 
-def cpu_baseline(cfg_name: str, P: int, backward: bool = True):
-    """C restatement of the reference (oracle/gs_oracle.c, OpenMP) timed on the host
-    cores for ONE view of the same workload -- reported, not a target."""
+def cpu_baseline(cfg_name: str, P: int, backward: bool = True, torch_budget_s: float = 20.0):
+    """Two CPU baselines on the host cores for ONE view of the same workload -- reported, not a target:
+      * `torch` (the headline entry, what BASELINE.json's north_star names): the alpha blend -- forward, and with
+        `backward` its autograd gradients -- in PURE PyTorch on the CPU (oracle/torch_blend.py), on a bounded sample of
+        the view's tiles (every k-th tile, k chosen so that the sample takes about `torch_budget_s` seconds), scaled to
+        the whole image.  It times the blend stage ALONE from the C port's 2-D state (no projection, no SH, no binning,
+        no sort): an upper bound on what a pure-PyTorch rasterizer would reach;
+      * `port`: the whole op (preprocess -> sort -> blend -> backward) as the OpenMP C restatement of the reference
+        algorithm (oracle/gs_oracle.c), one full view."""
     import numpy as np
+    import torch
     from frosting_amd import scenes
     from oracle import gs_oracle as G
+    from oracle import torch_blend as TB
     G.build()
     scene, cam, bg = scenes.config_scene(cfg_name, 0, P=P)
     kw = dict(means3D=scene.means3D.numpy(), opacities=scene.opacities.numpy(), viewmatrix=cam.viewmatrix.numpy(),
@@ -150,13 +168,39 @@ def cpu_baseline(cfg_name: str, P: int, backward: bool = True):
               scales=scene.scales.numpy(), rotations=scene.rotations.numpy(), sh_degree=scene.sh_degree)
     t0 = time.perf_counter()
     st = G.forward(**kw)
+    gpix = (np.sign(st["out_color"] - 0.5) / st["out_color"].size).astype(np.float32)
     if backward:
-        gpix = (np.sign(st["out_color"] - 0.5) / st["out_color"].size).astype(np.float32)
         G.backward(st, gpix)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "views/s", "cores": G.num_threads(), "kind": "port",
-            "sample": f"1 view {'fwd+bwd' if backward else 'forward'} of {cfg_name} at P={P} (R={st['num_rendered']}), {dt:.2f} s "
-                      f"wall, OpenMP C port of the reference algorithm (oracle/gs_oracle.c)"}
+    what = "fwd+bwd" if backward else "forward"
+    port = {"value": 1.0 / dt, "unit": "views/s", "cores": G.num_threads(), "kind": "port",
+            "sample": f"1 view {what} of {cfg_name} at P={P} (R={st['num_rendered']}), {dt:.2f} s "
+                      f"wall, OpenMP C port of the reference algorithm (oracle/gs_oracle.c), whole op"}
+    try:
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        W, H = cam.image_width, cam.image_height
+        T = st["ranges"].shape[0]
+        args_t = (t(st["means2D"]), t(st["conic_opacity"]), t(st["rgb"]), t(st["ranges"].astype(np.int64)),
+                  t(st["point_list"].astype(np.int64)), bg, W, H)
+        g_t = t(gpix) if backward else None
+        probe = list(range(T // 2, T, max(1, T // 16)))[:8]           # a few tiles from the middle rows: the rate
+        r = TB.render(*args_t, tiles=probe, dL_dimage=g_t)
+        per_tile = r["seconds"] / len(probe)
+        stride = max(1, int(np.ceil(per_tile * T / torch_budget_s)))
+        tiles = list(range(0, T, stride))
+        r = TB.render(*args_t, tiles=tiles, dL_dimage=g_t)
+        frac = float(sum(int(st["ranges"][i, 1]) - int(st["ranges"][i, 0]) for i in tiles)) / max(1, st["num_rendered"])
+        est = r["seconds"] / max(frac, 1e-9)                          # scaled by the share of the list entries sampled
+        out = {"value": 1.0 / est, "unit": "views/s", "cores": torch.get_num_threads(), "kind": "torch",
+               "sample": f"alpha blend {what} ALONE (no projection / SH / binning / sort) of 1 view of {cfg_name} at P={P}: every "
+                         f"{stride}-th of the {T} tiles ({len(tiles)} tiles, {100 * frac:.1f} % of the {st['num_rendered']} list entries) "
+                         f"in {r['seconds']:.1f} s, scaled to the whole image; pure PyTorch float32 on the CPU with autograd "
+                         f"(oracle/torch_blend.py), {torch.get_num_threads()} torch threads",
+               "port": port}
+        return out
+    except Exception as ex:       # the C port alone is still a baseline
+        port["torch_error"] = repr(ex)
+        return port
 
 
 def reference_on_this_gpu(scene_d, cam_d, bg_d, gpix, backward: bool, iters: int = 5):
@@ -294,11 +338,14 @@ def main():
     cfg = scenes.CONFIGS[args.config]
     P = args.points or cfg["P"]
     shell = None
+    n_views = max(1, min(8, args.views))
+    view_ids = [(rank + k) % 8 for k in range(n_views)]       # this rank's cameras, in the order it renders them
     if cfg.get("kind") == "shell":
-        shell, cam, bg = scenes.config_shell_scene(args.config, rank % 8, P=P)
+        shell, cam, bg = scenes.config_shell_scene(args.config, view_ids[0], P=P)
         scene = shell.scene
     else:
-        scene, cam, bg = scenes.config_scene(args.config, rank % 8, P=P)
+        scene, cam, bg = scenes.config_scene(args.config, view_ids[0], P=P)
+    cams = [cam] + [scenes.ring_camera(v, cfg["width"], cfg["height"], cfg["fx"], cfg["fy"]) for v in view_ids[1:]]
     do_backward = args.config != "c2"
     for kv in args.option:
         k, v = kv.split("=")
@@ -312,23 +359,34 @@ def main():
                                  factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters,
                                  reduce=args.reduce)
     exchanging = dist is not None and do_backward
-    cam_d = cam.to(dev)
+    cams_d = [c.to(dev) for c in cams]
+    cam_d = cams_d[0]
     bg_d = bg.to(dev)
     mesh_ctx = M.RasterizeGLContext() if shell is not None else None
     if shell is not None:
         verts_d, faces_d, cell_d = shell.verts.to(dev), shell.faces.to(dev), shell.cell.to(dev)
 
-    def cull_mask():
+    def cull_mask(c_d=None):
         """C4: triangle occlusion raster of the shell's base mesh -> visible faces -> per-Gaussian keep flag
         (frosting_model.py:1524-1539,1564-1586), every step (the per-frame inference form)."""
         if shell is None:
             return None
-        fm = M.visible_face_mask(verts_d, faces_d, cam_d.projmatrix, cam.image_height, cam.image_width, mesh_ctx)
+        c_d = c_d or cam_d
+        fm = M.visible_face_mask(verts_d, faces_d, c_d.projmatrix, cam.image_height, cam.image_width, mesh_ctx)
         return M.occlusion_mask_from_face_mask(cell_d, fm)
 
+    # one pass over this rank's cameras: the fixed loss gradient dL/dimage of every view, and what each view holds
+    gpixs, view_V, view_R = [], [], []
+    for k, c_d in enumerate(cams_d):
+        image, radii_k = vpr.forward(c_d, bg_d, keep_mask=cull_mask(c_d))
+        vpr.finish()
+        g_k, _ = scenes.l1_target_grad(image.cpu(), 20241022 + view_ids[k])
+        gpixs.append(g_k.to(dev))
+        view_V.append(int((radii_k > 0).sum()))
+        view_R.append(int(vpr.true_num_rendered))
     image, radii = vpr.forward(cam_d, bg_d, keep_mask=cull_mask())
-    gpix, _ = scenes.l1_target_grad(image.cpu(), 20241022 + rank)
-    gpix = gpix.to(dev)
+    vpr.finish()
+    gpix = gpixs[0]
 
     # Exchange schedule (N > 1).  Default, IN-STEP: the collectives are enqueued right behind the backward and are all
     # complete when the step ends -- what a training loop needs that updates the parameters before it renders the next
@@ -337,6 +395,7 @@ def main():
     # part.  --stale-overlap: round 2's software pipeline (the collectives of step k are waited for in step k+2 and
     # overlap the next render; two buffers) -- valid only for one-step-stale gradients.
     counter = [0]
+    cycle = [True]            # False: the fixed-camera loop of rounds 1-3 (timed after the timed region, field 'fixed_view')
     exchange_on = [exchanging]
     schedule = ["stale" if args.stale_overlap else "sync" if args.sync_exchange else "in-step"]
     dstats = DensificationStats(P, dev, dist.group.WORLD) if (dist is not None and args.densify_stats) else None
@@ -345,8 +404,10 @@ def main():
         ex = exchange_on[0]
         stale = ex and schedule[0] == "stale"
         slot = counter[0] % 2 if stale else 0
+        k = counter[0] % n_views if cycle[0] else 0      # this step's camera
+        c_d, g_d = cams_d[k], gpixs[k]
         counter[0] += 1
-        vpr.forward(cam_d, bg_d, keep_mask=cull_mask())
+        vpr.forward(c_d, bg_d, keep_mask=cull_mask(c_d))
         if not do_backward:
             vpr.finish()
             return
@@ -354,10 +415,10 @@ def main():
             # the exchange launched two steps ago on this buffer: its collectives are waited for here, its
             # SH rebuild runs on a side stream under the backward below
             vpr.prefetch_exchange(slot)
-        vpr.backward(gpix, slot)             # writes straight into the flat gradient buffer
+        vpr.backward(g_d, slot)              # writes straight into the flat gradient buffer
         if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
-            vpr.forward(cam_d, bg_d, deferred=False, keep_mask=cull_mask())
-            vpr.backward(gpix, slot)
+            vpr.forward(c_d, bg_d, deferred=False, keep_mask=cull_mask(c_d))
+            vpr.backward(g_d, slot)
         if stale:
             vpr.wait_exchange(slot)          # join the rebuild before this buffer's collectives start again
             vpr.start_exchange(slot)
@@ -406,11 +467,13 @@ def main():
         warm = {k: v for k, v in _lib.stage_times().items() if v > 0}
         dom_stage = max(warm, key=warm.get) if warm else "blend_bwd"
         _lib.set_option("profile_stage", _lib.STAGE_NAMES.index(dom_stage))
+    counter[0] = 0                        # the timed steps render views 0, 1, ... of this rank's cycle
     if dist:
         dist.barrier()
     dt, per_step_ms = timed(args.steps)
     if dist:
         dist.barrier()
+    timed_views = [view_ids[i % n_views] for i in range(args.steps)]
     stage_avg, dom_ms = {}, None
     if timers:
         # hipEvents recorded by the C ABI on the launch stream around the dominant kernel of every
@@ -430,17 +493,38 @@ def main():
         dt = float(tmax.item())
 
     # ---- informative passes, all after and outside the timed region -------------------------------------------
+    fixed_view = None
+    if n_views > 1 and extras:
+        # rounds 1-3's loop: one camera rendered over and over (identical tile lists, arena sizes and cache contents
+        # every step -- the best case of a trainer; kept for comparison with the earlier rounds' numbers)
+        cycle[0] = False
+        for _ in range(3):
+            step()
+        drain()
+        dt_f, ms_f = timed(args.steps)
+        if dist:
+            tf = torch.tensor([dt_f], dtype=torch.float64, device=dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            dt_f = float(tf.item())
+        fixed_view = {"view": view_ids[0], "ms_per_step": 1e3 * dt_f / args.steps, "median_ms_per_step": statistics.median(ms_f),
+                      "value": world * args.steps / dt_f, "unit": "views/s", "num_rendered": view_R[0],
+                      "note": "the same steps on ONE fixed camera (the timed loop of rounds 1-3), after the timed region"}
+        cycle[0] = True
+    cycle[0] = False        # the passes below compare modes on one camera
     compute_only, other_schedule = None, None
     if exchanging:
         def max_over_ranks(x):
             t_ = torch.tensor([x], dtype=torch.float64, device=dev)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
             return float(t_.item())
-        # the same steps without the exchange: what the collectives add to the step
+        # the same steps without the exchange: what the collectives add to the step (same camera cycle as the timed region)
         drain()
+        cycle[0] = True
+        counter[0] = 0
         exchange_on[0] = False
         for _ in range(3):
             step()
+        counter[0] = 0
         dt_c, _ = timed(args.steps, with_drain=False)
         exchange_on[0] = True
         compute_only = 1e3 * max_over_ranks(dt_c) / args.steps
@@ -455,6 +539,7 @@ def main():
         other_schedule["exposed_ms_per_step"] = other_schedule["ms_per_step"] - compute_only
         drain()
         schedule[0] = mine
+        cycle[0] = False
     single = world == 1 and not exchanging
     tight = None
     if single and extras and not args.tight_binning:
@@ -547,12 +632,14 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         views_per_s = world * args.steps / dt
-        V = int((radii > 0).sum())
-        R = int(vpr.true_num_rendered)
+        # per-view figures of the timed steps: the byte model takes their means over the views actually rendered
+        idx = [i % n_views for i in range(args.steps)]
+        V = sum(view_V[i] for i in idx) / len(idx)
+        R = sum(view_R[i] for i in idx) / len(idx)
         N = cam.image_width * cam.image_height
         T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
         from frosting_amd.introspect import State      # report-only: per-tile list statistics
-        rng = State(P, cam.image_width, cam.image_height, R, vpr.geom.buf, vpr.binning.buf, vpr.img.buf).ranges
+        rng = State(P, cam.image_width, cam.image_height, int(vpr.true_num_rendered), vpr.geom.buf, vpr.binning.buf, vpr.img.buf).ranges
         tile_len = (rng[:, 1] - rng[:, 0]).float()
         B = stage_bytes(P, V, R, N, T)
         if do_backward:
@@ -569,8 +656,13 @@ def main():
                            "launch stream, rank 0); value and ms_per_step are wall clock over all steps, max over ranks",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, SH deg 3, {cam.image_width}x{cam.image_height}, "
-                                   f"{what}, 1 view per GPU per step", "P": P, "visible": V,
-                       "num_rendered": R, "instances_per_visible": R / max(V, 1), "tiles": T,
+                                   f"{what}, 1 view per GPU per step", "P": P,
+                       "views": n_views, "views_note": f"step i of rank r renders camera (r + i) % {n_views} of the 8-camera ring; "
+                                                       "visible / num_rendered / byte model = means over the timed steps' views",
+                       "timed_views_rank0": timed_views,
+                       "visible": V, "num_rendered": R, "num_rendered_min": min(view_R), "num_rendered_max": max(view_R),
+                       "num_rendered_by_view": dict(zip(map(str, view_ids), view_R)),
+                       "instances_per_visible": R / max(V, 1), "tiles": T,
                        "tile_list_mean": float(tile_len.mean()), "tile_list_max": int(tile_len.max()),
                        "parallelism": f"view-parallel x{world}", "ranks": world, "backend": (args.backend if dist else "none"),
                        "exchange": ("none" if not exchanging else
@@ -611,8 +703,11 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.config, P),
                                "algorithmic_bytes_per_launch": B[dom], "avg_launch_ms": dom_ms,
                                "timed": "hipEvents around this kernel in every timed step"}
+            out["roofline"]["build"] = _lib.build_fingerprint()
             out["stage_ms"] = stage_avg
             out["stage_ms_note"] = "all stages, 5 extra steps after the timed region"
+        if fixed_view:
+            out["fixed_view"] = fixed_view
         if tight:
             out["tight_binning"] = tight
         if api_path:
@@ -623,7 +718,11 @@ def main():
             out["skew_scene"] = skew
         out.update(side)
         whole = pmc_traffic("*", args.config, P)
-        if whole:
+        if whole == "stale":
+            out["op_hbm"]["measured_bytes_per_view"] = "stale"
+            out["op_hbm"]["measured_note"] = ("the newest committed PMC passes (profiles/r0N_pmc_traffic.json) were taken with other "
+                                              "kernel sources than this build's: not quoted")
+        elif whole:
             out["op_hbm"]["measured_bytes_per_view"] = whole["bytes"]
             out["op_hbm"]["measured_over_algorithmic"] = whole["bytes"] / total_bytes
             out["op_hbm"]["measured_note"] = (f"sum over the stages of the HBM-side bytes per launch from the committed rocprofv3 PMC "

@@ -190,6 +190,22 @@ def lib():
     return L
 
 
+def build_fingerprint() -> dict:
+    """What identifies the kernels a measurement was taken with: sha256 over the kernel sources (csrc/*.hip, *.h, the
+    Makefile and the public header, sorted by name -- the same wherever the tree is checked out) and over the loaded
+    library file.  tools/collect_traffic.py stores it beside the PMC figures; bench.py only quotes figures whose
+    source hash is that of the running tree."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_PKG), "include", "frosting_rasterizer.h"), "rb").read())
+    lib_sha = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest() if os.path.exists(LIB_PATH) else None
+    return {"kernel_sources_sha256": h.hexdigest(), "library_sha256": lib_sha}
+
+
 def last_error() -> str:
     return lib().frg_last_error().decode("utf-8", "replace")
 

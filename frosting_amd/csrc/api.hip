@@ -19,6 +19,18 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// spin-wait hint of the mailbox polls (the host side is not tied to x86)
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    __asm__ __volatile__("yield");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+
 int fail(int code, const char* fmt, ...)
 {
     va_list ap;
@@ -45,6 +57,9 @@ std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that ca
 // beside the sort, bit 1 the per-Gaussian backward beside the backward blend -- an upper bound on what overlapping
 // a VALU-bound with an LDS- or HBM-bound stage can give before any dependency-respecting pipeline is built
 std::atomic<int> g_probe{0};
+// TEST HOOK (FROSTING_EXPERIMENTS=1): pretend every forward posted "no heavy waves", so that the backward skips the 16-wave
+// launch of the per-Gaussian backward whatever the geometry holds -- the plain kernel's safety net must then do that work
+std::atomic<int> g_assume_no_heavy{0};
 
 // Optional per-stage GPU timing (frg_set_option("profile", 1)): hipEvents are
 // recorded on the caller's stream between the kernels of one forward / backward;
@@ -197,26 +212,44 @@ std::atomic<int> g_sparse_sh{1};            // option "sparse_sh": the SH pass o
 std::atomic<int> g_bwd_heavy_first{1};
 std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
 
-// Which mailbox post belongs to which forward, by geometry buffer (process-wide: autograd runs the backward on another
-// thread than the forward).  The pinned mailboxes are never freed.
-struct HeavyNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; };
+// What the host remembers about the forward that last filled a geometry buffer (process-wide: autograd runs the backward
+// on another thread than the forward): which mailbox post is its scatter's, and the arithmetic of its blend, so that a
+// backward called without an explicit mode (the reference's 21-argument signature has no place for one) follows ITS
+// forward, not whatever frg_set_option says by then.  A ring of kFwdNotes entries: with more forwards than that
+// outstanding the oldest are forgotten -- their backward then launches both forms of the per-Gaussian backward (as if
+// nothing had been posted) and takes the process-wide blend mode.  The pinned mailboxes are never freed.
+struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; };
+constexpr int kFwdNotes = 64;
 std::mutex g_heavy_mu;
-HeavyNote g_heavy_notes[16];
-unsigned g_heavy_next = 0;
+FwdNote g_fwd_notes[kFwdNotes];
+unsigned g_fwd_next = 0;
+// a forward starts on `geom`: whatever an earlier forward posted about this buffer is void now
+void note_forward(const void* geom, int exact)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = nullptr; n.seq = 0; n.exact = exact; return; }
+    g_fwd_notes[g_fwd_next++ % kFwdNotes] = FwdNote{geom, nullptr, 0, exact};
+}
 void note_heavy_post(const void* geom, const frg::Mailbox* mail, uint32_t seq)
 {
     std::lock_guard<std::mutex> lk(g_heavy_mu);
-    for (auto& n : g_heavy_notes) if (n.geom == geom) { n.mail = mail; n.seq = seq; return; }
-    g_heavy_notes[g_heavy_next++ % 16] = HeavyNote{geom, mail, seq};
+    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = mail; n.seq = seq; return; }
+}
+// -> the blend arithmetic (0 fast | 1 exact) of the forward that last filled `geom`, or -1 when it is not remembered
+int forward_exact_mode(const void* geom)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (const auto& n : g_fwd_notes) if (n.geom == geom) return n.exact;
+    return -1;
 }
 // -> the number of heavy waves of the forward that last filled `geom`, or -1 when unknown (no post, not arrived yet,
 // the mailbox already belongs to a later forward)
 int heavy_waves_posted(const void* geom)
 {
-    HeavyNote n;
+    FwdNote n;
     {
         std::lock_guard<std::mutex> lk(g_heavy_mu);
-        for (const auto& x : g_heavy_notes) if (x.geom == geom) n = x;
+        for (const auto& x : g_fwd_notes) if (x.geom == geom) n = x;
     }
     if (!n.mail || !g_use_mailbox.load(std::memory_order_relaxed)) return -1;
     // The forward returned when the scan stage was through; the scatter posts as its first act.  A backward called
@@ -229,7 +262,7 @@ int heavy_waves_posted(const void* geom)
         if (cur == n.seq) return (int)((uint32_t)post > 0x7fffffffu ? 0x7fffffffu : (uint32_t)post);
         if ((int32_t)(cur - n.seq) > 0) return -1;      // the mailbox already carries a later forward's post
         if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return -1;
-        __builtin_ia32_pause();
+        cpu_relax();
     }
 }
 
@@ -243,7 +276,7 @@ bool mailbox_wait(const uint32_t* flag, uint32_t seq, hipStream_t stream)
             if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
             if (q != hipErrorNotReady) return false;
         }
-        __builtin_ia32_pause();
+        cpu_relax();
     }
 }
 
@@ -385,13 +418,16 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
     // stray call must not be able to switch them on -- they exist only in processes started with FROSTING_EXPERIMENTS=1
-    if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0)) {
+    if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0 || strcmp(name, "bwd_tile_moments") == 0 ||
+                 strcmp(name, "assume_no_heavy") == 0)) {
         static const bool experiments = [] { const char* e = getenv("FROSTING_EXPERIMENTS"); return e && e[0] == '1'; }();
         if (!experiments)
             return fail(FRG_EINVAL, "option '%s' is a timing experiment (results are wrong by design): start the process with "
                                     "FROSTING_EXPERIMENTS=1 to use it", name);
         if (strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
         if (strcmp(name, "probe") == 0) return g_probe.exchange(value);
+        if (strcmp(name, "assume_no_heavy") == 0) return g_assume_no_heavy.exchange(value ? 1 : 0);
+        if (strcmp(name, "bwd_tile_moments") == 0) { const int old = frg::g_bwd_tile_moments; frg::g_bwd_tile_moments = value ? 1 : 0; return old; }
         const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old;
     }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
@@ -534,7 +570,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     char* geom_chunk = geometry_alloc(user, frg_geometry_bytes(P));
     char* img_chunk = image_alloc(user, frg_image_bytes(width, height));
     if (!geom_chunk || !img_chunk) return fail(FRG_EALLOC, "allocation callback returned null");
-    note_heavy_post(geom_chunk, nullptr, 0);      // whatever an earlier forward posted about this buffer is void now
+    note_forward(geom_chunk, exact);
     const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
     const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height, g_global_bins.load() != 0);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:228-231
@@ -791,7 +827,11 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
-    const int exact = FwdModes::pick(exact_mode, 1, exact_blend());
+    // the arithmetic of this backward's blend pass: what the caller says (frg_backward_args::exact_blend), else what
+    // the forward that filled these buffers used (the backward recomputes that forward's alpha, T and contributor
+    // tests: the same arithmetic keeps them consistent), else the process-wide option
+    const int noted = (exact_mode == 0 && geom_buffer) ? forward_exact_mode(geom_buffer) : -1;
+    const int exact = FwdModes::pick(exact_mode, 1, noted >= 0 ? noted : exact_blend());
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
     if (P == 0) return FRG_OK;
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !viewmatrix || !projmatrix || !campos)
@@ -827,12 +867,13 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
     out.dL_dshell_logits = dL_dshell_logits;
     out.dL_dshell_verts = dL_dshell_verts;
+    const int pbw_flags = (!exact && frg::g_bwd_tile_moments) ? FRG_PBW_TILE_MOMENTS : 0;
     const bool probe_bwd = (g_probe.load() & 2) && g_probe_side.ensure();
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
         FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, g_probe_side.stream));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, false, g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, g_probe_side.stream));
         FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
     }
     {
@@ -848,7 +889,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         // (usually its workgroups find an empty list and leave)
         StageScope sc_(ST_PREPROCESS_BWD, stream);
         // the forward's scatter posted how many waves of Gaussians need the 16-wave form (Mailbox::heavy): none, usually
-        const int heavy = debug ? -1 : heavy_waves_posted(geom_buffer);
+        const int heavy = g_assume_no_heavy.load(std::memory_order_relaxed) ? 0 : debug ? -1 : heavy_waves_posted(geom_buffer);
         const bool skip_heavy = heavy == 0;
         const bool side = !skip_heavy && !debug && g_bwd_side.ensure();
         // Known to exist: the few 16-wave workgroups go on the CALLER's stream and start at once on an empty GPU, the
@@ -860,8 +901,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         hipStream_t s_heavy = heavy_first ? stream : hs, s_plain = heavy_first ? hs : stream;
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
         if (!skip_heavy)
-            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, true, s_heavy), "preprocess_bwd (long runs)");
-        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), exact ? 0 : 1, false, s_plain), "preprocess_bwd");
+            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy), "preprocess_bwd (long runs)");
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain), "preprocess_bwd");
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
     }
     return FRG_OK;

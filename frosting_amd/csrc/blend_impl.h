@@ -319,7 +319,7 @@ __device__ __forceinline__ float fold_two(float a, float b)
 }
 
 // BWD_BATCH: instances whose partial sums are reduced together (2 or 3: 18 / 27 matrix rows, two lanes per row)
-template <bool EXACT, int BWD_BATCH>
+template <bool EXACT, int BWD_BATCH, bool TILE_MOM = false>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
@@ -499,7 +499,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                     const float dL_dalpha = M::mad(Tr[q], cdot, -(S[q] * rinv));
                     S[q] = M::mad(w, cdot, S[q]);
                     const float v = g_eff * dL_dalpha;
-                    if (EXACT) {
+                    if (!TILE_MOM) {       // about the Gaussian's centre, the reference's d (backward.cu:441,536-554)
                         const float vx = v * dx, vy = v * dy;
                         part[3] += vx;
                         part[4] += vy;
@@ -559,7 +559,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 // [entry][quadrant][9] table, and after a workgroup barrier per round of 64 list entries the table is summed over the
 // quadrants in a fixed order ((q0 + q1) + q2) + q3 and stored: deterministic, no atomics, one store per slot value.
 // The per-wave critical path -- what bounds such a frame -- is a quarter of the tile-per-wave form's.
-template <bool EXACT, int BWD_BATCH>
+template <bool EXACT, int BWD_BATCH, bool TILE_MOM = false>
 __global__ void __launch_bounds__(BLEND_THREADS)
 blend_bwd_quad_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
@@ -689,7 +689,7 @@ blend_bwd_quad_kernel(int T, int gx, int gy, int W, int H, const uint2* __restri
                 const float dL_dalpha = M::mad(Tr, cdot, -(S * rinv));
                 S = M::mad(w, cdot, S);
                 const float v = g_eff * dL_dalpha;
-                if (EXACT) {
+                if (!TILE_MOM) {
                     const float vx = v * dx, vy = v * dy;
                     part[3] += vx;
                     part[4] += vy;

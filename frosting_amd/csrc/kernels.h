@@ -34,6 +34,7 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // to be called before launch_scatter (same arguments as launch_tile_sort's): plans the sort of the long lists
 extern int g_sort_heavy_on_caller;
 extern int g_fwd_prefetch;
+extern int g_bwd_tile_moments;
 hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
                             const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream, int fork_mode = 0);
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
@@ -58,11 +59,12 @@ struct BwdOutputs {
     // [F,6,3] is ACCUMULATED into (caller zeroes it): the learnable shell of learn_shell = True
     float *dL_dshell_logits = nullptr, *dL_dshell_verts = nullptr;
 };
-// tile_moments: the slots hold moments about the tile centre (fast blend backward).  heavy_only: false = every wave of
-// 64 Gaussians that is not on GeomState::heavy_waves (the plain kernel), true = the listed waves (the 16-wave form; any
-// stream ordered after the blend backward)
+// heavy_only: false = every wave of 64 Gaussians that is not on GeomState::heavy_waves (the plain kernel), true = the
+// listed waves (the 16-wave form; any stream ordered after the blend backward).  flags:
+#define FRG_PBW_TILE_MOMENTS 1     // TIMING EXPERIMENT: the slots hold moments about the tile centre (round 3's fast blend backward)
+#define FRG_PBW_NO_HEAVY_LAUNCH 2  // the 16-wave launch is skipped: the plain kernel reduces waves of any slot count itself
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
-                                 const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int tile_moments,
+                                 const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int flags,
                                  bool heavy_only, hipStream_t s);
 
 // view-parallel exchange helpers (view_exchange.hip)

@@ -61,7 +61,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
-                      const float* __restrict__ sh_dir, int tile_moments, const uint32_t* __restrict__ heavy,
+                      const float* __restrict__ sh_dir, int flags, const uint32_t* __restrict__ heavy,
                       const uint32_t* __restrict__ sh_layout)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
@@ -132,7 +132,10 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     uint16_t* live = reinterpret_cast<uint16_t*>(shbuf + 96);           // [BWD_WIN] behind own_co / own_xy
     if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
     const uint32_t nwin = (S + BWD_WIN - 1) / BWD_WIN;                   // wave-uniform
-    if (!HEAVY && S > (uint32_t)FRG_BWD_HEAVY_SLOTS) return;             // on the forward's list: the 16-wave launch has it
+    // on the forward's list: the 16-wave launch has it -- unless the host skipped that launch (FRG_PBW_NO_HEAVY_LAUNCH:
+    // its forward posted "no such wave"), in which case a wave that does own that many slots is reduced right here,
+    // window after window: whatever the host believed, no Gaussian is left without its gradients
+    if (!HEAVY && S > (uint32_t)FRG_BWD_HEAVY_SLOTS && !(flags & FRG_PBW_NO_HEAVY_LAUNCH)) return;
     // HEAVY: round r gives window 16 r + wave to this wave; non-heavy: window after window
     for (uint32_t wr = 0; wr < (HEAVY ? (nwin + BWD_HEAVY_WAVES - 1) / BWD_HEAVY_WAVES : nwin); wr++) {
         const uint32_t w0 = (HEAVY ? wr * BWD_HEAVY_WAVES + (uint32_t)wave : wr) * BWD_WIN;
@@ -196,7 +199,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 const float* sp = slots + (size_t)(wave_base + sl) * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
-                if (tile_moments) {
+                if (flags & FRG_PBW_TILE_MOMENTS) {
                     // the fast blend leaves the moments of v = G dL/dalpha about the TILE centre (offset (u, w) of the
                     // pixel): with d = (Dx - u, Dy - w), (Dx, Dy) = Gaussian centre - tile centre,
                     //   sum v dx = Dx m0 - mu,  sum v dx^2 = Dx^2 m0 - 2 Dx mu + muu,  sum v dx dy = Dx Dy m0 - Dx mw - Dy mu + muw
@@ -555,7 +558,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 }
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
-                                 const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int tile_moments,
+                                 const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int flags,
                                  bool heavy_only, hipStream_t s)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
@@ -567,7 +570,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, tile_moments, g.heavy_waves, g.sh_layout)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout)
     // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }

@@ -50,8 +50,10 @@ def projection_matrix(znear: float, zfar: float, tanfovx: float, tanfovy: float)
 
 
 def look_at_camera(center, width: int, height: int, fx: float, fy: float,
-                   znear: float = 0.01, zfar: float = 100.0) -> Camera:
-    """COLMAP axes (x right, y down, z forward), looking at the origin."""
+                   znear: float = 0.01, zfar: float = 100.0, principal=None) -> Camera:
+    """COLMAP axes (x right, y down, z forward), looking at the origin.
+    principal = (cx, cy): an off-centre principal point in NDC units, patched into the projection the way Frosting's
+    camera conversion does it (frosting_scene/frosting_model.py:1440-1442: proj[2,0] = -K[0,2], proj[2,1] = -K[1,2])."""
     c = torch.as_tensor(center, dtype=torch.float64)
     z = -c / c.norm()
     x = torch.linalg.cross(z, torch.tensor([0.0, -1.0, 0.0], dtype=torch.float64))
@@ -65,15 +67,18 @@ def look_at_camera(center, width: int, height: int, fx: float, fy: float,
     # algebra in float32: full_proj = world_view @ projection, campos = inverse(world_view)[3,:3])
     wv64 = w2c.t().contiguous()  # row-vector convention
     proj64 = projection_matrix(znear, zfar, tanfovx, tanfovy).t().contiguous()
+    if principal is not None:
+        proj64[2, 0] = -float(principal[0])
+        proj64[2, 1] = -float(principal[1])
     world_view = wv64.float()
     full = (wv64 @ proj64).float()
     campos = c.float().contiguous()
     return Camera(height, width, float(tanfovx), float(tanfovy), world_view, full.contiguous(), campos)
 
 
-def ring_camera(k: int, width: int, height: int, fx: float, fy: float, n: int = 8, dist: float = 4.0) -> Camera:
+def ring_camera(k: int, width: int, height: int, fx: float, fy: float, n: int = 8, dist: float = 4.0, principal=None) -> Camera:
     th = 2.0 * math.pi * k / n
-    return look_at_camera([dist * math.sin(th), 0.0, -dist * math.cos(th)], width, height, fx, fy)
+    return look_at_camera([dist * math.sin(th), 0.0, -dist * math.cos(th)], width, height, fx, fy, principal=principal)
 
 
 @dataclass

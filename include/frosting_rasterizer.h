@@ -147,8 +147,9 @@ typedef struct frg_forward_args {
      * blend arithmetic; tight_binning 1 | 2 = off | on; async_sh 1 .. 4 = modes 0 .. 3.
      *   shell_bary_mode  how shell_logits become barycentric weights (frosting_model.py:713-719): 0 softmax
      *                    (use_softmax_for_bary_coords = True, the default of the reference) | 1 relu + renormalise:
-     *                    w = relu(x) / max(sum relu(x), 1e-8) ... exactly torch.nn.functional.relu + the division the
-     *                    reference writes, gradient zero where x <= 0 */
+     *                    w = relu(x) / sum relu(x) -- torch.nn.functional.relu + the plain division the reference
+     *                    writes (frosting_model.py:716-718), NO epsilon: a row whose six logits are all <= 0 gives
+     *                    0 / 0 = NaN here exactly as it does there; gradient zero where x <= 0 */
     int exact_blend, tight_binning, async_sh;
     int shell_bary_mode;
 } frg_forward_args;
@@ -170,7 +171,8 @@ size_t frg_backward_workspace_bytes(int P, int R);
  * SH row is then not materialised (its view-direction term still reaches dL_dmean3D) and dL_dcolor
  * receives the clamp-masked colour gradient (backward.cu:31-34), i.e. the per-Gaussian factor dRGB of
  * dL_dsh[i][ch] = basis_i * dRGB[ch], from which frg_sh_grad_from_views rebuilds the row.  Summation order is fixed, so
- * results are bit-reproducible run to run (the reference's atomics are not). */
+ * results are bit-reproducible run to run (the reference's atomics are not).  The blend pass uses the arithmetic
+ * (exact_blend) of the forward that filled the buffers -- see frg_backward_args::exact_blend. */
 int frg_backward(int P, int D, int M, int R,
                  const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
@@ -211,8 +213,11 @@ typedef struct frg_backward_args {
     const float *shell_logits, *shell_cell_verts;
     const long long* shell_cells;
     float *dL_dshell_logits, *dL_dshell_cell_verts;
-    /* second generation (struct_size tells): exact_blend 0 = frg_set_option's value, 1 | 2 = fast | exact arithmetic
-     * of THIS backward's blend pass; shell_bary_mode as in frg_forward_args, and equal to the forward's */
+    /* second generation (struct_size tells): exact_blend 1 | 2 = fast | exact arithmetic of THIS backward's blend
+     * pass; 0 (and frg_backward, which has no such argument) = the arithmetic of the forward that last filled
+     * geom_buffer -- per-call mode or process default, remembered by the library for the 64 most recent geometry
+     * buffers of the process -- and frg_set_option's value when that forward is no longer remembered.
+     * shell_bary_mode as in frg_forward_args, and equal to the forward's */
     int exact_blend;
     int shell_bary_mode;
 } frg_backward_args;

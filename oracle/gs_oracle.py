@@ -16,11 +16,26 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libgs_oracle.so")
 _lib = None
 
 
+_LIB64_PATH = os.path.join(_HERE, "_build", "libgs_oracle_f64.so")
+_lib64 = None
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "gs_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "_build/libgs_oracle.so"], stdout=subprocess.DEVNULL)
+    for path in (_LIB_PATH, _LIB64_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, os.path.relpath(path, _HERE)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+def lib64():
+    """gs_oracle.c with every float a double (oracle/Makefile, F64): only its two backward functions are used."""
+    global _lib64
+    if _lib64 is None:
+        if not os.path.exists(_LIB64_PATH):
+            build()
+        _lib64 = C.CDLL(_LIB64_PATH)
+    return _lib64
 
 
 def lib():
@@ -145,4 +160,45 @@ def backward(st, dL_dout_color):
                               C.c_float(i["tanfovx"]), C.c_float(i["tanfovy"]), _p(i["campos"]),
                               _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dcolors"]), _p(g["dL_dmeans3D"]),
                               _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+    return g
+
+
+def backward_f64(state, dL_dout_color):
+    """The exact-arithmetic (float64) gradient for a float32 forward state.
+
+    `state`: dict with the float32 forward's artefacts -- P, W, H, M, D, ranges [T,2], point_list [R], means2D [P,2],
+    conic_opacity [P,4], colors [P,3] (the clamped rgb, or colors_precomp), clamped [P,3] u8, final_T [H,W],
+    n_contrib [H,W], radii [P], cov3D [P,6] (computed or precomp), and the inputs means3D, shs (or None), scales /
+    rotations (or None), viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, scale_modifier.  The discrete decisions
+    (tile lists, last contributors) are the float32 run's; every sum and product behind the gradients is redone in
+    binary64, so the result is what the float32 implementations -- the reference with its atomics in scheduling order,
+    ours in a fixed order -- are both roundings of.  Returns float64 arrays named like backward()'s."""
+    L = lib64()
+    d = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    P, W, H, M, D = (int(state[k]) for k in ("P", "W", "H", "M", "D"))
+    plist = np.ascontiguousarray(np.asarray(state["point_list"]).astype(np.uint32))
+    R = int(plist.shape[0])
+    ranges = np.ascontiguousarray(np.asarray(state["ranges"]).astype(np.uint32))
+    ncon = np.ascontiguousarray(np.asarray(state["n_contrib"]).astype(np.uint32))
+    radii = np.ascontiguousarray(np.asarray(state["radii"]).astype(np.int32))
+    clamped = np.ascontiguousarray(np.asarray(state["clamped"]).astype(np.uint8))
+    shs, sc, rot = d(state.get("shs")), d(state.get("scales")), d(state.get("rotations"))
+    g = dict(dL_dmeans2D=np.zeros((P, 3)), dL_dconic=np.zeros((P, 4)), dL_dopacity=np.zeros((P, 1)),
+             dL_dcolors=np.zeros((P, 3)), dL_dmeans3D=np.zeros((P, 3)), dL_dcov3D=np.zeros((P, 6)),
+             dL_dsh=np.zeros((P, max(M, 1), 3))[:, :M], dL_dscales=np.zeros((P, 3)), dL_drotations=np.zeros((P, 4)))
+    g["dL_dsh"] = np.ascontiguousarray(g["dL_dsh"])
+    if P == 0:
+        return g
+    bg, m2, co, col = d(state["bg"]), d(state["means2D"]), d(state["conic_opacity"]), d(state["colors"])
+    fT, dpix = d(state["final_T"]), d(dL_dout_color)
+    L.gso_render_backward(C.c_int(P), C.c_int(R), C.c_int(W), C.c_int(H), _p(ranges), _p(plist), _p(bg), _p(m2), _p(co),
+                          _p(col), _p(fT), _p(ncon), _p(dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]),
+                          _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
+    m3, cov, vm, pm, cam = (d(state[k]) for k in ("means3D", "cov3D", "viewmatrix", "projmatrix", "campos"))
+    L.gso_preprocess_backward(C.c_int(P), C.c_int(D), C.c_int(M), _p(m3), _p(radii), _p(shs), _p(clamped), _p(sc), _p(rot),
+                              C.c_double(float(state.get("scale_modifier", 1.0))), _p(cov), _p(vm), _p(pm), C.c_int(W),
+                              C.c_int(H), C.c_double(float(state["tanfovx"])), C.c_double(float(state["tanfovy"])),
+                              _p(cam.reshape(-1)), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dcolors"]),
+                              _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]),
+                              _p(g["dL_drotations"]))
     return g

@@ -97,29 +97,44 @@ def distance_to_reference(g, runs, name):
     return min(rel_l2(g, r[name]) for r in runs)
 
 
-def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False, ops=None):
-    """Call the native entry points directly (what _RasterizeGaussians.forward does)."""
+def run_ours_native(scene, cam, bg, device, mode="sh", cov="sr", debug=False, ops=None, scale_modifier=1.0, colors=None,
+                    campos_2d=False):
+    """Call the native entry points directly (what _RasterizeGaussians.forward does).
+    colors: a [P,3] tensor handed over as colors_precomp (any per-Gaussian feature: Frosting renders view depth through
+    this argument, frosting_model.py:1800-1811); campos_2d: the camera centre as a [1,3] tensor, which is what
+    p3d_camera.get_camera_center() returns (frosting_model.py:1447,1462)."""
     sc = scene.to(device)
     e = torch.Tensor([])
+    if colors is not None:
+        mode = "colors"
     sh = sc.shs if mode == "sh" else e
     # colours are computed once on the CPU so every implementation sees the same bits
-    colors = e if mode == "sh" else precomp_colors(scene).to(device)
+    col = e if mode == "sh" else (colors if colors is not None else precomp_colors(scene)).to(device)
     scales, rots = (sc.scales, sc.rotations) if cov == "sr" else (e, e)
     cov3 = e if cov == "sr" else cov3d_from(scene).to(device)
-    args = (bg.to(device), sc.means3D, colors, sc.opacities, scales, rots, 1.0, cov3, cam.viewmatrix.to(device),
+    campos = cam.campos.to(device)
+    if campos_2d:
+        campos = campos.view(1, 3)
+    args = (bg.to(device), sc.means3D, col, sc.opacities, scales, rots, float(scale_modifier), cov3, cam.viewmatrix.to(device),
             cam.projmatrix.to(device), cam.tanfovx, cam.tanfovy, cam.image_height, cam.image_width, sh,
-            sc.sh_degree, cam.campos.to(device), False, debug)
+            sc.sh_degree, campos, False, debug)
     out = (ops or _C).rasterize_gaussians(*args)
     return out, args
 
 
-def oracle_kwargs(scene, cam, bg, mode="sh", cov="sr", as_numpy=True, device=None):
+def oracle_kwargs(scene, cam, bg, mode="sh", cov="sr", as_numpy=True, device=None, scale_modifier=1.0, colors=None):
     conv = (lambda t: t.numpy()) if as_numpy else (lambda t: t.to(device))
     kw = dict(means3D=conv(scene.means3D), opacities=conv(scene.opacities), viewmatrix=conv(cam.viewmatrix),
               projmatrix=conv(cam.projmatrix), campos=conv(cam.campos), bg=conv(bg), width=cam.image_width,
               height=cam.image_height, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=scene.sh_degree)
+    if scale_modifier != 1.0:
+        kw["scale_modifier"] = float(scale_modifier)
+    if colors is not None:
+        mode = "colors"
     if mode == "sh":
         kw["shs"] = conv(scene.shs)
+    elif colors is not None:
+        kw["colors_precomp"] = conv(colors)
     else:
         kw["colors_precomp"] = conv(precomp_colors(scene))
     if cov == "sr":

@@ -161,3 +161,74 @@ def test_oracle_backward_matches_independent_autograd():
     og = G.backward(st, wts.float().numpy())
     for name, p in zip(("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"), params):
         assert Hh.rel_l2(og[name], p.grad.numpy()) < 2e-3, (name, Hh.rel_l2(og[name], p.grad.numpy()))
+
+
+def _f64_state(st, scene, cam, bg):
+    """the float32 forward state of G.forward as the dict G.backward_f64 takes"""
+    return dict(P=st["P"], W=st["W"], H=st["H"], M=st["M"], D=st["D"], ranges=st["ranges"], point_list=st["point_list"],
+                means2D=st["means2D"], conic_opacity=st["conic_opacity"], colors=st["rgb"], clamped=st["clamped"],
+                final_T=st["final_T"], n_contrib=st["n_contrib"], radii=st["radii"], cov3D=st["cov3D"],
+                means3D=scene.means3D.numpy(), shs=scene.shs.numpy(), scales=scene.scales.numpy(),
+                rotations=scene.rotations.numpy(), viewmatrix=cam.viewmatrix.numpy(), projmatrix=cam.projmatrix.numpy(),
+                campos=cam.campos.numpy(), bg=bg.numpy(), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, scale_modifier=1.0)
+
+
+def test_float64_backward_is_the_limit_of_the_float32_one():
+    """oracle/_build/libgs_oracle_f64.so (gs_oracle.c with every float a double) is the yardstick of the sparse-frame
+    gradient tests on the GPU: here it is pinned on both sides -- within float32 rounding of the float32 oracle backward
+    on the same forward state, and on the independent float64 autograd derivation."""
+    import torch_ref
+    P = 40
+    scene = scenes.make_scene(P, 77, log_scale=np.log(0.08))
+    cam = scenes.ring_camera(0, 48, 32, 40.0, 40.0)
+    bg = torch.tensor([0.2, 0.4, 0.1])
+    st = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+    g = torch.Generator().manual_seed(5)
+    wts = torch.randn(3, 32, 48, generator=g, dtype=torch.float64)
+    g32 = G.backward(st, wts.float().numpy())
+    g64 = G.backward_f64(_f64_state(st, scene, cam, bg), wts.float().numpy())
+    for name in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert g64[name].dtype == np.float64
+        assert Hh.rel_l2(g32[name], g64[name]) < 2e-5, (name, Hh.rel_l2(g32[name], g64[name]))
+    params = [t.double().clone().requires_grad_(True) for t in
+              (scene.means3D, scene.scales, scene.rotations, scene.opacities, scene.shs)]
+    img = torch_ref.render(*params, cam, bg, 3)
+    (img * wts.float().double()).sum().backward()
+    for name, p in zip(("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"), params):
+        d64, d32 = Hh.rel_l2(g64[name], p.grad.numpy()), Hh.rel_l2(g32[name], p.grad.numpy())
+        # (the autograd side renders from float64 parameters end to end, the oracle from the float32 forward's 2-D
+        # state: what is left between them is that state's rounding, not the backward's)
+        assert d64 < max(2.0 * d32, 1e-5), (name, d64, d32)
+
+
+def test_pure_torch_alpha_blend_baseline_matches_the_oracle():
+    """oracle/torch_blend.py (the pure-PyTorch CPU alpha-blend bench.py times as north_star's CPU baseline): image,
+    final_T and n_contrib against the C oracle's blend on the same 2-D state, its autograd gradients against the oracle's
+    analytic blend backward (the reference's dL_dmean2D carries the NDC factor W/2, H/2 and its conic.y term is half
+    the derivative: backward.cu:536-554)."""
+    from oracle import torch_blend as TB
+    scene, cam, bg = scenes.config_scene("mini", 3, P=1200)
+    st = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
+    W, H = cam.image_width, cam.image_height
+    gpix, _ = scenes.l1_target_grad(torch.from_numpy(st["out_color"]), 13)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    res = TB.render(t(st["means2D"]), t(st["conic_opacity"]), t(st["rgb"]), t(st["ranges"].astype(np.int64)),
+                    t(st["point_list"].astype(np.int64)), bg, W, H, dL_dimage=gpix, chunk=64)
+    assert float((res["image"] - t(st["out_color"])).abs().mean()) < 1e-6
+    assert float((res["final_T"] - t(st["final_T"])).abs().max()) < 1e-5
+    assert (res["n_contrib"] != t(st["n_contrib"].astype(np.int64))).float().mean() < 1e-3   # (libm expf vs torch.exp at a threshold)
+    og = G.backward(st, gpix.numpy())
+    ndc = torch.tensor([0.5 * W, 0.5 * H])
+    assert Hh.rel_l2(res["dL_dmeans2D"] * ndc, og["dL_dmeans2D"][:, :2]) < 1e-4
+    assert Hh.rel_l2(res["dL_dcolors"], og["dL_dcolors"]) < 1e-5
+    assert Hh.rel_l2(res["dL_dconic_opacity"][:, 3], og["dL_dopacity"][:, 0]) < 1e-4
+    co = res["dL_dconic_opacity"]
+    mine = torch.stack([co[:, 0], 0.5 * co[:, 1], co[:, 2]], 1)
+    assert Hh.rel_l2(mine, og["dL_dconic"][:, [0, 1, 3]]) < 1e-4
+    # a subset of the tiles (what bench.py samples) touches only those tiles
+    part = TB.render(t(st["means2D"]), t(st["conic_opacity"]), t(st["rgb"]), t(st["ranges"].astype(np.int64)),
+                     t(st["point_list"].astype(np.int64)), bg, W, H, tiles=[0, 5, 17], chunk=64)
+    gx = (W + 15) // 16
+    for tile in (0, 5, 17):
+        y0, x0 = (tile // gx) * 16, (tile % gx) * 16
+        assert torch.equal(part["image"][:, y0:y0 + 16, x0:x0 + 16], res["image"][:, y0:y0 + 16, x0:x0 + 16])

@@ -4,6 +4,8 @@ quad-cycles, MI355X_MICROARCH.md)."""
 import collections, csv, glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from frosting_amd import _lib
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -16,6 +18,6 @@ for name in ("sq1", "sq2", "tcc"):
             k = re.sub(r"\(.*", "", k).replace("void ", "")
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: int(sum(v) / len(v)) for c, v in cs.items()} for k, cs in acc.items()}
-json.dump({"source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes, tools/pmc_round2.sh), bench.py c3; average per launch",
+json.dump({"build": _lib.build_fingerprint(), "source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes, tools/pmc_round2.sh), bench.py c3; average per launch",
            "kernels": out}, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json"), "w"), indent=1)
 print(json.dumps({k: v.get("SQ_INSTS_VALU") for k, v in out.items()}, indent=1))

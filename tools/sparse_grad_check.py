@@ -1,0 +1,103 @@
+"""Where do the default-arithmetic gradients of sparse frames on a large image sit?  
+
+For every frame: ours (default = fast arithmetic + automatic form; EXACT; both forms forced) and four runs of the reference's
+own backward (oracle/_ref, atomics in scheduling order) -- each against the other AND against the float64 gradient of the
+same float32 forward state (oracle/_build/libgs_oracle_f64.so): the exact-arithmetic value all of them are roundings of.
+usage: python tools/sparse_grad_check.py [--frames c3:50000,c3:150000,...]  [--truth-max-points N]
+TEST / MEASUREMENT TOOL: imports oracle/ (never part of the product path)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from frosting_amd import _lib, scenes
+from oracle import gs_oracle as G
+from oracle import ref_rasterizer as REF
+import helpers as Hh
+
+NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+
+
+def frame(spec):
+    cfg, P = spec.split(":")
+    P = int(P)
+    if cfg == "c2big":      # the C2 scene rendered on the C3 image
+        scene, _, bg = scenes.config_scene("c2", 0, P=P)
+        _, cam, _ = scenes.config_scene("c3", 1, P=8)
+        return scene, cam, bg
+    return scenes.config_scene(cfg, 2, P=P)
+
+
+def truth_state(rst, scene, cam, bg):
+    c = lambda t: t.detach().cpu().numpy()
+    return dict(P=rst.P, W=rst.W, H=rst.H, M=scene.shs.shape[1], D=scene.sh_degree, ranges=c(rst.ranges), point_list=c(rst.point_list),
+                means2D=c(rst.means2D), conic_opacity=c(rst.conic_opacity), colors=c(rst.rgb), clamped=c(rst.clamped),
+                final_T=c(rst.final_T), n_contrib=c(rst.n_contrib), radii=c(rst.radii), cov3D=c(rst.cov3D),
+                means3D=scene.means3D.numpy(), shs=scene.shs.numpy(), scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
+                viewmatrix=cam.viewmatrix.numpy(), projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(), bg=bg.numpy(),
+                tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, scale_modifier=1.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", default="c3:50000,c3:150000,c3:400000,c2big:100000,c2:60000,c3:3000000")
+    ap.add_argument("--truth-max-points", type=int, default=3_000_000)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ops = Hh.native_ops("ext")
+    experiments = os.environ.get("FROSTING_EXPERIMENTS") == "1"
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _bwd_args
+    for spec in a.frames.split(","):
+        scene, cam, bg = frame(spec)
+        _lib.set_option("exact_blend", 1)
+        out, args = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
+        _, rcolor, _, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=dev))
+        assert torch.equal(out[1], rcolor)
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 9)
+        gpix = gpix.to(dev)
+        runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
+        active = int((rst.ranges[:, 1] > rst.ranges[:, 0]).sum())
+        print(f"\n=== {spec}: R = {out[0]}, non-empty tiles {active} of {rst.ranges.shape[0]}", flush=True)
+        ours = {}
+        ours["exact/auto"] = [g.clone() for g in ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix))]
+        _lib.set_option("exact_blend", 0)
+        out2, _ = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
+        b2 = _bwd_args(args, out2, gpix)
+        ours["fast/auto"] = [g.clone() for g in ops.rasterize_gaussians_backward(*b2)]
+        for nm, tiles in (("fast/tile", 0), ("fast/quad", 1 << 30)):
+            _lib.set_option("bwd_quad_tiles", tiles)
+            ours[nm] = [g.clone() for g in ops.rasterize_gaussians_backward(*b2)]
+        if experiments:
+            _lib.set_option("bwd_tile_moments", 1)
+            for nm, tiles in (("r03tilemom/tile", 0), ("r03tilemom/quad", 1 << 30)):
+                _lib.set_option("bwd_quad_tiles", tiles)
+                ours[nm] = [g.clone() for g in ops.rasterize_gaussians_backward(*b2)]
+            _lib.set_option("bwd_tile_moments", 0)
+        _lib.set_option("bwd_quad_tiles", -1)
+        auto_is = "tile" if all(torch.equal(x, y) for x, y in zip(ours["fast/auto"], ours["fast/tile"])) else "quad"
+        print(f"    automatic form: {auto_is}")
+        truth = None
+        if scene.P <= a.truth_max_points:
+            truth = G.backward_f64(truth_state(rst, scene, cam, bg), gpix.cpu().numpy())
+        hdr = f"    {'tensor':14s} {'ref~ref':>9s}" + "".join(f" {k:>16s}" for k in ours)
+        print(hdr + ("   | vs float64:  ref(min..max)      " + "".join(f" {k:>16s}" for k in ours) if truth else ""))
+        for i, name in enumerate(NAMES):
+            noise = Hh.reference_noise(runs, name)
+            line = f"    {name[3:]:14s} {noise:9.1e}" + "".join(f" {Hh.distance_to_reference(g[i], runs, name):16.1e}" for g in ours.values())
+            if truth:
+                t = truth[name]
+                rr = [Hh.rel_l2(r[name].cpu().numpy(), t) for r in runs]
+                line += f"   |              {min(rr):.1e}..{max(rr):.1e}  " + "".join(f" {Hh.rel_l2(g[i].cpu().numpy(), t):16.1e}" for g in ours.values())
+            print(line, flush=True)
+        del rst, runs, ours, out, out2
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
