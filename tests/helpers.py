@@ -44,39 +44,114 @@ def native_ops(binding: str):
     return _C
 
 
-# Per-tensor bars for gradients against the reference's own backward (rel. L2 over the whole tensor).
-# Ours is bit-reproducible; the reference sums 9 float atomics per (pixel, Gaussian) pair in scheduling order, so
-# it differs from ITSELF run to run by 5e-8 (colour) .. 3e-4 (quaternion) at the C2 / C3 / C4 sizes.  A comparison
-# against the live reference passes within max(5 x that measured spread, floor).  Floors = at most ~3x the largest
-# difference measured at full size where the spread term does not cover it (3 M Gaussians, round 3:
-# gpurun_out/s1_pytest.log, profiles/r03_pytest_gpu.log):
-#   EXACT arithmetic (the reference's operation order): 6.1e-7 means2D, 2.3e-7 colour / SH, 2.6e-7 opacity, 1.5e-6 means3D,
-#     1.6e-5 cov3D, 1.2e-5 scales, 4.1e-5 quaternions;
-#   default (fast) arithmetic -- falloff as exp2 of a pre-scaled quadratic form in fused multiply-adds: alpha
-#     agrees with the reference's to ~5e-7, which the strongly cancelling sums behind dL_dmeans2D / dL_dmeans3D
-#     turn into 2.7e-5 / 2.5e-5; 2.6e-6 colour / SH, 4.5e-6 opacity, 2.5e-5 cov3D, 2.4e-5 scales, 5.7e-5 quaternions.
-# Scenes whose sums are much longer than the uniform scene's (near-camera Gaussians of hundreds of tiles, cluster tiles
-# of 10^5 entries, the thin shell of C4 seen edge-on) pass floor_scale = 3: two valid float32 summation orders drift apart
-# with the length of the sum.  (Round 1 used a blanket 3e-4; round 2 floors 2-7x above the measurements.)
-GRAD_FLOOR = {"dL_dmeans2D": 2e-6, "dL_dcolors": 8e-7, "dL_dopacity": 8e-7, "dL_dmeans3D": 5e-6, "dL_dcov3D": 3e-5,
-              "dL_dsh": 8e-7, "dL_dscales": 3e-5, "dL_drotations": 1.5e-4}
-GRAD_FLOOR_FAST = {"dL_dmeans2D": 6e-5, "dL_dcolors": 8e-6, "dL_dopacity": 1.2e-5, "dL_dmeans3D": 6e-5, "dL_dcov3D": 7e-5,
-                   "dL_dsh": 8e-6, "dL_dscales": 7e-5, "dL_drotations": 1.7e-4}
-# Comparisons WITHOUT a spread estimate: against the committed golden fixtures (ONE stored run of the reference: its
-# atomic-order noise is frozen into the fixture) and against the C oracle's sequential summation at small sizes, where
-# single Gaussians dominate a tensor's norm.  Round 2's floors, unchanged.
-FIXTURE_FLOOR = {"dL_dmeans2D": 8e-6, "dL_dcolors": 2e-6, "dL_dopacity": 2e-6, "dL_dmeans3D": 2e-5, "dL_dcov3D": 6e-5,
-                 "dL_dsh": 2e-6, "dL_dscales": 1e-4, "dL_drotations": 3e-4}
-FIXTURE_FLOOR_FAST = {"dL_dmeans2D": 6e-5, "dL_dcolors": 8e-6, "dL_dopacity": 1.2e-5, "dL_dmeans3D": 6e-5, "dL_dcov3D": 1e-4,
-                      "dL_dsh": 8e-6, "dL_dscales": 1.5e-4, "dL_drotations": 4e-4}
+# ---- gradient bars ------------------------------------------------------------------------------------------------
+# The gate is SURVEY 7.1 step 5: rel. L2 <= 1e-4 per gradient tensor.  Ours is bit-reproducible; the reference sums nine
+# float atomics per (pixel, Gaussian) pair in scheduling order and differs from ITSELF run to run.  Round 4 measured what
+# that spread is made of (tools/sparse_grad_check.py, profiles/r04_sparse_grad_check.log): on every scene 84 - 100 % of
+# the reference's squared error against the float64 gradient sits in ONE Gaussian -- a needle seen edge-on whose cov2D
+# is held invertible only by the 0.3-pixel low-pass, so that backward.cu:197-271 multiplies the rounding of its pixel
+# sums by ~1e6.  On such a Gaussian every float32 evaluation (the reference's included) is a draw; whole-tensor rel. L2
+# then measures which draw one got (the reference against itself: 3e-7 ... 7e-2 on dL_drotations from session to
+# session), not the arithmetic.  So the yardstick is the exact-arithmetic gradient: oracle/_build/libgs_oracle_f64.so
+# (gs_oracle.c with every float a double) run on the float32 forward state, and every comparison is made twice:
+#   * on the float32-COMPUTABLE Gaussians -- all but the ceil(1e-4 x #rows) rows on which the reference's own runs are
+#     farthest from the float64 value -- ours must meet the gate against the float64 gradient (where the reference
+#     itself does not -- the thin shell of C4 seen edge-on: 9.7e-5 -- at most 1.5 x the reference's distance) AND stay
+#     within a small factor of the reference's own distance to it: 3 x in EXACT arithmetic (the reference's operation
+#     order: what is left is the order of the additions, two draws of the same rounding noise), 5 x in the default
+#     arithmetic (exp2 of a pre-scaled quadratic form in fused multiply-adds: measured 1 - 3.4 x);
+#   * on the whole tensor, the ill-conditioned rows included, ours must be within max(5 x the reference's run-to-run
+#     spread, gate) of the nearest reference run, OR no farther from the float64 gradient than 3 x (EXACT) / 6 x
+#     (default) the reference's own worst run: where float32 cannot compute a row, ours must not be out of the
+#     reference's league at it (a wrong clamp, a NaN, a lost slot would be off by orders of magnitude, not by a draw).
+# No per-scene factors: the bars of rounds 1-3 (floors x 2 ... x 8 by scene, a flat 5e-3 for one case) are gone.
+GATE = 1e-4
+TRIM_FRACTION = 1e-4
+WELL_FACTOR = {False: 3.0, True: 5.0}        # [fast]: ours vs the reference's own distance to float64, computable rows
+WELL_FLOOR = {False: 1e-5, True: 3e-5}       # ... below which that factor is not asked for (the reference itself sits at 1e-7 ... 1e-5)
+WHOLE_FACTOR = {False: 3.0, True: 6.0}
+GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
 
 
-def grad_bar(name, noise=None, fast=False, floor_scale=1.0):
-    """noise given (the reference's measured run-to-run spread): max(5 x noise, floor_scale x floor);
-    noise None: the fixture / oracle floors."""
-    if noise is None:
-        return (FIXTURE_FLOOR_FAST if fast else FIXTURE_FLOOR)[name]
-    return max(5.0 * noise, floor_scale * (GRAD_FLOOR_FAST if fast else GRAD_FLOOR)[name])
+def _rows(a, P):
+    t = torch.as_tensor(a.detach().cpu() if isinstance(a, torch.Tensor) else a).to(torch.float64)
+    return t.reshape(P, -1) if t.numel() else t.reshape(P, 0)
+
+
+def truth_from_ref_state(rst, dL_dimage):
+    """float64 gradient (oracle.gs_oracle.backward_f64) of the float32 forward state of a reference run (RefState)."""
+    from oracle import gs_oracle as G
+    c = lambda t: None if t is None else t.detach().cpu().numpy()
+    i = rst.inputs
+    pre = i["colors_precomp"]
+    state = dict(P=rst.P, W=rst.W, H=rst.H, M=i["M"], D=i["sh_degree"], ranges=c(rst.ranges), point_list=c(rst.point_list),
+                 means2D=c(rst.means2D), conic_opacity=c(rst.conic_opacity), colors=c(pre) if pre is not None else c(rst.rgb),
+                 clamped=c(rst.clamped), final_T=c(rst.final_T), n_contrib=c(rst.n_contrib), radii=c(rst.radii),
+                 cov3D=c(i["cov3D_precomp"]) if i["cov3D_precomp"] is not None else c(rst.cov3D),
+                 means3D=c(i["means3D"]), shs=c(i["shs"]), scales=c(i["scales"]), rotations=c(i["rotations"]),
+                 viewmatrix=c(i["viewmatrix"]), projmatrix=c(i["projmatrix"]), campos=c(i["campos"]), bg=c(i["bg"]),
+                 tanfovx=i["tanfovx"], tanfovy=i["tanfovy"], scale_modifier=i["scale_modifier"])
+    return G.backward_f64(state, c(dL_dimage))
+
+
+def truth_from_oracle_state(st, dL_dimage):
+    """float64 gradient of the float32 forward state of the C oracle (gs_oracle.forward's dict)."""
+    from oracle import gs_oracle as G
+    i = st["_inputs"]
+    pre = i["colors_precomp"]
+    state = dict(P=st["P"], W=st["W"], H=st["H"], M=st["M"], D=st["D"], ranges=st["ranges"], point_list=st["point_list"],
+                 means2D=st["means2D"], conic_opacity=st["conic_opacity"], colors=pre if pre is not None else st["rgb"],
+                 clamped=st["clamped"], final_T=st["final_T"], n_contrib=st["n_contrib"], radii=st["radii"],
+                 cov3D=i["cov3D_precomp"] if i["cov3D_precomp"] is not None else st["cov3D"], means3D=i["means3D"],
+                 shs=i["shs"], scales=i["scales"], rotations=i["rotations"], viewmatrix=i["viewmatrix"],
+                 projmatrix=i["projmatrix"], campos=i["campos"], bg=i["bg"], tanfovx=i["tanfovx"], tanfovy=i["tanfovy"],
+                 scale_modifier=i["scale_modifier"])
+    return G.backward_f64(state, np.asarray(dL_dimage))
+
+
+def judge_gradients(ours, refs, truth, fast, label, names=None, quiet=False):
+    """ours: {name: tensor} (or the 8-tuple of rasterize_gaussians_backward); refs: list of {name: tensor / array} -- runs
+    of a float32 reference on the same forward state (the reference's atomics, a stored fixture, the C oracle);
+    truth: {name: float64 array}.  Asserts the two comparisons described above and returns the per-tensor report."""
+    if not isinstance(ours, dict):
+        ours = dict(zip(GRAD_NAMES, ours))
+    report = {}
+    for name in (names or GRAD_NAMES):
+        if name not in ours or name not in truth:
+            continue
+        t_full = np.asarray(truth[name])
+        P = t_full.shape[0]
+        t = _rows(t_full, P)
+        if t.numel() == 0 or not bool(t.any()):
+            assert not bool(_rows(ours[name], P).any()) or t.numel() == 0, (label, name, "expected an all-zero gradient")
+            continue
+        o = _rows(ours[name], P)
+        rs = [_rows(r[name], P) for r in refs]
+        e_ref = torch.stack([(r - t).pow(2).sum(1) for r in rs]).max(0).values          # per row: the reference's worst run
+        live = int((t.pow(2).sum(1) > 0).sum())
+        k = max(1, int(np.ceil(TRIM_FRACTION * live)))
+        keep = torch.ones(P, dtype=torch.bool)
+        keep[torch.topk(e_ref, k).indices] = False
+        tn, tkn = float(t.norm()), float(t[keep].norm())
+        well_ours = float((o[keep] - t[keep]).norm()) / tkn
+        well_ref = max(float((r[keep] - t[keep]).norm()) for r in rs) / tkn
+        all_ours = float((o - t).norm()) / tn
+        all_ref = max(float((r - t).norm()) for r in rs) / tn
+        d_ref = min(float((o - r).norm()) / float(r.norm()) for r in rs)
+        noise = max((float((rs[a] - rs[b]).norm()) / float(rs[b].norm()) for a in range(len(rs)) for b in range(a)), default=0.0)
+        report[name] = dict(well_ours=well_ours, well_ref=well_ref, all_ours=all_ours, all_ref=all_ref, d_ref=d_ref, noise=noise, trimmed=k)
+    if not quiet:
+        print(f"\n[{label}, {'default' if fast else 'EXACT'} arithmetic] rel. L2 vs float64 on the float32-computable rows: ours (reference) | whole "
+              f"tensor: ours vs float64 (reference vs float64), ours vs nearest reference run (reference vs itself)")
+        for name, r in report.items():
+            print(f"    {name[3:]:11s} {r['well_ours']:.1e} ({r['well_ref']:.1e}; {r['trimmed']} rows set aside) | {r['all_ours']:.1e} "
+                  f"({r['all_ref']:.1e}), {r['d_ref']:.1e} ({r['noise']:.1e})")
+    for name, r in report.items():
+        msg = (label, "fast" if fast else "exact", name, r)
+        assert r["well_ours"] <= max(GATE, 1.5 * r["well_ref"]), msg
+        assert r["well_ours"] <= max(WELL_FACTOR[fast] * r["well_ref"], WELL_FLOOR[fast]), msg
+        assert r["d_ref"] < max(5.0 * r["noise"], GATE) or r["all_ours"] <= max(WHOLE_FACTOR[fast] * r["all_ref"], GATE), msg
+    return report
 
 
 def reference_runs(backward_fn, n=4):

@@ -36,8 +36,7 @@ def _bwd_args(args, out, gpix):
             gpix, args[14], args[15], args[16], geom, R, binning, img, False)
 
 
-GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
-              "dL_drotations"]
+GRAD_NAMES = Hh.GRAD_NAMES
 
 
 @pytest.fixture(autouse=True)
@@ -93,12 +92,13 @@ def test_against_reference_golden_fixture(gpu_device, path, exact, ops):
         assert np.abs(image - fx["image"]).mean() <= L1_BAR
     gpix, _ = scenes.l1_target_grad(torch.from_numpy(fx["image"]), int(fx["loss_seed"]))
     grads = ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
-    for name, g in zip(GRAD_NAMES, grads):
-        ref = fx["grad_" + name]
-        if ref.size == 0 or not np.any(ref):
-            continue
-        # one run of the reference's atomics is frozen in the fixture: 5 x its typical spread as noise term
-        assert Hh.rel_l2(g.cpu().numpy(), ref) < Hh.grad_bar(name, fast=not exact), (name, Hh.rel_l2(g.cpu().numpy(), ref))
+    # ONE stored run of the reference's backward (its atomic-order noise is frozen into the fixture), judged like a live
+    # one: both against the float64 gradient of the same forward state (the C oracle's, whose per-Gaussian stage is
+    # bit-identical to the reference's)
+    o = G.forward(**Hh.oracle_kwargs(scene, cam, bg, str(fx["mode"]), str(fx["cov"])))
+    truth = Hh.truth_from_oracle_state(o, gpix.numpy())
+    stored = {name: fx["grad_" + name] for name in GRAD_NAMES if fx["grad_" + name].size}
+    Hh.judge_gradients(grads, [stored], truth, fast=not exact, label=os.path.basename(path), names=list(stored))
 
 
 @pytest.mark.parametrize("mode,cov", [("sh", "sr"), ("colors", "sr"), ("sh", "cov"), ("colors", "cov")])
@@ -121,8 +121,7 @@ def test_against_c_oracle_all_input_modes(gpu_device, mode, cov):
     for name, g in zip(GRAD_NAMES, grads):
         if og[name].size == 0 or not np.any(og[name]):
             assert not g.cpu().numpy().any() or og[name].size == 0
-            continue
-        assert Hh.rel_l2(g.cpu().numpy(), og[name]) < Hh.grad_bar(name), (name, Hh.rel_l2(g.cpu().numpy(), og[name]))
+    Hh.judge_gradients(grads, [og], Hh.truth_from_oracle_state(o, gpix.numpy()), fast=False, label=f"C oracle {mode}/{cov}")
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
@@ -137,7 +136,7 @@ def test_lower_sh_degrees(gpu_device, deg):
     grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
     og = G.backward(o, gpix.numpy())
     dsh = grads[5].cpu().numpy()
-    assert Hh.rel_l2(dsh, og["dL_dsh"]) < Hh.grad_bar("dL_dsh")
+    Hh.judge_gradients(grads, [og], Hh.truth_from_oracle_state(o, gpix.numpy()), fast=False, label=f"SH degree {deg}", names=["dL_dsh"])
     assert not dsh[:, (deg + 1) ** 2:, :].any()  # coefficients above the active degree get zero gradient
 
 
@@ -176,18 +175,20 @@ def test_truncated_sh_storage(gpu_device, deg):
         gpix, _ = scenes.l1_target_grad(out[1].cpu(), 6)
         grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
         og = G.backward(o, gpix.numpy())
-        for name, g in zip(GRAD_NAMES, grads):
-            if name in ("dL_dsh", "dL_dmeans3D", "dL_dopacity", "dL_dscales"):
-                assert Hh.rel_l2(g.cpu().numpy(), og[name]) < Hh.grad_bar(name), (name, Hh.rel_l2(g.cpu().numpy(), og[name]))
+        Hh.judge_gradients(grads, [og], Hh.truth_from_oracle_state(o, gpix.numpy()), fast=False, label=f"M = {M}",
+                           names=["dL_dsh", "dL_dmeans3D", "dL_dopacity", "dL_dscales"])
     finally:
         _lib.set_option("exact_blend", 0)
 
 
-def _check_against_reference_rasterizer(gpu_device, scene, cam, bg, ops, label, floor_scale=1.0, scale_modifier=1.0,
-                                        colors=None, campos_2d=False):
+_TRUTH_CACHE = {}
+
+
+def _check_against_reference_rasterizer(gpu_device, scene, cam, bg, ops, label, scale_modifier=1.0, colors=None, campos_2d=False):
     """Ours beside the reference's own code (oracle/_ref, hipcc -ffp-contract=off) on the same tensors: every forward
-    artefact bit-identical in EXACT mode, the eight gradients within max(5 x the reference's own run-to-run spread,
-    floor_scale x floor) in EXACT and in the default arithmetic.  Returns (tile list lengths, slots per 64-Gaussian wave).
+    artefact bit-identical in EXACT mode; the eight gradients, in EXACT and in the default arithmetic, judged beside four
+    runs of the reference's backward against the float64 gradient of that forward state (helpers.judge_gradients: the
+    1e-4 gate, no per-scene factors).  Returns (tile list lengths, slots per 64-Gaussian wave).
     scale_modifier / colors (a [P,3] feature tensor as colors_precomp) / campos_2d ([1,3] camera centre): the call-site
     variations of helpers.run_ours_native."""
     P = scene.P
@@ -217,14 +218,15 @@ def _check_against_reference_rasterizer(gpu_device, scene, cam, bg, ops, label, 
     gpix, _ = scenes.l1_target_grad(color.cpu(), 9)
     gpix = gpix.to(gpu_device)
     runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
-    noise = {name: Hh.reference_noise(runs, name) for name in GRAD_NAMES}   # the reference's own run-to-run spread
+    # (the float64 pass over a 3 M-Gaussian frame takes most of a minute of host time: one per scene, whatever the binding)
+    key = (label, P, R, cam.image_width, cam.image_height, float(scale_modifier))
+    if key not in _TRUTH_CACHE:
+        _TRUTH_CACHE.clear()
+        _TRUTH_CACHE[key] = Hh.truth_from_ref_state(rst, gpix)
+    truth = _TRUTH_CACHE[key]
 
     def check(grads, fast, mode):
-        report = {name: Hh.distance_to_reference(g, runs, name) for name, g in zip(GRAD_NAMES, grads)}
-        print(f"\n[{label} {mode}] gradient rel-L2 vs reference (reference vs itself): " +
-              ", ".join(f"{k[3:]} {v:.1e} ({noise[k]:.1e})" for k, v in report.items()))
-        for name, err in report.items():
-            assert err < Hh.grad_bar(name, noise[name], fast, floor_scale), (label, mode, name, err, noise[name])
+        Hh.judge_gradients(grads, runs, truth, fast, label)
 
     # EXACT arithmetic (the reference's operation order): backward on the bit-identical forward state
     check(ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix)), False, "exact")
@@ -266,8 +268,7 @@ def test_call_site_variations_vs_reference_rasterizer(gpu_device, case):
     else:
         kw["campos_2d"] = True
     ops = Hh.native_ops("ext" if case[0] in "sd" else "ctypes")
-    # (floors x 2: 150 k Gaussians carry each tensor's norm instead of the 3 M the floors were measured on)
-    _check_against_reference_rasterizer(gpu_device, scene, cam, bg, ops, case, floor_scale=2.0, **kw)
+    _check_against_reference_rasterizer(gpu_device, scene, cam, bg, ops, case, **kw)
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
@@ -277,10 +278,28 @@ def test_bit_exact_vs_reference_rasterizer(gpu_device, cfg, P, view, binding):
     """The reference's own code (hipcc, -ffp-contract=off) run beside ours on the same tensors, at the FULL
     sizes of BASELINE.json's configs[1] (C2) and configs[2] (C3: 3 M Gaussians, 1600x1056, 16.4 M instances)."""
     scene, cam, bg = scenes.config_scene(cfg, view, P=P)
-    # (the 400 k-Gaussian scene on the 1600x1056 image: floors x 2 -- fewer Gaussians carry each tensor's norm than at the
-    # 3 M the floors were measured on; its distances on the covariance chain sit AT the 3 M floors, 4.9e-6 ... 2.2e-4)
-    _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops(binding), f"{cfg} P={P}",
-                                        floor_scale=2.0 if (cfg == "c3" and P < 1_000_000) else 1.0)
+    _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops(binding), f"{cfg} P={P}")
+
+
+@pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("frame", ["c3:50000", "c3:150000", "c3:400000", "c2-scene-on-the-c3-image:100000"])
+def test_sparse_frames_default_modes_vs_reference(gpu_device, frame):
+    """Sparse frames on the large image: 50 k - 400 k Gaussians on 1600x1056 light every one of the
+    6600 tiles with short lists -- the state of a scene early in training (3DGS starts from ~1e5 SfM points) -- and get
+    the tile-per-wave backward in the default arithmetic.  Default options (fast arithmetic, automatic form), through
+    the compiled extension, beside the reference's own code: forward artefacts bit-identical in EXACT mode; all eight
+    gradients at the 1e-4 gate, no per-scene factor (helpers.judge_gradients).  What round 3's kernel did here -- pixel
+    moments about the tile centre, shifted per instance -- is gone: the moments are the reference's, about the Gaussian
+    (blend_impl.h); measured on these frames in profiles/r04_sparse_grad_check.log."""
+    name, P = frame.split(":")
+    if name == "c3":
+        scene, cam, bg = scenes.config_scene("c3", 2, P=int(P))
+    else:
+        scene, _, bg = scenes.config_scene("c2", 0, P=int(P))
+        _, cam, _ = scenes.config_scene("c3", 1, P=8)
+    assert _lib.get_option("bwd_quad_tiles") == -1 and _lib.get_option("tight_binning") == 0      # default options
+    list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops("ext"), frame)
+    assert int((list_len > 0).sum()) > 2560           # more active tiles than FRG_BWD_QUAD_TILES: the tile-per-wave form
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
@@ -292,11 +311,7 @@ def test_skewed_scene_vs_reference_rasterizer(gpu_device):
     cfg = scenes.CONFIGS["c3"]
     scene = scenes.make_skew_scene(cfg["P"], cfg["seed"] + 77)
     _, cam, bg = scenes.config_scene("c3", 0, P=1000)
-    # floors x 5: a near-camera Gaussian sums its gradient over hundreds of tiles, a cluster tile over 10^5 entries --
-    # two valid float32 summation orders (the reference's atomics, our per-tile partials) drift apart with the length
-    # of the sums (measured: 1.9e-6 ... 2.0e-6 on dL_dopacity and 1.7e-6 on the colours, where the uniform scene has
-    # 2.6e-7 / 2.3e-7; the distance moves with the reference's realisation, so the bar keeps a factor 2 over it)
-    list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops("ext"), "skew 3M", floor_scale=5.0)
+    list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops("ext"), "skew 3M")
     assert int(list_len.max()) > 250_000 and int((list_len > 8192).sum()) >= 100
 
 
@@ -308,7 +323,7 @@ def test_long_lists_and_giant_gaussians_vs_reference_rasterizer(gpu_device, bind
     whole image (their waves' slot runs are handed to the 16-wave form of the per-Gaussian backward) -- every
     sort key, the image and all eight gradients against the reference's own code."""
     scene, cam, bg = scenes.long_list_scene()
-    list_len, slots = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops(binding), "long lists", floor_scale=3.0)
+    list_len, slots = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops(binding), "long lists")
     assert int((list_len > 250_000).sum()) >= 1 and int((list_len > 8192).sum()) >= 100
     assert int((slots > 4 * 896).sum()) >= 1       # BWD_HEAVY_WINDOWS x BWD_WIN (preprocess_bwd.hip)
 
@@ -421,9 +436,10 @@ def test_autograd_module_api_matches_call_sites(gpu_device):
     (rendered_image - target).abs().mean().backward()
     o = G.forward(**Hh.oracle_kwargs(scene, cam, bg))
     og = G.backward(o, (torch.sign(rendered_image.detach() - target) / target.numel()).cpu().numpy())
-    assert Hh.rel_l2(means3D.grad.cpu(), og["dL_dmeans3D"]) < Hh.grad_bar("dL_dmeans3D", fast=True)
-    assert Hh.rel_l2(shs.grad.cpu(), og["dL_dsh"]) < Hh.grad_bar("dL_dsh", fast=True)
-    assert Hh.rel_l2(screenspace_points.grad.cpu(), og["dL_dmeans2D"]) < Hh.grad_bar("dL_dmeans2D", fast=True)  # densification statistic
+    gpix_np = (torch.sign(rendered_image.detach() - target) / target.numel()).cpu().numpy()
+    mine = {"dL_dmeans3D": means3D.grad, "dL_dsh": shs.grad, "dL_dmeans2D": screenspace_points.grad,   # (means2D: the densification statistic)
+            "dL_dopacity": opac.grad, "dL_dscales": scales.grad, "dL_drotations": rots.grad}
+    Hh.judge_gradients(mine, [og], Hh.truth_from_oracle_state(o, gpix_np), fast=True, label="autograd module", names=list(mine))
     assert not screenspace_points.grad[:, 2].any()
     vis = rasterizer.markVisible(sc.means3D)
     np.testing.assert_array_equal(vis.cpu().numpy(), G.mark_visible(scene.means3D.numpy(), cam.viewmatrix.numpy(),
@@ -607,8 +623,8 @@ def test_backward_follows_the_forwards_modes_not_the_process_options(gpu_device)
 def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
     """Few active tiles -> four waves per tile (blend_bwd_quad_kernel), many -> one (blend_bwd_kernel): the same
     partial sums in two fixed orders.  Both forms forced on the same forward (option bwd_quad_tiles): each is
-    bit-reproducible and within the usual bars of the reference's own backward; the choice follows the number of active
-    tiles (the full-size tests run the tile form: 6600 active tiles)."""
+    bit-reproducible and judged like every other backward (helpers.judge_gradients); the choice follows the number of
+    active tiles (the full-size tests run the tile form: 6600 active tiles)."""
     scene, cam, bg = scenes.config_scene("c2", 3, P=60_000)
     _lib.set_option("exact_blend", exact)
     out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
@@ -629,29 +645,11 @@ def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
     _lib.set_option("bwd_quad_tiles", -1)
     _, _, _, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
     runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
-    for name, gt, gq in zip(GRAD_NAMES, got["tile"], got["quad"]):
-        noise = Hh.reference_noise(runs, name)
-        dt, dq = Hh.distance_to_reference(gt, runs, name), Hh.distance_to_reference(gq, runs, name)
-        print(f"{name}: tile form vs reference {dt:.1e}, quadrant form vs reference {dq:.1e} (reference vs itself {noise:.1e}), "
-              f"quadrant vs tile form {Hh.rel_l2(gq, gt):.1e}")
-        # Fast arithmetic, tile form: the moments are taken about the TILE centre (six instructions per pixel and instance
-        # instead of eight) and shifted to the Gaussian once per tile instance.  On this sparse 60 k-Gaussian frame --
-        # which the automatic choice gives to the quadrant form -- the cancelling sums behind the covariance chain then
-        # sit further from the reference than on the frames the tile form is chosen for (measured here over several
-        # sessions: dL_dmeans3D 4.5e-5 ... 9.2e-5, dL_dscales 1.6e-4 ... 2.4e-4, dL_drotations 1.8e-3, against
-        # 1.6e-5 / 4.2e-5 / 1.4e-4 for the quadrant form; at C3, tile form, 2.5e-5 / 2.4e-5 / 5.3e-5).  The reference's
-        # own spread over four runs swings between 3e-7 and 1e-3 on this frame, so it cannot carry the bar: the forced
-        # tile form gets a fixed sanity bar on those four tensors here, the usual bars everywhere else.
-        # The other bars: floors x 8 on the covariance chain of this frame (EXACT: both forms sit 2.2e-5 / 2.4e-4 from the
-        # reference on dL_dmeans3D / dL_drotations whatever its realisation -- few Gaussians, a handful of ill-conditioned
-        # ones carry the norm); the tight floors are checked where they were measured, on the 0.1 - 3 M scenes.
-        chain = name in ("dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations")
-        bar = Hh.grad_bar(name, noise, fast=not exact, floor_scale=8.0 if chain else 1.0)
-        if not exact and chain:
-            assert dt < 5e-3, (name, "tile", dt, noise)
-        else:
-            assert dt < bar, (name, "tile", dt, noise)
-        assert dq < bar, (name, "quad", dq, noise)
+    truth = Hh.truth_from_ref_state(rst, gpix)
+    # both forms, the same bars as everywhere (round 3 gave the forced tile form of the default arithmetic a flat 5e-3 here:
+    # its moments were taken about the tile centre; they are taken about the Gaussian now, in both forms and arithmetics)
+    for form in ("tile", "quad"):
+        Hh.judge_gradients(got[form], runs, truth, fast=not exact, label=f"60 k frame, {form} form")
     # a frame that covers a corner of the image only: few active tiles -> the automatic choice is the quadrant form
     small = scenes.Scene(scene.means3D * 0.12 + torch.tensor([0.9, 0.6, 0.0]), scene.scales, scene.rotations, scene.opacities,
                          scene.shs, scene.sh_degree)
@@ -919,6 +917,7 @@ def test_backward_uses_the_blend_arithmetic_of_its_forward(gpu_device):
         got = _C.rasterize_gaussians_backward(*_bwd_args(args, out_m, gpix.to(gpu_device)))
         assert all(torch.equal(a, b) for a, b in zip(want[exact][1], got)), exact
         # and the backward of the process-default forward made in between still follows ITS forward
+        gpix, _ = scenes.l1_target_grad(want[1 - exact][0].cpu(), 41)
         got2 = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
         assert all(torch.equal(a, b) for a, b in zip(want[1 - exact][1], got2)), exact
 

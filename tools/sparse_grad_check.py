@@ -95,6 +95,30 @@ def main():
                 rr = [Hh.rel_l2(r[name].cpu().numpy(), t) for r in runs]
                 line += f"   |              {min(rr):.1e}..{max(rr):.1e}  " + "".join(f" {Hh.rel_l2(g[i].cpu().numpy(), t):16.1e}" for g in ours.values())
             print(line, flush=True)
+        if truth:
+            # how concentrated is the float32 error?  per Gaussian: the reference's worst run against the float64 value
+            for name in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
+                i = NAMES.index(name)
+                t = torch.from_numpy(truth[name]).reshape(scene.P, -1)
+                e_ref = torch.stack([(r[name].cpu().double().reshape(scene.P, -1) - t).pow(2).sum(1) for r in runs]).max(0).values
+                tn = t.pow(2).sum(1)
+                tot = float(e_ref.sum())
+                srt = torch.sort(e_ref, descending=True).values
+                conc = [float(srt[:k].sum()) / max(tot, 1e-300) for k in (1, 10, 100, 1000)]
+                rel = (e_ref / tn.clamp_min(1e-300)).sqrt()
+                vis = tn > 0
+                line = f"    {name[3:]:12s} share of the reference's squared error in its top 1/10/100/1000 Gaussians: " + " ".join(f"{c:.3f}" for c in conc)
+                line += f" | Gaussians with ref rel. error > 1e-2: {int((rel[vis] > 1e-2).sum())} of {int(vis.sum())}, > 1e-3: {int((rel[vis] > 1e-3).sum())}"
+                print(line)
+                for frac in (1e-4, 1e-3):
+                    k = max(1, int(frac * int(vis.sum())))
+                    drop = torch.topk(e_ref, k).indices
+                    keep = torch.ones(scene.P, dtype=torch.bool); keep[drop] = False
+                    tk = t[keep]
+                    f = lambda g: float((g.cpu().double().reshape(scene.P, -1)[keep] - tk).norm() / tk.norm())
+                    rr = [f(r[name]) for r in runs]
+                    print(f"      without the {k} worst-conditioned Gaussians (ref vs float64): ref {min(rr):.1e}..{max(rr):.1e} | " +
+                          " ".join(f"{kk} {f(g[i]):.1e}" for kk, g in ours.items()), flush=True)
         del rst, runs, ours, out, out2
         torch.cuda.empty_cache()
 
