@@ -93,12 +93,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         clamp_bits = __float_as_uint(rgb_clamped[FRG_REC * idx].w);
         tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
     }
-    // d(colour)/d(direction) of this Gaussian, left by the forward's SH pass (GeomState::sh_dir): requested now, used
-    // after the slot reduction.  The backward does not read the 192-byte SH rows at all.
-    float shd[9];
     const int sh_row = idx0 + sh_slot_of(__ballot(visible), lane, *sh_layout != 0u);     // (frg_common.h: by lane or by rank among the wave's visible Gaussians)
-#pragma unroll
-    for (int k = 0; k < 9; k++) shd[k] = (visible && shs) ? sh_dir[(size_t)sh_row * 9 + k] : 0.0f;
     // ---- 1. slot reduction ------------------------------------------------------
     const uint32_t incl = valid ? point_offsets[idx] : 0u;
     const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
@@ -280,12 +275,24 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
     }
     if (HEAVY && wave != 0) continue;      // (workgroup-level loop over the handed-over waves; wave 0 does the per-Gaussian part)
+    // LIVE Gaussians: those whose slot sums are not all zero.  At C3 only one visible Gaussian in seven is reached by
+    // a pixel before its tiles saturate (370 000 of 2.5 M); for the others every term below is a product with these
+    // zeros, so every gradient row is zero: they skip the loads (sh_dir 36 B, mean 12, scale 12, quaternion 16) and the
+    // arithmetic, and write their zero rows.  (The rows they wrote before were +-0 from the same products.)
+    bool has_grad = false;
+#pragma unroll
+    for (int c = 0; c < FRG_SLOT_FLOATS; c++) has_grad |= part[c] != 0.0f;
+    has_grad &= visible;
+    // d(colour)/d(direction), left by the forward's SH pass (GeomState::sh_dir): the backward does not read the 192-byte SH rows
+    float shd[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) shd[k] = (has_grad && shs) ? sh_dir[(size_t)sh_row * 9 + k] : 0.0f;
     // The blend backward stores pixel MOMENTS of v = G dL/dalpha per (tile, Gaussian): sum v dx, v dy, v dx^2,
     // v dx dy, v dy^2, v.  The map to the reference's terms (backward.cu:536-554: dL/dG = o dL/dalpha,
     // dG/d(delta) = -G (a dx + b dy, c dy + b dx), d(delta)/d(NDC) = (W/2, H/2)) is linear with per-GAUSSIAN
     // coefficients, so it is applied here, once per Gaussian after the sum over its tiles, instead of once per
     // (tile, Gaussian) instance in the blend kernel.
-    if (visible) {
+    if (has_grad) {
         const float4 kc = conic_opacity[FRG_REC * idx];
         const float o = kc.w, m3 = part[3], m4 = part[4];
         part[3] = -o * (kc.x * m3 + kc.y * m4) * (0.5f * vp.W);
@@ -298,7 +305,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float3 mean = make_float3(0.f, 0.f, 0.f);
-    if (visible) {
+    if (has_grad) {
         mean = param_mean(means3D, raw, idx);
         // ---- 2. computeCov2DCUDA (backward.cu:144-274) ----
         float cov[6];
@@ -371,7 +378,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dL_dmean2D[3 * idx] = part[3]; dL_dmean2D[3 * idx + 1] = part[4]; dL_dmean2D[3 * idx + 2] = 0.0f;
         if (dL_dconic) *reinterpret_cast<float4*>(dL_dconic + 4 * idx) = make_float4(part[5], part[6], 0.0f, part[7]);
         // raw mode: d sigmoid = o (1 - o)
-        dL_dopacity[idx] = (raw.raw_opacity && visible) ? part[8] * ((1.0f - conic_opacity[FRG_REC * idx].w) * conic_opacity[FRG_REC * idx].w) : part[8];
+        dL_dopacity[idx] = (raw.raw_opacity && has_grad) ? part[8] * ((1.0f - conic_opacity[FRG_REC * idx].w) * conic_opacity[FRG_REC * idx].w) : part[8];
         // with shs given and dL_dsh == nullptr the caller wants the factor of the SH gradient instead
         // (the clamp-masked colour gradient, stored below): see frg_backward in the header
         if (dL_dcolor && !(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
@@ -387,7 +394,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         const int M = vp.M;
         const int deg = vp.D;
         float x = 0.f, y = 0.f, z = 1.f, dox = 0.f, doy = 0.f, doz = 1.f;
-        if (visible) {
+        if (has_grad) {
             dox = mean.x - vmx.campos[0]; doy = mean.y - vmx.campos[1]; doz = mean.z - vmx.campos[2];
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
             x = dox / len; y = doy / len; z = doz / len;
@@ -396,7 +403,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
         if (!dL_dsh && valid) { dL_dcolor[3 * idx] = dRGB[0]; dL_dcolor[3 * idx + 1] = dRGB[1]; dL_dcolor[3 * idx + 2] = dRGB[2]; }
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        if (visible) {
+        if (has_grad) {
             wgt[0] = kSH0;
             if (deg > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
             if (deg > 1) {
@@ -410,7 +417,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
             }
         }
-        if (visible) {
+        if (has_grad) {
             const float dd0 = shd[0] * dRGB[0] + shd[1] * dRGB[1] + shd[2] * dRGB[2];
             const float dd1 = shd[3] * dRGB[0] + shd[4] * dRGB[1] + shd[5] * dRGB[2];
             const float dd2 = shd[6] * dRGB[0] + shd[7] * dRGB[1] + shd[8] * dRGB[2];
@@ -470,7 +477,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     //   dL/dv_k    += w_k dL/dmean                                              (learnable shell, learn_shell = True)
     if (raw.shell_logits && valid) {
         float gl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (visible) {
+        if (has_grad) {
             float w[6], gk[6];
             raw_bary6(raw, idx, w);
             const size_t cell = (size_t)raw.shell_cells[idx];
@@ -507,7 +514,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // ---- 5. cov3D -> scale, quaternion (backward.cu:278-341) ----
     if ((scales || raw.raw_scale) && valid) {
         float ds[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
-        if (visible) {
+        if (has_grad) {
             const float3 sc = param_scale(scales, raw, idx);
             const float4 q = param_rot(rotations, raw, idx);
             const float r = q.x, x = q.y, y = q.z, z = q.w;
@@ -538,11 +545,11 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
             dq[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
             dq[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
         }
-        if (visible && raw.raw_scale) {          // d exp = exp
+        if (has_grad && raw.raw_scale) {          // d exp = exp
             const float3 sc = param_scale(scales, raw, idx);
             ds[0] *= sc.x; ds[1] *= sc.y; ds[2] *= sc.z;
         }
-        if (visible && raw.raw_rot) {            // y = x / max(|x|, eps): dx = (g - y (y . g)) / max(|x|, eps)
+        if (has_grad && raw.raw_rot) {            // y = x / max(|x|, eps): dx = (g - y (y . g)) / max(|x|, eps)
             const float4 x = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
             const float nrm = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
             const float inv = 1.0f / fmaxf(nrm, 1e-12f);
