@@ -480,10 +480,13 @@ int frg_get_option(const char* name)
 size_t frg_geometry_bytes(int P) { return frg::GeomState::carve(nullptr, P).bytes; }
 size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nullptr, width, height, g_global_bins.load() != 0).bytes; }
 size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count).bytes; }
+// slots (36 B per instance) + the backward blend's list of full-segment work items ((tile, segment) per FRG_BWD_SEG instances)
+static size_t slots_bytes(int R) { return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256); }
+static size_t list_a_items(int R) { return (size_t)(R > 0 ? R : 1) / FRG_BWD_SEG + 8; }
 size_t frg_backward_workspace_bytes(int P, int R)
 {
     (void)P;
-    return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256);
+    return slots_bytes(R) + frg::align_up(list_a_items(R) * sizeof(uint2), 256);
 }
 
 int frg_geometry_layout_n(int P, long long* out, int n)
@@ -860,6 +863,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, false);
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
+    uint2* list_a = reinterpret_cast<uint2*>(workspace + slots_bytes(R));
+    const uint32_t list_a_cap = (uint32_t)list_a_items(R);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
@@ -879,9 +884,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
     {

@@ -121,7 +121,8 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 float* __restrict__ out_color, uint32_t* __restrict__ tile_work)
+                 float* __restrict__ out_color, uint32_t* __restrict__ tile_work, float4* __restrict__ ckpt,
+                 float4* __restrict__ final_C)
 {
     using M = BlendMath<EXACT>;
     const int tile = xcd_tile_of_block(blockIdx.x, T);
@@ -162,6 +163,12 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     if (PREFETCH && n > 0) fetch(0);
     for (int base = 0; base < n; base += 64) {
         if (wave_ballot(alive != 0.0f) == 0ull) break;   // this quadrant is saturated
+        // A segment boundary of the backward blend (every FRG_BWD_SEG entries; wave-uniform): the state of the quadrant's
+        // pixels BEFORE entry `base` is left for the backward's work item of the segment that ends here (a pixel that has
+        // stopped leaves stale values nobody reads: its last contributor lies in front of the boundary).  1 KB per
+        // quadrant and boundary, contiguous.
+        if (base != 0 && (base & (FRG_BWD_SEG - 1)) == 0)
+            ckpt[((size_t)(rg.x / FRG_BWD_SEG) + (size_t)(base / FRG_BWD_SEG)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
         const int cnt = min(64, n - base);
         bool hit = false;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
@@ -217,42 +224,46 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         out_color[plane + pid] = M::mad(Tr, bg[1], C1);
         out_color[2 * plane + pid] = M::mad(Tr, bg[2], C2);
     }
-    // how deep this tile's list was walked: the backward blend's work per tile, used to
-    // dispatch its long tiles first (bwd_order_kernel)
+    // how deep this tile's list was walked: the backward blend's work per tile (bwd_order_kernel cuts it into segments)
     uint32_t deepest = inside ? last : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, d, 64));
     if (lane == 0 && deepest) atomicMax(&tile_work[tile], deepest);
+    // a pixel whose last contributor lies behind a segment boundary: the backward needs the colour it ended with
+    if (deepest > (uint32_t)FRG_BWD_SEG) final_C[(size_t)tile * FRG_TILE_PIX + q * 64 + lane] = make_float4(C0, C1, C2, 0.0f);
 }
 
-// Workgroup -> tile map of the backward blend.  One wave per tile and 6.6 k tiles of very unequal
-// depth (324..1077 processed entries at C3) on 5 k wave slots: in index order the last, long tiles
-// run alone (makespan ~1.9x the balanced one).  Tiles are bucketed by processed depth (32 entries per
-// bucket, deepest first) inside their XCD band -- neighbouring tiles still share an L2 -- and dealt
-// to workgroups band-major, so workgroup b (XCD b % 8) takes the (b / 8)-th deepest tile of its band.
-// Few active tiles (a mesh-bound shell seen from outside covers a fifth of the image; BASELINE configs[3]): one wave per
-// tile then leaves most of the chip idle while every wave walks its tile's 10^3 .. 10^4 entries alone -- 0.77 ms for 5 M
-// instances on 1 400 tiles, twice the time of the 16 M instances of C3.  At or below FRG_BWD_QUAD_TILES active tiles
-// (tiles in which the forward blended anything: the same number in both binning modes) the QUADRANT form runs instead:
-// four waves per tile, one pixel per lane (blend_bwd_quad_kernel), tiles dealt deepest first over the whole chip
-// instead of per XCD band (the active tiles of such a scene sit in a few bands).  Measured crossover (tools/ab.py --shrink,
-// the C3 scene scaled to cover part of the 6600-tile image): 2 142 active tiles (C4) 0.79 -> 0.56 ms with the quadrant
-// form, ~3 000 equal (0.57 / 0.60), 5 600 and up the tile form wins (0.50 / 0.78; C3 itself 0.39 / 0.81).
-#define FRG_BWD_QUAD_TILES 2560
+// Work items of the backward blend.  A tile's processed prefix (tile_work[t] entries: up to the last contributor of its
+// last pixel) is cut into SEGMENTS of FRG_BWD_SEG entries; every segment is one work item of one wave.  Round 1-3 gave
+// a whole tile to one wave (or, on frames with few active tiles, to four): 324..1077 entries at C3, but 10^3..5 10^3 at
+// the limb of a shell seen from outside (C4) and 10^4..10^5 in a cluster -- the frame then waited for its deepest tile
+// (C4: 0.58 ms for 2.9 M tile-entries, when C3's 4.3 M take 0.39).  A segment can start anywhere because the forward left the
+// state there (BinningState::ckpt): the walk is a scan, and a scan can be restarted from a stored prefix.
+// bwd_order_kernel (one workgroup) builds, per XCD band of tiles (neighbouring tiles share their Gaussians: same L2),
+//   list A  the FULL segments (tile, k), k < nseg - 1: all the same length, longest items of the frame, pulled first;
+//   list B  every active tile's LAST segment, by decreasing length in 32 buckets;
+// and the header the persistent workgroups of blend_bwd_kernel pull from (BwdHdr).  Tiles in which the forward blended
+// nothing get their cutoff key cleared here (the per-Gaussian backward must not find an earlier frame's).
+struct BwdHdr {
+    // word 0: 1 = few active tiles, the quadrant form has this frame | 1: active tiles | 2: items in list A (all XCDs)
+    // words 8 + 4 x ..: A start, A count, B start, B count of XCD x | word 40 + 2 x: the cursor of XCD x (A then B, one index space)
+    __device__ static uint32_t* lists(uint32_t* h, int x) { return h + 8 + 4 * x; }
+    __device__ static uint32_t* cursors(uint32_t* h, int x) { return h + 40 + 2 * x; }
+};
+#define FRG_BWD_QUAD_TILES 0     // the quadrant form is a timing experiment now (option bwd_quad_tiles): segments balance what it balanced
+#define FRG_BWD_LEN_BUCKETS 32
 static __global__ void __launch_bounds__(1024)
-bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order,
-                 uint32_t* __restrict__ bwd_mode, uint32_t quad_tiles, uint2* __restrict__ cutoff)
+bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order, uint2* __restrict__ list_a,
+                 uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint32_t quad_tiles, uint2* __restrict__ cutoff, uint32_t waves_per_xcd)
 {
-    __shared__ uint32_t base[FRG_NUM_XCD * 64], cur[FRG_NUM_XCD * 64];
+    __shared__ uint32_t base[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS], cur[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS];
+    __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD];
     __shared__ uint32_t n_active;
     const int tid = threadIdx.x;
-    if (tid < FRG_NUM_XCD * 64) { base[tid] = 0; cur[tid] = 0; }
+    if (tid < FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS) { base[tid] = 0; cur[tid] = 0; }
+    if (tid < FRG_NUM_XCD) { a_cnt[tid] = 0; a_cur[tid] = 0; }
     if (tid == 0) n_active = 0;
-    for (int b = tid; b < nblocks; b += 1024) order[b] = 0xFFFFFFFFu;   // padding workgroups
     __syncthreads();
-    // A tile in which the forward blended nothing processes no instance: its cutoff key says so HERE -- the quadrant
-    // form only launches workgroups for the active tiles, and the per-Gaussian backward must not find the key an
-    // earlier frame left for such a tile.
     uint32_t mine = 0;
     for (int t = tid; t < T; t += 1024) {
         if (tile_work[t]) mine++;
@@ -261,24 +272,43 @@ bwd_order_kernel(int T, int nblocks, const uint32_t* __restrict__ tile_work, uin
     if (mine) atomicAdd(&n_active, mine);
     __syncthreads();
     const bool quad = n_active <= quad_tiles;
-    if (tid == 0) *bwd_mode = quad ? 1u : 0u;
-    // 63 buckets of 32 entries of processed depth, deepest first; the tiles where nothing was blended come last (bucket 63),
-    // so that the active tiles are exactly the first n_active of the order
+    // last segment of tile t: entries (tile_work - 1) % SEG + 1; bucket 0 = the longest
+    auto quad_bucket_of = [](uint32_t wk) { return (FRG_BWD_LEN_BUCKETS - 1) - (int)min((uint32_t)(FRG_BWD_LEN_BUCKETS - 1), wk >> 7); };   // (quadrant form: whole tiles, deepest first)
+    auto bucket_of = [](uint32_t wk) { return (FRG_BWD_LEN_BUCKETS - 1) - (((wk - 1u) % FRG_BWD_SEG) * FRG_BWD_LEN_BUCKETS) / FRG_BWD_SEG; };
     for (int t = tid; t < T; t += 1024) {
-        const uint32_t wk = tile_work[t], k = wk ? 62u - min(62u, wk >> 5) : 63u;
-        atomicAdd(&base[(quad ? 0 : xcd_of_tile(t, T)) * 64 + k], 1u);
-    }
-    __syncthreads();
-    if (tid < FRG_NUM_XCD) {
-        uint32_t run = 0;
-        for (int k = 0; k < 64; k++) { const uint32_t c = base[tid * 64 + k]; base[tid * 64 + k] = run; run += c; }
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
+        const uint32_t wk = tile_work[t];
+        if (!wk) continue;
         const int x = quad ? 0 : xcd_of_tile(t, T);
-        const uint32_t wk = tile_work[t], k = wk ? 62u - min(62u, wk >> 5) : 63u;
-        const uint32_t pos = base[x * 64 + k] + atomicAdd(&cur[x * 64 + k], 1u);
-        order[quad ? pos : pos * FRG_NUM_XCD + x] = (uint32_t)t;
+        atomicAdd(&base[x * FRG_BWD_LEN_BUCKETS + (quad ? quad_bucket_of(wk) : bucket_of(wk))], 1u);
+        if (!quad && wk > (uint32_t)FRG_BWD_SEG) atomicAdd(&a_cnt[x], (wk - 1u) / FRG_BWD_SEG);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0, arun = 0;
+        for (int x = 0; x < FRG_NUM_XCD; x++) {
+            uint32_t* l = BwdHdr::lists(hdr, x);
+            l[2] = run;
+            for (int k = 0; k < FRG_BWD_LEN_BUCKETS; k++) { const uint32_t c = base[x * FRG_BWD_LEN_BUCKETS + k]; base[x * FRG_BWD_LEN_BUCKETS + k] = run; run += c; }
+            l[3] = run - l[2];
+            // (the caller sizes list A for R / SEG items, which bounds their number; the clamp only guards the buffer)
+            const uint32_t ac = min(a_cnt[x], list_a_cap - min(list_a_cap, arun));
+            a_base[x] = arun; l[0] = arun; l[1] = ac; arun += ac;
+            BwdHdr::cursors(hdr, x)[0] = waves_per_xcd;     // the persistent waves' first items are static
+        }
+        hdr[0] = quad ? 1u : 0u; hdr[1] = n_active; hdr[2] = arun;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t wk = tile_work[t];
+        if (!wk) continue;
+        const int x = quad ? 0 : xcd_of_tile(t, T);
+        const int k = quad ? quad_bucket_of(wk) : bucket_of(wk);
+        order[base[x * FRG_BWD_LEN_BUCKETS + k] + atomicAdd(&cur[x * FRG_BWD_LEN_BUCKETS + k], 1u)] = (uint32_t)t;
+        if (!quad && wk > (uint32_t)FRG_BWD_SEG) {
+            const uint32_t nfull = (wk - 1u) / FRG_BWD_SEG, at = atomicAdd(&a_cur[x], nfull);
+            for (uint32_t sgm = 0; sgm < nfull; sgm++)
+                if (at + sgm < BwdHdr::lists(hdr, x)[1]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
+        }
     }
 }
 
@@ -319,6 +349,9 @@ __device__ __forceinline__ float fold_two(float a, float b)
 }
 
 // BWD_BATCH: instances whose partial sums are reduced together (2 or 3: 18 / 27 matrix rows, two lanes per row)
+// One wave per workgroup, PERSISTENT: it pulls (tile, segment) items from the lists of its XCD (bwd_order_kernel) -- the
+// full segments first, then the tiles' last segments by decreasing length -- and, when those are empty, from the other
+// XCDs' lists.  An item walks the list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
 template <bool EXACT, int BWD_BATCH, bool TILE_MOM = false>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
@@ -327,15 +360,12 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                  const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ bwd_mode)
+                 uint32_t* __restrict__ hdr, const uint2* __restrict__ list_a, const uint32_t* __restrict__ tile_work,
+                 const float4* __restrict__ ckpt, const float4* __restrict__ final_C)
 {
     using M = BlendMath<EXACT>;
-    if (*bwd_mode != 0u) return;     // few active tiles: blend_bwd_quad_kernel has this frame (wave-uniform scalar load)
-    const int tile = order ? (int)order[blockIdx.x] : xcd_tile_of_block(blockIdx.x, T);
-    if (tile < 0) return;
-    const int tx = tile % gx, ty = tile / gx;
+    if (hdr[0] != 0u) return;     // few active tiles and the quadrant form asked for: blend_bwd_quad_kernel has this frame
     const int lane = threadIdx.x;
-    const uint2 rg = ranges[tile];
 
     __shared__ float4 s_a[64];     // x, y, quadrant mask, 0-based list position
     __shared__ float4 s_co[64];
@@ -346,6 +376,46 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     // is worth more than the conflicts: 0.389 -> 0.407 ms; an XOR swizzle of the chunks by the row number keeps
     // the size but needs eight address registers: 130 VGPRs, three waves per SIMD.)
     __shared__ __attribute__((aligned(16))) float s_red[BWD_BATCH * FRG_SLOT_FLOATS * 64];   // reduction matrix, one column per lane
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const size_t plane = (size_t)H * W;
+
+    // ---- the item loop ----
+    // Items of XCD x = its list A followed by its list B, one index space, one cursor.  A wave's FIRST item is static
+    // (index blockIdx / 8 of its own XCD: the cursors start at the number of waves per XCD), every later one is pulled
+    // with an atomic -- behind a plain load of the cursor: 4096 waves polling sixteen exhausted cursors with atomics
+    // serialise in the L2 (measured: the kernel took 1.39 instead of 0.40 ms).
+    const int my_xcd = (int)(blockIdx.x % FRG_NUM_XCD);
+    int probe = 0;                 // own XCD first, then the others' leftovers
+    bool first = true;
+  for (;;) {
+    int tile = -1;
+    uint32_t seg = 0, walked = 0;
+    while (probe < FRG_NUM_XCD) {           // wave-uniform
+        const int x = (my_xcd + probe) % FRG_NUM_XCD;
+        const uint32_t* l = BwdHdr::lists(hdr, x);
+        const uint32_t na = l[1], total = na + l[3];
+        uint32_t k = 0xFFFFFFFFu;
+        if (first) k = blockIdx.x / FRG_NUM_XCD;
+        else if (lane == 0) {
+            uint32_t* cursor = BwdHdr::cursors(hdr, x);
+            if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) k = atomicAdd(cursor, 1u);
+        }
+        first = false;
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        if (k < total) {
+            if (k < na) { const uint2 it = list_a[l[0] + k]; tile = (int)it.x; seg = it.y; walked = tile_work[tile]; }
+            else { tile = (int)order[l[2] + (k - na)]; walked = tile_work[tile]; seg = (walked - 1u) / FRG_BWD_SEG; }
+            break;
+        }
+        probe++;
+    }
+    if (tile < 0) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const uint2 rg = ranges[tile];
+    const int seg_lo = (int)(seg * FRG_BWD_SEG);
+    const uint32_t seg_end = min(walked, (seg + 1u) * FRG_BWD_SEG);     // exclusive; == walked for the tile's last segment
+    const bool last_seg = seg_end == walked;
+    __syncthreads();               // the previous item's readers of the staging arrays are done
 
     // Per-pixel state of the back-to-front walk.  The reference carries the colour
     // composited behind the current Gaussian (accum_rec, last_color, last_alpha:
@@ -353,15 +423,12 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     //     S = sum_ch dL/dC_ch * (colour already composited behind) + T_final * (bg . dL/dC)
     // so that dL/dalpha_i = T_i * (c_i . dL/dC) - S / (1 - alpha_i), then S += alpha_i T_i (c_i . dL/dC).
     // Same mathematics, 2 registers instead of 9 per pixel.
+    // A pixel whose last contributor lies behind this segment starts from the forward's checkpoint at the segment's
+    // end: T = the transmittance there, colour behind = (colour the pixel ended with) - (colour accumulated there).
     float pxf[4], pyf[4], Tr[4], S[4], dLp[4][3];
-    // fast arithmetic: the pixel's offset (u, w) from the tile centre and its products -- the moments are then
-    // taken about the TILE centre, one FMA each on per-lane constants (six instructions per pixel and instance
-    // instead of eight about the Gaussian's centre); the per-Gaussian backward shifts every slot to its Gaussian
+    // timing experiment (TILE_MOM): round 3's moments about the tile centre
     float pu[4], pw[4], puu[4], puw[4], pww[4];
     uint32_t lastcon[4];
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const size_t plane = (size_t)H * W;
-    uint32_t maxc = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int px, py;
@@ -373,50 +440,59 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         const size_t pid = (size_t)py * W + px;
         Tr[q] = inside ? final_T[pid] : 0.0f;
         lastcon[q] = inside ? n_contrib[pid] : 0u;
-        maxc = max(maxc, lastcon[q]);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) dLp[q][ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
         S[q] = Tr[q] * M::mad(bg2, dLp[q][2], M::mad(bg1, dLp[q][1], bg0 * dLp[q][0]));
     }
-    // per-quadrant and tile-wide number of list entries that can still receive gradient
+    if (!last_seg) {               // wave-uniform: some pixel may go on behind this segment
+        const float4* ck = ckpt + ((size_t)(rg.x / FRG_BWD_SEG) + (size_t)(seg + 1u)) * FRG_TILE_PIX;
+        const float4* fc = final_C + (size_t)tile * FRG_TILE_PIX;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (lastcon[q] > seg_end) {
+                const float4 c = ck[q * 64 + lane], f = fc[q * 64 + lane];
+                const float behind = M::mad(f.z - c.w, dLp[q][2], M::mad(f.y - c.z, dLp[q][1], (f.x - c.y) * dLp[q][0]));
+                S[q] = S[q] + behind;          // (S held T_final (bg . dL/dC) so far)
+                Tr[q] = c.x;
+            }
+        }
+    }
+    // per-quadrant number of list entries that can still receive gradient, cut at the segment's end
     uint32_t qmax[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         qmax[q] = lastcon[q];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) qmax[q] = max(qmax[q], (uint32_t)__shfl_xor((int)qmax[q], d, 64));
+        qmax[q] = min(qmax[q], seg_end);
     }
-    maxc = max(max(qmax[0], qmax[1]), max(qmax[2], qmax[3]));
-    if (maxc == 0) {
-        if (lane == 0) cutoff[tile] = make_uint2(0u, 0u);
-        return;
-    }
-    if (lane == 0) {
-        const uint32_t id = point_list[rg.x + maxc - 1];
+    const uint32_t maxc = seg_end;     // (== max over the quadrants for the last segment: walked IS that maximum)
+    if (last_seg && lane == 0) {
+        const uint32_t id = point_list[rg.x + walked - 1];
         cutoff[tile] = make_uint2(__float_as_uint(xydr[FRG_REC * id].z), id);
     }
 
-    // walk the processed prefix [0, maxc) back to front, 64 instances at a time.  The walk is known in advance (no
+    // walk the segment [seg_lo, maxc) back to front, 64 instances at a time.  The walk is known in advance (no
     // early termination), so the records of round r + 1 -- id, three 16-byte gathers, the instance offset: a ~4 us
     // dependent chain -- are requested before round r is processed.  The loads are unconditional (clamped
     // positions): a conditional load into a loop-carried register makes the compiler copy it, and wait, at once.
     uint32_t id_n = 0, off_n = 0;
     float4 a_n, co_n, col_n;
     auto fetch = [&](int hi) {
-        id_n = point_list[rg.x + max(hi - lane, 0)];
+        id_n = point_list[rg.x + max(hi - lane, seg_lo)];
         a_n = xydr[FRG_REC * id_n];
         co_n = conic_opacity[FRG_REC * id_n];
         col_n = rgb_clamped[FRG_REC * id_n];
         off_n = point_offsets[max(id_n, 1u) - 1u];
     };
     fetch((int)maxc - 1);
-    for (int hi = (int)maxc - 1; hi >= 0; hi -= 64) {
-        const int cnt = min(64, hi + 1);
+    for (int hi = (int)maxc - 1; hi >= seg_lo; hi -= 64) {
+        const int cnt = min(64, hi - seg_lo + 1);
         uint32_t m = 0, my_slot = 0;
         const uint32_t id = id_n;
         const float4 a = a_n, co = co_n, col = col_n;
         const uint32_t off = id == 0 ? 0u : off_n;
-        if (hi >= 64) fetch(hi - 64);             // wave-uniform
+        if (hi - 64 >= seg_lo) fetch(hi - 64);    // wave-uniform
         if (lane < cnt) {
             const uint32_t mypos = (uint32_t)(hi - lane);
             m = quadrant_mask(a.x, a.y, co, tx, ty) &
@@ -549,6 +625,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             if (writer) *dst = sum;
         }
     }
+  }   // next item
 }
 
 
@@ -570,9 +647,8 @@ blend_bwd_quad_kernel(int T, int gx, int gy, int W, int H, const uint2* __restri
                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ bwd_mode)
 {
     using M = BlendMath<EXACT>;
-    if (*bwd_mode == 0u) return;
+    if (bwd_mode[0] == 0u || blockIdx.x >= bwd_mode[1]) return;     // (BwdHdr: the form of this frame, its active tiles)
     const int tile = (int)order[blockIdx.x];
-    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const uint2 rg = ranges[tile];
@@ -736,6 +812,51 @@ blend_bwd_quad_kernel(int T, int gx, int gy, int W, int H, const uint2* __restri
         }
         __syncthreads();             // before the next round rewrites the table and the slot numbers
     }
+}
+
+// ---- launchers (instantiated by blend_exact.hip / blend_fast.hip with their arithmetic) ----------------------------------
+template <bool EXACT>
+static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                     const float* bg, float* out_color, bool prefetch, hipStream_t s)
+{
+    const int T = vp.gx * vp.gy;
+#define FRG_FWD(PF)                                                                                                        \
+    hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
+                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,   \
+                       out_color, img.tile_work, b.ckpt, img.final_C)
+    if (prefetch) FRG_FWD(true); else FRG_FWD(false);
+#undef FRG_FWD
+    return hipGetLastError();
+}
+
+// list_a: room for list_a_cap (tile, segment) items behind the slots (frg_backward_workspace_bytes); waves: the persistent
+// single-wave workgroups of the segmented form (16 per CU fit the LDS)
+#define FRG_BWD_PERSISTENT_WAVES (256 * 16)
+template <bool EXACT, bool TILE_MOM>
+static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
+                                     const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
+                                     int batch, int quad_tiles, hipStream_t s)
+{
+    const int T = vp.gx * vp.gy;
+    // quad_tiles: at most this many active tiles -> the quadrant form (< 0: FRG_BWD_QUAD_TILES; 0: never)
+    const uint32_t qt = quad_tiles < 0 ? (uint32_t)FRG_BWD_QUAD_TILES : (uint32_t)quad_tiles;
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, img.tile_work, img.bwd_order, list_a, list_a_cap, img.bwd_hdr, qt, img.cutoff,
+                       (uint32_t)(FRG_BWD_PERSISTENT_WAVES / FRG_NUM_XCD));
+#define FRG_BWD(B)                                                                                                         \
+    hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B, TILE_MOM>), dim3(FRG_BWD_PERSISTENT_WAVES), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
+                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
+                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_hdr, list_a, img.tile_work, b.ckpt, img.final_C)
+    if (batch == 2) FRG_BWD(2); else FRG_BWD(3);
+#undef FRG_BWD
+    // the quadrant form (timing experiment, option bwd_quad_tiles): one of the two launches finds the mode word against it and leaves
+    const int nquad = (uint32_t)T < qt ? T : (int)qt;
+#define FRG_BWDQ(B)                                                                                                        \
+    hipLaunchKernelGGL((blend_bwd_quad_kernel<EXACT, B, TILE_MOM>), dim3(nquad), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
+                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
+                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_hdr)
+    if (nquad > 0) { if (batch == 2) FRG_BWDQ(2); else FRG_BWDQ(3); }
+#undef FRG_BWDQ
+    return hipGetLastError();
 }
 
 }  // namespace frg

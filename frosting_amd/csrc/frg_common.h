@@ -13,6 +13,10 @@
 #ifndef FRG_SLOT_STRIDE
 #define FRG_SLOT_STRIDE 9   // floats from one instance's slot to the next in the backward workspace
 #endif
+// The backward blend walks a tile's processed list prefix in SEGMENTS of this many entries, each segment an independent
+// work item (blend_impl.h): the forward leaves every pixel's transmittance and accumulated colour at the segment
+// boundaries it crosses (BinningState::ckpt, ImageState::final_C).  A multiple of 64 (the staging round).
+#define FRG_BWD_SEG 1024
 #define FRG_BWD_HEAVY_SLOTS (4 * 896)   // four slot windows of the per-Gaussian backward (preprocess_bwd.hip)
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
@@ -157,8 +161,14 @@ struct ImageState {
     uint32_t* tile_count;    // instances per tile: written by the tile scan (LDS bins) | cleared by the forward's memset and counted with atomics (global bins)
     uint32_t* tile_fill;     // scatter cursor; zero at the start of every forward (colsum_kernel, or the memset of the global-bins path)
     uint32_t* tile_work;     // list entries the forward blend walked (max over the tile's pixels); zeroed like tile_fill
-    uint32_t* bwd_order;     // [xcd_grid_blocks(T)] workgroup -> tile map of the backward blend (longest tiles first)
-    uint32_t* bwd_mode;      // 1: few active tiles, the quadrant form of the backward blend has this frame (bwd_order_kernel)
+    uint32_t* bwd_order;     // [T + 8] the active tiles, per XCD band, by decreasing length of their LAST segment (bwd_order_kernel)
+    // 64 words written by bwd_order_kernel for the backward blend's persistent workgroups (blend_impl.h, BwdHdr): per XCD
+    // the start / count of its full-segment items and of its last-segment items, and the two cursors the workgroups pull from
+    uint32_t* bwd_hdr;
+    // accumulated colour (without the background term) of every pixel of a tile whose walk crossed a segment boundary:
+    // float4[T * 256], quadrant-major like BinningState::ckpt.  The backward blend starts a segment that is not a
+    // pixel's last from S = dL/dC . (final_C - colour accumulated at the segment's end) + T_final (bg . dL/dC)
+    float4* final_C;
     Counters* counters;      // every field written by the forward's kernels (filtered: set-only, cleared when the assertion is on)
     uint2* cutoff;           // per tile: (depth bits, index) of the last instance the backward blend processed
     uint32_t* bin_matrix;    // [FRG_BIN_MAX_BLOCKS][T] per-workgroup tile counts (-> scatter bases when !row_order)
@@ -189,7 +199,8 @@ struct ImageState {
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
         s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
-        s.bwd_mode = (uint32_t*)(base + o); o = align_up(o + 4, 256);
+        s.bwd_hdr = (uint32_t*)(base + o); o = align_up(o + 64 * 4, 256);
+        s.final_C = (float4*)(base + o); o = align_up(o + T * FRG_TILE_PIX * 16, 256);
         s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
         const size_t gy = (size_t)((H + FRG_TILE - 1) / FRG_TILE);
         s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;
@@ -254,6 +265,13 @@ struct BigPlan {
 struct BinningState {
     uint32_t* point_list;    // sorted Gaussian indices, tile-major
     uint2* pairs;            // (depth bits, index), tile-major, scatter order
+    // Forward-blend checkpoints for the segmented backward blend: {T, C0, C1, C2} of every pixel of a tile at the list
+    // positions k * FRG_BWD_SEG (k >= 1) its walk passes -- the state BEFORE entry k * FRG_BWD_SEG is blended.  Record
+    // (first / FRG_BWD_SEG + k) belongs to the tile whose list starts at instance `first`: unique, because a list of n
+    // entries has floor((n - 1) / SEG) boundaries and the next list starts n instances later.  256 float4 per record,
+    // quadrant-major (the forward's wave q writes [q * 64, q * 64 + 64)).  4 bytes per instance; written only where crossed.
+    float4* ckpt;
+    __host__ __device__ static size_t ckpt_records(size_t R) { return R / FRG_BWD_SEG + 2; }
     uint2* pairs_tmp;        // second pair buffer (sorted chunks / ping-pong), only when some tile exceeds the LDS capacity
     uint32_t* big_hist;      // digit counters of the LSD sort of lists beyond FRG_SORT_MID_MAX: one 256-entry row per 1024 elements
     uint32_t* big_plan;      // BigPlan of the splitter sort
@@ -269,6 +287,7 @@ struct BinningState {
         size_t o = 0;
         s.point_list = (uint32_t*)(base + o); o = align_up(o + Rr * 4, 256);
         s.pairs = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
+        s.ckpt = (float4*)(base + o); o = align_up(o + ckpt_records(Rr) * FRG_TILE_PIX * 16, 256);
         s.pairs_tmp = nullptr;
         s.big_hist = nullptr;
         s.big_plan = nullptr;

