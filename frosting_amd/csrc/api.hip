@@ -414,6 +414,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.exchange(value ? 1 : 0);
     if (name && strcmp(name, "fwd_prefetch") == 0) { const int old = frg::g_fwd_prefetch; frg::g_fwd_prefetch = value ? 1 : 0; return old; }
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "bwd_waves") == 0) { const int old = frg::g_bwd_waves; frg::g_bwd_waves = value < 0 ? 0 : value; return old; }
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a

@@ -29,6 +29,7 @@
 // floating-point contraction mode for everything below)
 #pragma once
 #include "frg_common.h"
+#include <algorithm>
 
 namespace frg {
 
@@ -161,14 +162,19 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         col_n = rgb_clamped[FRG_REC * id];
     };
     if (PREFETCH && n > 0) fetch(0);
-    for (int base = 0; base < n; base += 64) {
-        if (wave_ballot(alive != 0.0f) == 0ull) break;   // this quadrant is saturated
-        // A segment boundary of the backward blend (every FRG_BWD_SEG entries; wave-uniform): the state of the quadrant's
-        // pixels BEFORE entry `base` is left for the backward's work item of the segment that ends here (a pixel that has
-        // stopped leaves stale values nobody reads: its last contributor lies in front of the boundary).  1 KB per
-        // quadrant and boundary, contiguous.
-        if (base != 0 && (base & (FRG_BWD_SEG - 1)) == 0)
-            ckpt[((size_t)(rg.x / FRG_BWD_SEG) + (size_t)(base / FRG_BWD_SEG)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
+    // The list is walked segment by segment (FRG_BWD_SEG entries: the work items of the backward blend).  At every
+    // boundary the quadrant crosses, the state of its pixels BEFORE the segment's first entry is left for the backward's
+    // item of the segment that ends there (a pixel that has stopped leaves stale values nobody reads: its last contributor
+    // lies in front of the boundary): 1 KB per quadrant and boundary, contiguous.  The inner loop is the loop of rounds 1-3.
+    bool saturated = false;
+    for (int sbase = 0; sbase < n && !saturated; sbase += FRG_BWD_SEG) {
+    if (sbase != 0) {
+        if (wave_ballot(alive != 0.0f) == 0ull) break;
+        ckpt[((size_t)(rg.x / FRG_BWD_SEG) + (size_t)(sbase / FRG_BWD_SEG)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
+    }
+    const int send = min(n, sbase + FRG_BWD_SEG);
+    for (int base = sbase; base < send; base += 64) {
+        if (wave_ballot(alive != 0.0f) == 0ull) { saturated = true; break; }   // this quadrant is saturated
         const int cnt = min(64, n - base);
         bool hit = false;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
@@ -214,6 +220,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
         }
     }
+    }
 
     if (inside) {
         const size_t plane = (size_t)H * W;
@@ -242,19 +249,25 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
 // bwd_order_kernel (one workgroup) builds, per XCD band of tiles (neighbouring tiles share their Gaussians: same L2),
 //   list A  the FULL segments (tile, k), k < nseg - 1: all the same length, longest items of the frame, pulled first;
 //   list B  every active tile's LAST segment, by decreasing length in 32 buckets;
-// and the header the persistent workgroups of blend_bwd_kernel pull from (BwdHdr).  Tiles in which the forward blended
-// nothing get their cutoff key cleared here (the per-Gaussian backward must not find an earlier frame's).
+// and the header blend_bwd_kernel's waves find their items through (BwdHdr).  The assignment is STATIC: XCD x's waves
+// stride over its items (A then B, one index space) -- no work queue: 4096 waves pulling from eight cursors with
+// device-scope atomics, which execute behind the XCDs' L2s one at a time per address, took 0.55 instead of 0.41 ms at C3.
+// What keeps the XCDs even is the header's pool: every XCD is given the same number of items (m = N / 8), an XCD with
+// more than that donates its LAST (shortest) ones, one with fewer takes from the pool.  Tiles in which the forward
+// blended nothing get their cutoff key cleared here (the per-Gaussian backward must not find an earlier frame's).
 struct BwdHdr {
-    // word 0: 1 = few active tiles, the quadrant form has this frame | 1: active tiles | 2: items in list A (all XCDs)
-    // words 8 + 4 x ..: A start, A count, B start, B count of XCD x | word 40 + 2 x: the cursor of XCD x (A then B, one index space)
-    __device__ static uint32_t* lists(uint32_t* h, int x) { return h + 8 + 4 * x; }
-    __device__ static uint32_t* cursors(uint32_t* h, int x) { return h + 40 + 2 * x; }
+    // word 0: 1 = few active tiles and the quadrant form asked for | 1: active tiles | 2: items in all
+    // words 8 + 8 x ..: A start, A count, B start, B count, m (items this XCD's waves process), its first pool index
+    //                   (when it has fewer than m of its own), the pool index of its first donated item (when more)
+    __host__ __device__ static int words() { return 8 + 8 * FRG_NUM_XCD; }
+    __device__ static const uint32_t* xcd(const uint32_t* h, int x) { return h + 8 + 8 * x; }
+    __device__ static uint32_t* xcd(uint32_t* h, int x) { return h + 8 + 8 * x; }
 };
 #define FRG_BWD_QUAD_TILES 0     // the quadrant form is a timing experiment now (option bwd_quad_tiles): segments balance what it balanced
 #define FRG_BWD_LEN_BUCKETS 32
 static __global__ void __launch_bounds__(1024)
 bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order, uint2* __restrict__ list_a,
-                 uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint32_t quad_tiles, uint2* __restrict__ cutoff, uint32_t waves_per_xcd)
+                 uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint32_t quad_tiles, uint2* __restrict__ cutoff)
 {
     __shared__ uint32_t base[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS], cur[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS];
     __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD];
@@ -286,16 +299,24 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
     if (tid == 0) {
         uint32_t run = 0, arun = 0;
         for (int x = 0; x < FRG_NUM_XCD; x++) {
-            uint32_t* l = BwdHdr::lists(hdr, x);
+            uint32_t* l = BwdHdr::xcd(hdr, x);
             l[2] = run;
             for (int k = 0; k < FRG_BWD_LEN_BUCKETS; k++) { const uint32_t c = base[x * FRG_BWD_LEN_BUCKETS + k]; base[x * FRG_BWD_LEN_BUCKETS + k] = run; run += c; }
             l[3] = run - l[2];
             // (the caller sizes list A for R / SEG items, which bounds their number; the clamp only guards the buffer)
             const uint32_t ac = min(a_cnt[x], list_a_cap - min(list_a_cap, arun));
             a_base[x] = arun; l[0] = arun; l[1] = ac; arun += ac;
-            BwdHdr::cursors(hdr, x)[0] = waves_per_xcd;     // the persistent waves' first items are static
         }
-        hdr[0] = quad ? 1u : 0u; hdr[1] = n_active; hdr[2] = arun;
+        // even shares: m_x = N / 8 (+ 1 for the first N % 8); donors' excess and takers' deficits line up in one pool
+        const uint32_t N = run + arun;
+        uint32_t taken = 0, given = 0;
+        for (int x = 0; x < FRG_NUM_XCD; x++) {
+            uint32_t* l = BwdHdr::xcd(hdr, x);
+            const uint32_t own = l[1] + l[3], m = N / FRG_NUM_XCD + ((uint32_t)x < N % FRG_NUM_XCD ? 1u : 0u);
+            l[4] = m; l[5] = taken; l[6] = given; l[7] = 0;
+            if (own < m) taken += m - own; else given += own - m;
+        }
+        hdr[0] = quad ? 1u : 0u; hdr[1] = n_active; hdr[2] = N;
     }
     __syncthreads();
     for (int t = tid; t < T; t += 1024) {
@@ -307,7 +328,7 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
         if (!quad && wk > (uint32_t)FRG_BWD_SEG) {
             const uint32_t nfull = (wk - 1u) / FRG_BWD_SEG, at = atomicAdd(&a_cur[x], nfull);
             for (uint32_t sgm = 0; sgm < nfull; sgm++)
-                if (at + sgm < BwdHdr::lists(hdr, x)[1]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
+                if (at + sgm < BwdHdr::xcd(hdr, x)[1]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
         }
     }
 }
@@ -360,7 +381,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                  const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order,
-                 uint32_t* __restrict__ hdr, const uint2* __restrict__ list_a, const uint32_t* __restrict__ tile_work,
+                 const uint32_t* __restrict__ hdr, const uint2* __restrict__ list_a, const uint32_t* __restrict__ tile_work,
                  const float4* __restrict__ ckpt, const float4* __restrict__ final_C)
 {
     using M = BlendMath<EXACT>;
@@ -379,37 +400,38 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t plane = (size_t)H * W;
 
-    // ---- the item loop ----
-    // Items of XCD x = its list A followed by its list B, one index space, one cursor.  A wave's FIRST item is static
-    // (index blockIdx / 8 of its own XCD: the cursors start at the number of waves per XCD), every later one is pulled
-    // with an atomic -- behind a plain load of the cursor: 4096 waves polling sixteen exhausted cursors with atomics
-    // serialise in the L2 (measured: the kernel took 1.39 instead of 0.40 ms).
+    // ---- the item loop: static, no queue (see BwdHdr) ----
+    // Wave w of the W waves of XCD x takes the items k = r W + w (r even) / r W + (W - 1 - w) (r odd) of its XCD's m
+    // items, r = 0, 1, ...: the items are in decreasing length, so the boustrophedon gives the wave with the longest
+    // item of one round the shortest of the next.  The grid is usually larger than the frame has items (every wave then
+    // has at most one: the hardware's dispatcher does the balancing, as it did with one workgroup per tile).
     const int my_xcd = (int)(blockIdx.x % FRG_NUM_XCD);
-    int probe = 0;                 // own XCD first, then the others' leftovers
-    bool first = true;
-  for (;;) {
+    const uint32_t W_ = gridDim.x / FRG_NUM_XCD, w_ = blockIdx.x / FRG_NUM_XCD;
+    const uint32_t* mine = BwdHdr::xcd(hdr, my_xcd);
+    const uint32_t my_own = mine[1] + mine[3], my_m = mine[4], my_pool = mine[5];
+  for (uint32_t round = 0; round * W_ < my_m; round++) {
+    const uint32_t k = round * W_ + ((round & 1u) ? W_ - 1u - w_ : w_);
+    if (k >= my_m) continue;        // (the last, partial round)
+    // item k of this XCD: one of its own, or -- an XCD with fewer than its share -- one from the pool of the others' excess
+    int src = my_xcd;
+    uint32_t ks = k;
+    if (k >= my_own) {
+        uint32_t j = my_pool + (k - my_own);
+        src = -1;
+        for (int d = 0; d < FRG_NUM_XCD; d++) {
+            const uint32_t* o = BwdHdr::xcd(hdr, d);
+            const uint32_t own = o[1] + o[3], m = o[4];
+            if (own > m && j >= o[6] && j < o[6] + (own - m)) { src = d; ks = m + (j - o[6]); }
+        }
+    }
     int tile = -1;
     uint32_t seg = 0, walked = 0;
-    while (probe < FRG_NUM_XCD) {           // wave-uniform
-        const int x = (my_xcd + probe) % FRG_NUM_XCD;
-        const uint32_t* l = BwdHdr::lists(hdr, x);
-        const uint32_t na = l[1], total = na + l[3];
-        uint32_t k = 0xFFFFFFFFu;
-        if (first) k = blockIdx.x / FRG_NUM_XCD;
-        else if (lane == 0) {
-            uint32_t* cursor = BwdHdr::cursors(hdr, x);
-            if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) k = atomicAdd(cursor, 1u);
-        }
-        first = false;
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-        if (k < total) {
-            if (k < na) { const uint2 it = list_a[l[0] + k]; tile = (int)it.x; seg = it.y; walked = tile_work[tile]; }
-            else { tile = (int)order[l[2] + (k - na)]; walked = tile_work[tile]; seg = (walked - 1u) / FRG_BWD_SEG; }
-            break;
-        }
-        probe++;
+    if (src >= 0) {
+        const uint32_t* l = BwdHdr::xcd(hdr, src);
+        if (ks < l[1]) { const uint2 it = list_a[l[0] + ks]; tile = (int)it.x; seg = it.y; walked = tile_work[tile]; }
+        else { tile = (int)order[l[2] + (ks - l[1])]; walked = tile_work[tile]; seg = (walked - 1u) / FRG_BWD_SEG; }
     }
-    if (tile < 0) return;
+    if (tile < 0) continue;         // (cannot happen: the pool is exactly the excess)
     const int tx = tile % gx, ty = tile / gx;
     const uint2 rg = ranges[tile];
     const int seg_lo = (int)(seg * FRG_BWD_SEG);
@@ -831,7 +853,8 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 
 // list_a: room for list_a_cap (tile, segment) items behind the slots (frg_backward_workspace_bytes); waves: the persistent
 // single-wave workgroups of the segmented form (16 per CU fit the LDS)
-#define FRG_BWD_PERSISTENT_WAVES (256 * 16)
+#define FRG_BWD_MAX_WAVES 8192      // measured at C3 / C4: 2048 0.69 / 0.56 ms, 4096 (= what is resident at once) 0.55 / 0.39 with a queue, 8192 and 16384 0.41 / 0.39
+extern int g_bwd_waves;       // tuning (frg_set_option("bwd_waves")): single-wave workgroups of the backward blend (0: the default)
 template <bool EXACT, bool TILE_MOM>
 static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                      const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
@@ -840,10 +863,13 @@ static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, c
     const int T = vp.gx * vp.gy;
     // quad_tiles: at most this many active tiles -> the quadrant form (< 0: FRG_BWD_QUAD_TILES; 0: never)
     const uint32_t qt = quad_tiles < 0 ? (uint32_t)FRG_BWD_QUAD_TILES : (uint32_t)quad_tiles;
-    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, img.tile_work, img.bwd_order, list_a, list_a_cap, img.bwd_hdr, qt, img.cutoff,
-                       (uint32_t)(FRG_BWD_PERSISTENT_WAVES / FRG_NUM_XCD));
+    // waves: one per item while the frame has at most FRG_BWD_MAX_WAVES items (an upper bound on their number: one last
+    // segment per tile + R / SEG full ones), beyond that the waves stride
+    const int bound = (int)std::min<size_t>((size_t)T + list_a_cap, (size_t)FRG_BWD_MAX_WAVES);
+    const int nwaves = ((g_bwd_waves > 0 ? g_bwd_waves : bound) + 7) / 8 * 8;
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, img.tile_work, img.bwd_order, list_a, list_a_cap, img.bwd_hdr, qt, img.cutoff);
 #define FRG_BWD(B)                                                                                                         \
-    hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B, TILE_MOM>), dim3(FRG_BWD_PERSISTENT_WAVES), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
+    hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B, TILE_MOM>), dim3(nwaves), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
                        img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_hdr, list_a, img.tile_work, b.ckpt, img.final_C)
     if (batch == 2) FRG_BWD(2); else FRG_BWD(3);

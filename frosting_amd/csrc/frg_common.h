@@ -162,8 +162,8 @@ struct ImageState {
     uint32_t* tile_fill;     // scatter cursor; zero at the start of every forward (colsum_kernel, or the memset of the global-bins path)
     uint32_t* tile_work;     // list entries the forward blend walked (max over the tile's pixels); zeroed like tile_fill
     uint32_t* bwd_order;     // [T + 8] the active tiles, per XCD band, by decreasing length of their LAST segment (bwd_order_kernel)
-    // 64 words written by bwd_order_kernel for the backward blend's persistent workgroups (blend_impl.h, BwdHdr): per XCD
-    // the start / count of its full-segment items and of its last-segment items, and the two cursors the workgroups pull from
+    // written by bwd_order_kernel for the backward blend's waves (blend_impl.h, BwdHdr): per XCD the start / count of its
+    // full-segment items and of its last-segment items, its share of the frame's items and its place in the pool that evens the shares
     uint32_t* bwd_hdr;
     // accumulated colour (without the background term) of every pixel of a tile whose walk crossed a segment boundary:
     // float4[T * 256], quadrant-major like BinningState::ckpt.  The backward blend starts a segment that is not a
@@ -199,7 +199,7 @@ struct ImageState {
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
         s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
-        s.bwd_hdr = (uint32_t*)(base + o); o = align_up(o + 64 * 4, 256);
+        s.bwd_hdr = (uint32_t*)(base + o); o = align_up(o + 128 * 4, 256);     // (BwdHdr::words() = 72)
         s.final_C = (float4*)(base + o); o = align_up(o + T * FRG_TILE_PIX * 16, 256);
         s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
         const size_t gy = (size_t)((H + FRG_TILE - 1) / FRG_TILE);

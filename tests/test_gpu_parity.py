@@ -664,6 +664,11 @@ def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
     _lib.set_option("bwd_quad_tiles", 1 << 30)
     quad2 = _C.rasterize_gaussians_backward(*b2)
     assert not all(torch.equal(x, y) for x, y in zip(auto2, quad2))     # (the forms differ in the last bits)
+    _lib.set_option("bwd_quad_tiles", -1)
+    # ... and it is right there: all the frame's work items belong to the tiles of one or two XCD bands, so most waves
+    # take theirs from the pool that evens the XCDs' shares (BwdHdr, blend_impl.h)
+    _check_against_reference_rasterizer(gpu_device, small, cam, bg, _C, "corner frame")
+    _lib.set_option("exact_blend", exact)
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
