@@ -50,8 +50,6 @@ std::atomic<int> g_global_bins{0};    // test hook: force the large-image (globa
 std::atomic<int> g_ablate{0};         // TIMING EXPERIMENTS ONLY: kernels skip parts of their work (results are wrong)
 std::atomic<int> g_async_sh{0};       // SH colours on a side stream beside the binning stages (0: inside preprocess)
 std::atomic<int> g_bwd_batch{3};      // tuning: instances per reduction step of the backward blend (2 | 3)
-// backward blend: quadrant form at or below this many active tiles (-1: FRG_BWD_QUAD_TILES; 0: never); FROSTING_BWD_QUAD_TILES presets it
-std::atomic<int> g_bwd_quad{[] { const char* e = getenv("FROSTING_BWD_QUAD_TILES"); return e ? atoi(e) : -1; }()};
 std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
 // TIMING EXPERIMENTS ONLY (results are those of the previous frame's lists / slots): bit 0 launches the forward blend
 // beside the sort, bit 1 the per-Gaussian backward beside the backward blend -- an upper bound on what overlapping
@@ -409,7 +407,6 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
-    if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.exchange(value < 0 ? -1 : value);
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.exchange(value ? 1 : 0);
     if (name && strcmp(name, "fwd_prefetch") == 0) { const int old = frg::g_fwd_prefetch; frg::g_fwd_prefetch = value ? 1 : 0; return old; }
@@ -419,8 +416,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
     // stray call must not be able to switch them on -- they exist only in processes started with FROSTING_EXPERIMENTS=1
-    if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0 || strcmp(name, "bwd_tile_moments") == 0 ||
-                 strcmp(name, "assume_no_heavy") == 0)) {
+    if (name && (strcmp(name, "ablate") == 0 || strcmp(name, "probe") == 0 || strcmp(name, "rows_grid") == 0 || strcmp(name, "assume_no_heavy") == 0)) {
         static const bool experiments = [] { const char* e = getenv("FROSTING_EXPERIMENTS"); return e && e[0] == '1'; }();
         if (!experiments)
             return fail(FRG_EINVAL, "option '%s' is a timing experiment (results are wrong by design): start the process with "
@@ -428,7 +424,6 @@ int frg_set_option(const char* name, int value)
         if (strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
         if (strcmp(name, "probe") == 0) return g_probe.exchange(value);
         if (strcmp(name, "assume_no_heavy") == 0) return g_assume_no_heavy.exchange(value ? 1 : 0);
-        if (strcmp(name, "bwd_tile_moments") == 0) { const int old = frg::g_bwd_tile_moments; frg::g_bwd_tile_moments = value ? 1 : 0; return old; }
         const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old;
     }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
@@ -467,7 +462,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.load();
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
-    if (name && strcmp(name, "bwd_quad_tiles") == 0) return g_bwd_quad.load();
+    if (name && strcmp(name, "bwd_waves") == 0) return frg::g_bwd_waves;
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
     if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.load();
     if (name && strcmp(name, "fwd_prefetch") == 0) return frg::g_fwd_prefetch;
@@ -873,7 +868,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
     out.dL_dshell_logits = dL_dshell_logits;
     out.dL_dshell_verts = dL_dshell_verts;
-    const int pbw_flags = (!exact && frg::g_bwd_tile_moments) ? FRG_PBW_TILE_MOMENTS : 0;
+    const int pbw_flags = 0;
     const bool probe_bwd = (g_probe.load() & 2) && g_probe_side.ensure();
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
@@ -885,9 +880,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), g_bwd_quad.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
     {

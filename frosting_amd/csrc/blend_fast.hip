@@ -4,7 +4,6 @@
 #include "blend_impl.h"
 #include "kernels.h"
 namespace frg {
-int g_bwd_tile_moments = 0;   // TIMING EXPERIMENT (frg_set_option("bwd_tile_moments"), FROSTING_EXPERIMENTS=1): round 3's moments about the tile centre
 int g_bwd_waves = 0;
 int g_fwd_prefetch = 1;   // frg_set_option("fwd_prefetch"): forward blend requests round r + 1's records before it processes round r
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
@@ -15,9 +14,8 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
 
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                  const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                 int batch, int quad_tiles, hipStream_t s)
+                                 int batch, hipStream_t s)
 {
-    if (g_bwd_tile_moments) return launch_blend_bwd_t<false, true>(vp, g, img, b, bg, dL_dpix, slots, list_a, list_a_cap, batch, quad_tiles, s);
-    return launch_blend_bwd_t<false, false>(vp, g, img, b, bg, dL_dpix, slots, list_a, list_a_cap, batch, quad_tiles, s);
+    return launch_blend_bwd_t<false>(vp, g, img, b, bg, dL_dpix, slots, list_a, list_a_cap, batch, s);
 }
 }  // namespace frg

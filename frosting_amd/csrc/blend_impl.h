@@ -5,9 +5,10 @@
 //     quadrants of one tile; its waves never synchronise with each other), one pixel per
 //     lane: 45 VGPRs, so 8 waves per SIMD hide the LDS / transcendental latency of the
 //     per-Gaussian dependent chain, and a quadrant that saturates retires on its own;
-//   * BACKWARD: one wave per TILE, four pixels per lane (one per quadrant): the nine
-//     gradient components of a (tile, Gaussian) pair are first summed over the lane's
-//     pixels, so the cross-lane reduction -- the single most expensive step -- is paid once
+//   * BACKWARD: one wave per SEGMENT of a tile's processed list prefix (FRG_BWD_SEG entries; the forward
+//     leaves the pixels' state at the boundaries, so a segment starts anywhere), four pixels per lane
+//     (one per quadrant): the nine gradient components of a (tile, Gaussian) pair are first summed over
+//     the lane's pixels, so the cross-lane reduction -- the single most expensive step -- is paid once
 //     per tile instance instead of once per quadrant instance (measured: 0.72 vs 0.79 ms);
 //   * instances are staged 64 at a time through wave-private LDS from 16-byte
 //     per-Gaussian records (three global_load_dwordx4 gathers per instance);
@@ -16,9 +17,9 @@
 //     wave compacts the staged list by ballot.  The reference's tile lists are 3-sigma
 //     squares: more than half of the (quadrant, Gaussian) pairs never reach alpha >= 1/255,
 //     and they are dropped while every pixel keeps exactly its value;
-//   * the backward reduction folds two Gaussians at a time (v_permlane32_swap + one DPP
-//     tree) and stores each (tile, Gaussian) gradient ONCE, without atomics, in the
-//     instance's Gaussian-major slot; the per-Gaussian backward kernel sums the slots in a
+//   * the backward reduction takes the 27 partial sums of three instances through an LDS
+//     matrix (one column per lane) and stores each (tile, Gaussian) gradient ONCE, without
+//     atomics, in the instance's Gaussian-major slot; the per-Gaussian backward kernel sums the slots in a
 //     fixed order.  The reference issues 9 global float atomics per (pixel, Gaussian)
 //     pair (backward.cu:523,545-554) and is not reproducible run to run.
 //
@@ -256,18 +257,17 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
 // more than that donates its LAST (shortest) ones, one with fewer takes from the pool.  Tiles in which the forward
 // blended nothing get their cutoff key cleared here (the per-Gaussian backward must not find an earlier frame's).
 struct BwdHdr {
-    // word 0: 1 = few active tiles and the quadrant form asked for | 1: active tiles | 2: items in all
+    // word 0: unused | 1: active tiles | 2: items in all
     // words 8 + 8 x ..: A start, A count, B start, B count, m (items this XCD's waves process), its first pool index
     //                   (when it has fewer than m of its own), the pool index of its first donated item (when more)
     __host__ __device__ static int words() { return 8 + 8 * FRG_NUM_XCD; }
     __device__ static const uint32_t* xcd(const uint32_t* h, int x) { return h + 8 + 8 * x; }
     __device__ static uint32_t* xcd(uint32_t* h, int x) { return h + 8 + 8 * x; }
 };
-#define FRG_BWD_QUAD_TILES 0     // the quadrant form is a timing experiment now (option bwd_quad_tiles): segments balance what it balanced
 #define FRG_BWD_LEN_BUCKETS 32
 static __global__ void __launch_bounds__(1024)
 bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order, uint2* __restrict__ list_a,
-                 uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint32_t quad_tiles, uint2* __restrict__ cutoff)
+                 uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint2* __restrict__ cutoff)
 {
     __shared__ uint32_t base[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS], cur[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS];
     __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD];
@@ -284,16 +284,14 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
     }
     if (mine) atomicAdd(&n_active, mine);
     __syncthreads();
-    const bool quad = n_active <= quad_tiles;
     // last segment of tile t: entries (tile_work - 1) % SEG + 1; bucket 0 = the longest
-    auto quad_bucket_of = [](uint32_t wk) { return (FRG_BWD_LEN_BUCKETS - 1) - (int)min((uint32_t)(FRG_BWD_LEN_BUCKETS - 1), wk >> 7); };   // (quadrant form: whole tiles, deepest first)
     auto bucket_of = [](uint32_t wk) { return (FRG_BWD_LEN_BUCKETS - 1) - (((wk - 1u) % FRG_BWD_SEG) * FRG_BWD_LEN_BUCKETS) / FRG_BWD_SEG; };
     for (int t = tid; t < T; t += 1024) {
         const uint32_t wk = tile_work[t];
         if (!wk) continue;
-        const int x = quad ? 0 : xcd_of_tile(t, T);
-        atomicAdd(&base[x * FRG_BWD_LEN_BUCKETS + (quad ? quad_bucket_of(wk) : bucket_of(wk))], 1u);
-        if (!quad && wk > (uint32_t)FRG_BWD_SEG) atomicAdd(&a_cnt[x], (wk - 1u) / FRG_BWD_SEG);
+        const int x = xcd_of_tile(t, T);
+        atomicAdd(&base[x * FRG_BWD_LEN_BUCKETS + bucket_of(wk)], 1u);
+        if (wk > (uint32_t)FRG_BWD_SEG) atomicAdd(&a_cnt[x], (wk - 1u) / FRG_BWD_SEG);
     }
     __syncthreads();
     if (tid == 0) {
@@ -316,16 +314,16 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
             l[4] = m; l[5] = taken; l[6] = given; l[7] = 0;
             if (own < m) taken += m - own; else given += own - m;
         }
-        hdr[0] = quad ? 1u : 0u; hdr[1] = n_active; hdr[2] = N;
+        hdr[0] = 0u; hdr[1] = n_active; hdr[2] = N;
     }
     __syncthreads();
     for (int t = tid; t < T; t += 1024) {
         const uint32_t wk = tile_work[t];
         if (!wk) continue;
-        const int x = quad ? 0 : xcd_of_tile(t, T);
-        const int k = quad ? quad_bucket_of(wk) : bucket_of(wk);
+        const int x = xcd_of_tile(t, T);
+        const int k = bucket_of(wk);
         order[base[x * FRG_BWD_LEN_BUCKETS + k] + atomicAdd(&cur[x * FRG_BWD_LEN_BUCKETS + k], 1u)] = (uint32_t)t;
-        if (!quad && wk > (uint32_t)FRG_BWD_SEG) {
+        if (wk > (uint32_t)FRG_BWD_SEG) {
             const uint32_t nfull = (wk - 1u) / FRG_BWD_SEG, at = atomicAdd(&a_cur[x], nfull);
             for (uint32_t sgm = 0; sgm < nfull; sgm++)
                 if (at + sgm < BwdHdr::xcd(hdr, x)[1]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
@@ -373,7 +371,7 @@ __device__ __forceinline__ float fold_two(float a, float b)
 // One wave per workgroup, PERSISTENT: it pulls (tile, segment) items from the lists of its XCD (bwd_order_kernel) -- the
 // full segments first, then the tiles' last segments by decreasing length -- and, when those are empty, from the other
 // XCDs' lists.  An item walks the list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
-template <bool EXACT, int BWD_BATCH, bool TILE_MOM = false>
+template <bool EXACT, int BWD_BATCH>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
@@ -385,7 +383,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const float4* __restrict__ ckpt, const float4* __restrict__ final_C)
 {
     using M = BlendMath<EXACT>;
-    if (hdr[0] != 0u) return;     // few active tiles and the quadrant form asked for: blend_bwd_quad_kernel has this frame
     const int lane = threadIdx.x;
 
     __shared__ float4 s_a[64];     // x, y, quadrant mask, 0-based list position
@@ -448,16 +445,12 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     // A pixel whose last contributor lies behind this segment starts from the forward's checkpoint at the segment's
     // end: T = the transmittance there, colour behind = (colour the pixel ended with) - (colour accumulated there).
     float pxf[4], pyf[4], Tr[4], S[4], dLp[4][3];
-    // timing experiment (TILE_MOM): round 3's moments about the tile centre
-    float pu[4], pw[4], puu[4], puw[4], pww[4];
     uint32_t lastcon[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int px, py;
         lane_pixel(lane, q, tx, ty, px, py);
         pxf[q] = (float)px; pyf[q] = (float)py;
-        pu[q] = (float)(px - tx * FRG_TILE) - 7.5f; pw[q] = (float)(py - ty * FRG_TILE) - 7.5f;   // exact: multiples of 1/2
-        puu[q] = pu[q] * pu[q]; puw[q] = pu[q] * pw[q]; pww[q] = pw[q] * pw[q];
         const bool inside = px < W && py < H;
         const size_t pid = (size_t)py * W + px;
         Tr[q] = inside ? final_T[pid] : 0.0f;
@@ -597,20 +590,16 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                     const float dL_dalpha = M::mad(Tr[q], cdot, -(S[q] * rinv));
                     S[q] = M::mad(w, cdot, S[q]);
                     const float v = g_eff * dL_dalpha;
-                    if (!TILE_MOM) {       // about the Gaussian's centre, the reference's d (backward.cu:441,536-554)
-                        const float vx = v * dx, vy = v * dy;
-                        part[3] += vx;
-                        part[4] += vy;
-                        part[5] = M::mad(vx, dx, part[5]);
-                        part[6] = M::mad(vx, dy, part[6]);
-                        part[7] = M::mad(vy, dy, part[7]);
-                    } else {
-                        part[3] = __builtin_fmaf(v, pu[q], part[3]);
-                        part[4] = __builtin_fmaf(v, pw[q], part[4]);
-                        part[5] = __builtin_fmaf(v, puu[q], part[5]);
-                        part[6] = __builtin_fmaf(v, puw[q], part[6]);
-                        part[7] = __builtin_fmaf(v, pww[q], part[7]);
-                    }
+                    // moments about the Gaussian's centre, the reference's d (backward.cu:441,536-554), in both arithmetics.
+                    // (Round 3's default arithmetic took them about the TILE centre -- one FMA each on per-lane constants, 6
+                    // instead of 8 instructions -- and shifted every slot to its Gaussian afterwards: 5 us faster at C3, and
+                    // up to 5 x farther from the float64 gradient on sparse frames, profiles/r04_sparse_grad_check_with_r03_forms.log.)
+                    const float vx = v * dx, vy = v * dy;
+                    part[3] += vx;
+                    part[4] += vy;
+                    part[5] = M::mad(vx, dx, part[5]);
+                    part[6] = M::mad(vx, dy, part[6]);
+                    part[7] = M::mad(vy, dy, part[7]);
                     part[8] += v;
                 }
             }
@@ -651,191 +640,6 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 }
 
 
-// ---------------------------------------------------------------------------
-// The backward blend with FOUR waves per tile (one per 8x8 quadrant, one pixel per lane), for frames with few active
-// tiles (bwd_order_kernel decides).  Same mathematics, same slots: each wave reduces the nine partial sums of its
-// quadrant's pixels exactly as the tile-per-wave form reduces a tile's (through its own LDS matrix), leaves them in a
-// [entry][quadrant][9] table, and after a workgroup barrier per round of 64 list entries the table is summed over the
-// quadrants in a fixed order ((q0 + q1) + q2) + q3 and stored: deterministic, no atomics, one store per slot value.
-// The per-wave critical path -- what bounds such a frame -- is a quarter of the tile-per-wave form's.
-template <bool EXACT, int BWD_BATCH, bool TILE_MOM = false>
-__global__ void __launch_bounds__(BLEND_THREADS)
-blend_bwd_quad_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
-                      const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
-                      const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
-                      const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
-                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff,
-                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ bwd_mode)
-{
-    using M = BlendMath<EXACT>;
-    if (bwd_mode[0] == 0u || blockIdx.x >= bwd_mode[1]) return;     // (BwdHdr: the form of this frame, its active tiles)
-    const int tile = (int)order[blockIdx.x];
-    const int tx = tile % gx, ty = tile / gx;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const uint2 rg = ranges[tile];
-
-    __shared__ float4 s_a_all[4][64];      // x, y, entry of the round (0 = deepest), 0-based list position
-    __shared__ float4 s_co_all[4][64];
-    __shared__ float4 s_rgb_all[4][64];
-    __shared__ __attribute__((aligned(16))) float s_red_all[4][BWD_BATCH * FRG_SLOT_FLOATS * 64];
-    __shared__ float s_res[64][4][FRG_SLOT_FLOATS];   // per entry of the round and quadrant: the reduced partials
-    __shared__ uint32_t s_slot[64];
-    __shared__ uint32_t s_qmax[4];
-    float4* s_a = s_a_all[q];
-    float4* s_co = s_co_all[q];
-    float4* s_rgb = s_rgb_all[q];
-    float* s_red = s_red_all[q];
-
-    const int qx0 = tx * FRG_TILE + (q & 1) * 8, qy0 = ty * FRG_TILE + (q >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const float pxf = (float)px, pyf = (float)py;
-    const float pu = (float)(px - tx * FRG_TILE) - 7.5f, pw = (float)(py - ty * FRG_TILE) - 7.5f;   // offset from the tile centre
-    const float puu = pu * pu, puw = pu * pw, pww = pw * pw;
-    const bool inside = px < W && py < H;
-    const size_t plane = (size_t)H * W, pid = (size_t)py * W + px;
-    float Tr = inside ? final_T[pid] : 0.0f;
-    const uint32_t lastcon = inside ? n_contrib[pid] : 0u;
-    float dLp[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) dLp[ch] = inside ? dL_dpix[ch * plane + pid] : 0.0f;
-    float S = Tr * M::mad(bg[2], dLp[2], M::mad(bg[1], dLp[1], bg[0] * dLp[0]));
-    uint32_t qmax = lastcon;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) qmax = max(qmax, (uint32_t)__shfl_xor((int)qmax, d, 64));
-    if (lane == 0) s_qmax[q] = qmax;
-    __syncthreads();
-    const uint32_t maxc = max(max(s_qmax[0], s_qmax[1]), max(s_qmax[2], s_qmax[3]));
-    if (maxc == 0) {                       // workgroup-uniform
-        if (threadIdx.x == 0) cutoff[tile] = make_uint2(0u, 0u);
-        return;
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t id = point_list[rg.x + maxc - 1];
-        cutoff[tile] = make_uint2(__float_as_uint(xydr[FRG_REC * id].z), id);
-    }
-
-    uint32_t id_n = 0, off_n = 0;
-    float4 a_n, co_n, col_n;
-    auto fetch = [&](int hi) {
-        id_n = point_list[rg.x + max(hi - lane, 0)];
-        a_n = xydr[FRG_REC * id_n];
-        co_n = conic_opacity[FRG_REC * id_n];
-        col_n = rgb_clamped[FRG_REC * id_n];
-        off_n = point_offsets[max(id_n, 1u) - 1u];
-    };
-    fetch((int)maxc - 1);
-    for (int hi = (int)maxc - 1; hi >= 0; hi -= 64) {
-        const int cnt = min(64, hi + 1);
-        const uint32_t id = id_n;
-        const float4 a = a_n, co = co_n, col = col_n;
-        const uint32_t off = id == 0 ? 0u : off_n;
-        if (hi >= 64) fetch(hi - 64);             // workgroup-uniform
-        bool hit = false;
-        if (lane < cnt) {
-            const uint32_t mypos = (uint32_t)(hi - lane);
-            hit = mypos < qmax && quadrant_hit(a.x, a.y, co, qx0, qy0);
-            if (q == 0) {   // Gaussian-major slot of this (Gaussian, tile) instance (rasterizer_impl.cu:98-108 emission order)
-                int x0, y0, x1, y1;
-                tile_rect(a.x, a.y, (int)a.w, gx, gy, x0, y0, x1, y1);
-                s_slot[lane] = off + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-            }
-        }
-        // this quadrant's column of the round's table starts at zero: entries it culls or never blends contribute nothing
-#pragma unroll
-        for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_res[lane][q][c] = 0.0f;
-        const uint64_t keep = wave_ballot(hit);
-        const int nkeep = __popcll(keep);
-        wave_lds_sync();                          // (the previous round's readers passed the workgroup barrier below)
-        if (hit) {
-            const int d = lanes_before(keep, lane);
-            s_a[d] = make_float4(a.x, a.y, __uint_as_float((uint32_t)lane), __uint_as_float((uint32_t)(hi - lane)));
-            s_co[d] = M::stage(co);
-            s_rgb[d] = col;
-        }
-        wave_lds_sync();
-        for (int k = 0; k < nkeep; k += BWD_BATCH) {
-            float acc[BWD_BATCH][FRG_SLOT_FLOATS];
-#pragma unroll
-            for (int h = 0; h < BWD_BATCH; h++)
-#pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) { acc[h][c] = 0.0f; asm volatile("" : "+v"(acc[h][c])); }
-            bool any = false;
-#pragma unroll
-            for (int h = 0; h < BWD_BATCH; h++) {
-                const int kk = k + h;
-                if (kk >= nkeep) break;
-                float* part = acc[h];
-                const float4 ca = s_a[kk], cco = s_co[kk];
-                const uint32_t pos = __float_as_uint(ca.w);
-                const float4 gc = s_rgb[kk];
-                float dx, dy;
-                const float power = M::power(ca.x, ca.y, cco, pxf, pyf, dx, dy);
-                const float G = M::expo(power);
-                const float alpha = fminf(0.99f, cco.w * G);
-                const bool ok = pos < lastcon && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (wave_ballot(ok) == 0ull) continue;       // wave-uniform
-                any = true;
-                const float a_eff = ok ? alpha : 0.0f, g_eff = ok ? G : 0.0f;
-                const float rinv = M::recip(1.f - a_eff);
-                Tr = Tr * rinv;
-                const float w = a_eff * Tr;
-                const float cdot = M::mad(gc.z, dLp[2], M::mad(gc.y, dLp[1], gc.x * dLp[0]));
-                part[0] = M::mad(w, dLp[0], part[0]);
-                part[1] = M::mad(w, dLp[1], part[1]);
-                part[2] = M::mad(w, dLp[2], part[2]);
-                const float dL_dalpha = M::mad(Tr, cdot, -(S * rinv));
-                S = M::mad(w, cdot, S);
-                const float v = g_eff * dL_dalpha;
-                if (!TILE_MOM) {
-                    const float vx = v * dx, vy = v * dy;
-                    part[3] += vx;
-                    part[4] += vy;
-                    part[5] = M::mad(vx, dx, part[5]);
-                    part[6] = M::mad(vx, dy, part[6]);
-                    part[7] = M::mad(vy, dy, part[7]);
-                } else {
-                    part[3] = __builtin_fmaf(v, pu, part[3]);
-                    part[4] = __builtin_fmaf(v, pw, part[4]);
-                    part[5] = __builtin_fmaf(v, puu, part[5]);
-                    part[6] = __builtin_fmaf(v, puw, part[6]);
-                    part[7] = __builtin_fmaf(v, pww, part[7]);
-                }
-                part[8] += v;
-            }
-            if (!any) continue;                   // nothing blended in this batch: the table keeps its zeros
-            const int row = lane >> 1, half = lane & 1;
-            const int inst = row / FRG_SLOT_FLOATS;
-            const int comp = row - inst * FRG_SLOT_FLOATS;
-            const bool writer = half == 0 && row < BWD_BATCH * FRG_SLOT_FLOATS && k + inst < nkeep;
-            wave_lds_sync();         // the previous batch's readers are done with s_red
-#pragma unroll
-            for (int h = 0; h < BWD_BATCH; h++)
-#pragma unroll
-                for (int c = 0; c < FRG_SLOT_FLOATS; c++) s_red[(h * FRG_SLOT_FLOATS + c) * 64 + lane] = acc[h][c];
-            wave_lds_sync();
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            if (row < BWD_BATCH * FRG_SLOT_FLOATS) {
-                const float4* src = reinterpret_cast<const float4*>(s_red + row * 64 + half * 32);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float4 v = src[(j + comp) & 7];
-                    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-                }
-            }
-            float sum = (s0 + s1) + (s2 + s3);
-            sum = dpp_step<0xB1, 0xf>(sum);
-            if (writer) s_res[__float_as_uint(s_a[k + inst].z)][q][comp] = sum;
-        }
-        __syncthreads();             // the four quadrants' columns are complete
-        for (int t = threadIdx.x; t < cnt * FRG_SLOT_FLOATS; t += BLEND_THREADS) {
-            const int e = t / FRG_SLOT_FLOATS, c = t - e * FRG_SLOT_FLOATS;
-            slots[(size_t)s_slot[e] * FRG_SLOT_STRIDE + c] = ((s_res[e][0][c] + s_res[e][1][c]) + s_res[e][2][c]) + s_res[e][3][c];
-        }
-        __syncthreads();             // before the next round rewrites the table and the slot numbers
-    }
-}
-
 // ---- launchers (instantiated by blend_exact.hip / blend_fast.hip with their arithmetic) ----------------------------------
 template <bool EXACT>
 static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
@@ -855,33 +659,23 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 // single-wave workgroups of the segmented form (16 per CU fit the LDS)
 #define FRG_BWD_MAX_WAVES 8192      // measured at C3 / C4: 2048 0.69 / 0.56 ms, 4096 (= what is resident at once) 0.55 / 0.39 with a queue, 8192 and 16384 0.41 / 0.39
 extern int g_bwd_waves;       // tuning (frg_set_option("bwd_waves")): single-wave workgroups of the backward blend (0: the default)
-template <bool EXACT, bool TILE_MOM>
+template <bool EXACT>
 static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                      const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                     int batch, int quad_tiles, hipStream_t s)
+                                     int batch, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
-    // quad_tiles: at most this many active tiles -> the quadrant form (< 0: FRG_BWD_QUAD_TILES; 0: never)
-    const uint32_t qt = quad_tiles < 0 ? (uint32_t)FRG_BWD_QUAD_TILES : (uint32_t)quad_tiles;
     // waves: one per item while the frame has at most FRG_BWD_MAX_WAVES items (an upper bound on their number: one last
     // segment per tile + R / SEG full ones), beyond that the waves stride
     const int bound = (int)std::min<size_t>((size_t)T + list_a_cap, (size_t)FRG_BWD_MAX_WAVES);
     const int nwaves = ((g_bwd_waves > 0 ? g_bwd_waves : bound) + 7) / 8 * 8;
-    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, img.tile_work, img.bwd_order, list_a, list_a_cap, img.bwd_hdr, qt, img.cutoff);
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, img.tile_work, img.bwd_order, list_a, list_a_cap, img.bwd_hdr, img.cutoff);
 #define FRG_BWD(B)                                                                                                         \
-    hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B, TILE_MOM>), dim3(nwaves), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
+    hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B>), dim3(nwaves), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H,               \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
                        img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_hdr, list_a, img.tile_work, b.ckpt, img.final_C)
     if (batch == 2) FRG_BWD(2); else FRG_BWD(3);
 #undef FRG_BWD
-    // the quadrant form (timing experiment, option bwd_quad_tiles): one of the two launches finds the mode word against it and leaves
-    const int nquad = (uint32_t)T < qt ? T : (int)qt;
-#define FRG_BWDQ(B)                                                                                                        \
-    hipLaunchKernelGGL((blend_bwd_quad_kernel<EXACT, B, TILE_MOM>), dim3(nquad), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.gy, vp.W, vp.H, \
-                       img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
-                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_hdr)
-    if (nquad > 0) { if (batch == 2) FRG_BWDQ(2); else FRG_BWDQ(3); }
-#undef FRG_BWDQ
     return hipGetLastError();
 }
 

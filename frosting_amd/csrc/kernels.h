@@ -34,7 +34,6 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // to be called before launch_scatter (same arguments as launch_tile_sort's): plans the sort of the long lists
 extern int g_sort_heavy_on_caller;
 extern int g_fwd_prefetch;
-extern int g_bwd_tile_moments;
 extern int g_bwd_waves;         // tuning: single-wave workgroups of the backward blend (0: the default, 16 per CU)
 hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
                             const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream, int fork_mode = 0);
@@ -51,10 +50,10 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
 // list_a / list_a_cap: room for the (tile, segment) items of the full segments, behind the slots in the backward workspace
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                   const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                  int batch, int quad_tiles, hipStream_t s);
+                                  int batch, hipStream_t s);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                  const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                 int batch, int quad_tiles, hipStream_t s);
+                                 int batch, hipStream_t s);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
@@ -65,7 +64,6 @@ struct BwdOutputs {
 };
 // heavy_only: false = every wave of 64 Gaussians that is not on GeomState::heavy_waves (the plain kernel), true = the
 // listed waves (the 16-wave form; any stream ordered after the blend backward).  flags:
-#define FRG_PBW_TILE_MOMENTS 1     // TIMING EXPERIMENT: the slots hold moments about the tile centre (round 3's fast blend backward)
 #define FRG_PBW_NO_HEAVY_LAUNCH 2  // the 16-wave launch is skipped: the plain kernel reduces waves of any slot count itself
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int flags,

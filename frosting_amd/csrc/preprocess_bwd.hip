@@ -194,23 +194,6 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 const float* sp = slots + (size_t)(wave_base + sl) * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
-                if (flags & FRG_PBW_TILE_MOMENTS) {
-                    // the fast blend leaves the moments of v = G dL/dalpha about the TILE centre (offset (u, w) of the
-                    // pixel): with d = (Dx - u, Dy - w), (Dx, Dy) = Gaussian centre - tile centre,
-                    //   sum v dx = Dx m0 - mu,  sum v dx^2 = Dx^2 m0 - 2 Dx mu + muu,  sum v dx dy = Dx Dy m0 - Dx mw - Dy mu + muw
-                    const int4 info = own_info[owner];
-                    uint32_t ry, rx;
-                    rect_divmod(sl - own_start[owner], (uint32_t)info.z, ry, rx);
-                    const float2 c2 = own_xy[owner];
-                    const float Dx = c2.x - ((float)((info.x + (int)rx) * FRG_TILE) + 7.5f);
-                    const float Dy = c2.y - ((float)((info.y + (int)ry) * FRG_TILE) + 7.5f);
-                    const float m0 = part[8], mu = part[3], mw = part[4], muu = part[5], muw = part[6], mww = part[7];
-                    part[3] = Dx * m0 - mu;
-                    part[4] = Dy * m0 - mw;
-                    part[5] = (Dx * Dx) * m0 - 2.0f * Dx * mu + muu;
-                    part[6] = (Dx * Dy) * m0 - Dx * mw - Dy * mu + muw;
-                    part[7] = (Dy * Dy) * m0 - 2.0f * Dy * mw + mww;
-                }
             }
         };
         // software pipeline: the next batch's rows are in flight during the scan

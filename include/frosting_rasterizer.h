@@ -237,10 +237,10 @@ int frg_backward_ex(const frg_backward_args* args);
  * (forward.cu:236-255), about twice as many.  num_rendered, radii, the image and all gradients are
  * bit-identical either way; the tile lists become order-preserving sub-lists of the reference's.
  * Default 0: lists identical to the reference's, entry for entry.
- * "bwd_quad_tiles": the backward blend runs four waves per tile (one per 8x8 quadrant) instead of one when at most
- * this many tiles blended anything in the forward -- sparsely covered frames are bound by the longest tile's wave;
- * -1 (default) = the built-in 2560, 0 = never.  The two forms add the same partial sums in different orders (both
- * fixed): gradients agree to rounding, each is bit-reproducible.
+ * "bwd_waves" (default 0 = one single-wave workgroup per work item, at most 8192): workgroups of the backward blend.
+ * A work item is a SEGMENT of 1024 entries of a tile's processed list prefix (the forward leaves every pixel's state at
+ * the segment boundaries in the binning / image chunks); the assignment of items to waves is static, so the gradients
+ * do not depend on this number.  Scheduling only.
  * "counter_mailbox" (default 1): the blocking forward learns num_rendered and the sort's class sizes from a pinned
  * host mailbox the scan workgroups post to with system-scope stores -- the scatter is enqueued while the scan stage
  * still runs -- instead of a copy + stream synchronisation behind the scan (0).  The binning callback is then asked

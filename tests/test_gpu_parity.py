@@ -42,7 +42,7 @@ GRAD_NAMES = Hh.GRAD_NAMES
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    _lib.set_option("bwd_quad_tiles", -1)
+    _lib.set_option("bwd_waves", 0)
     _lib.set_option("counter_mailbox", 1)
     _lib.set_option("sparse_sh", 1)
     _lib.set_option("exact_blend", 0)
@@ -297,9 +297,9 @@ def test_sparse_frames_default_modes_vs_reference(gpu_device, frame):
     else:
         scene, _, bg = scenes.config_scene("c2", 0, P=int(P))
         _, cam, _ = scenes.config_scene("c3", 1, P=8)
-    assert _lib.get_option("bwd_quad_tiles") == -1 and _lib.get_option("tight_binning") == 0      # default options
+    assert _lib.get_option("bwd_waves") == 0 and _lib.get_option("tight_binning") == 0      # default options
     list_len, _ = _check_against_reference_rasterizer(gpu_device, scene, cam, bg, Hh.native_ops("ext"), frame)
-    assert int((list_len > 0).sum()) > 2560           # more active tiles than FRG_BWD_QUAD_TILES: the tile-per-wave form
+    assert int((list_len > 0).sum()) > 2560
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
@@ -620,55 +620,30 @@ def test_backward_follows_the_forwards_modes_not_the_process_options(gpu_device)
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
 @pytest.mark.parametrize("exact", [1, 0])
-def test_quadrant_form_of_the_backward_blend(gpu_device, exact):
-    """Few active tiles -> four waves per tile (blend_bwd_quad_kernel), many -> one (blend_bwd_kernel): the same
-    partial sums in two fixed orders.  Both forms forced on the same forward (option bwd_quad_tiles): each is
-    bit-reproducible and judged like every other backward (helpers.judge_gradients); the choice follows the number of
-    active tiles (the full-size tests run the tile form: 6600 active tiles)."""
+def test_backward_blend_work_items_whatever_the_grid(gpu_device, exact):
+    """The backward blend's work items (tile, segment) are dealt to its waves statically (bwd_order_kernel + BwdHdr):
+    whatever the number of waves (option bwd_waves: fewer than items -> the waves stride, more -> most find nothing), every
+    slot is written once with the same value -- gradients identical bit for bit -- on a sparse 60 k-Gaussian frame and on a
+    frame that covers one corner of the image (all its items belong to the tiles of one or two XCD bands: most waves take
+    theirs from the pool that evens the XCDs' shares).  Both frames against the reference's own code."""
     scene, cam, bg = scenes.config_scene("c2", 3, P=60_000)
-    _lib.set_option("exact_blend", exact)
-    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
-    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 29)
-    gpix = gpix.to(gpu_device)
-    b = _bwd_args(args, out, gpix)
-    got = {}
-    for name, tiles in (("tile", 0), ("quad", 1 << 30)):
-        _lib.set_option("bwd_quad_tiles", tiles)
-        got[name] = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
-        again = _C.rasterize_gaussians_backward(*b)
-        assert all(torch.equal(x, y) for x, y in zip(got[name], again)), name
-    _lib.set_option("bwd_quad_tiles", -1)
-    auto = _C.rasterize_gaussians_backward(*b)       # the default: segments of the tile-per-wave form, whatever the number of active tiles
-    assert all(torch.equal(x, y) for x, y in zip(got["tile"], auto))
-    _lib.set_option("bwd_quad_tiles", 1000)          # fewer than the 2500 active tiles: still the tile-per-wave form
-    assert all(torch.equal(x, y) for x, y in zip(got["tile"], _C.rasterize_gaussians_backward(*b)))
-    _lib.set_option("bwd_quad_tiles", -1)
-    _, _, _, rst = REF.forward(**Hh.oracle_kwargs(scene, cam, bg, as_numpy=False, device=gpu_device))
-    runs = Hh.reference_runs(lambda: REF.backward(rst, gpix))
-    truth = Hh.truth_from_ref_state(rst, gpix)
-    # both forms, the same bars as everywhere (round 3 gave the forced tile form of the default arithmetic a flat 5e-3 here:
-    # its moments were taken about the tile centre; they are taken about the Gaussian now, in both forms and arithmetics)
-    for form in ("tile", "quad"):
-        Hh.judge_gradients(got[form], runs, truth, fast=not exact, label=f"60 k frame, {form} form")
-    # a frame that covers a corner of the image only (few active tiles): still the segmented tile-per-wave form by default
     small = scenes.Scene(scene.means3D * 0.12 + torch.tensor([0.9, 0.6, 0.0]), scene.scales, scene.rotations, scene.opacities,
                          scene.shs, scene.sh_degree)
-    out2, args2 = Hh.run_ours_native(small, cam, bg, gpu_device)
-    st = State(small.P, cam.image_width, cam.image_height, out2[0], out2[3], out2[4], out2[5])
-    assert 0 < int((st.tile_count > 0).sum()) < 1000
-    g2, _ = scenes.l1_target_grad(out2[1].cpu(), 31)
-    b2 = _bwd_args(args2, out2, g2.to(gpu_device))
-    auto2 = [g.clone() for g in _C.rasterize_gaussians_backward(*b2)]
-    _lib.set_option("bwd_quad_tiles", 0)
-    assert all(torch.equal(x, y) for x, y in zip(auto2, _C.rasterize_gaussians_backward(*b2)))
-    _lib.set_option("bwd_quad_tiles", 1 << 30)
-    quad2 = _C.rasterize_gaussians_backward(*b2)
-    assert not all(torch.equal(x, y) for x, y in zip(auto2, quad2))     # (the forms differ in the last bits)
-    _lib.set_option("bwd_quad_tiles", -1)
-    # ... and it is right there: all the frame's work items belong to the tiles of one or two XCD bands, so most waves
-    # take theirs from the pool that evens the XCDs' shares (BwdHdr, blend_impl.h)
-    _check_against_reference_rasterizer(gpu_device, small, cam, bg, _C, "corner frame")
-    _lib.set_option("exact_blend", exact)
+    for label, sc in (("60 k frame", scene), ("corner frame", small)):
+        _lib.set_option("exact_blend", exact)
+        out, args = Hh.run_ours_native(sc, cam, bg, gpu_device)
+        if sc is small:
+            st = State(small.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
+            assert 0 < int((st.tile_count > 0).sum()) < 1000
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 29)
+        b = _bwd_args(args, out, gpix.to(gpu_device))
+        want = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
+        for waves in (8, 64, 1000, 4096, 30_000):
+            _lib.set_option("bwd_waves", waves)
+            got = _C.rasterize_gaussians_backward(*b)
+            assert all(torch.equal(x, y) for x, y in zip(want, got)), (label, waves)
+        _lib.set_option("bwd_waves", 0)
+        _check_against_reference_rasterizer(gpu_device, sc, cam, bg, _C, label)
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")

@@ -12,7 +12,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pm
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 STAGE_OF = {"preprocess_fwd_kernel": "preprocess", "scan_kernel": "scan", "colsum_kernel": "scan", "colbase_kernel": "scan",
             "scatter_kernel": "scatter", "scatter_rows_kernel": "scatter", "reorder_kernel": "scan", "sort_tiles": "sort", "blend_fwd_kernel": "blend_fwd",
-            "blend_bwd_kernel": "blend_bwd", "blend_bwd_quad_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
+            "blend_bwd_kernel": "blend_bwd", "bwd_order_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
             "big_plan_kernel": "sort", "big_chunk_sort_kernel": "sort", "big_splitters_kernel": "sort", "big_bucket_sort_kernel": "sort"}
 
 def load(name, counter):

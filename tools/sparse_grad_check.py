@@ -1,6 +1,6 @@
 """Where do the default-arithmetic gradients of sparse frames on a large image sit?  
 
-For every frame: ours (default = fast arithmetic + automatic form; EXACT; both forms forced) and four runs of the reference's
+For every frame: ours (default = fast arithmetic; EXACT) and four runs of the reference's
 own backward (oracle/_ref, atomics in scheduling order) -- each against the other AND against the float64 gradient of the
 same float32 forward state (oracle/_build/libgs_oracle_f64.so): the exact-arithmetic value all of them are roundings of.
 usage: python tools/sparse_grad_check.py [--frames c3:50000,c3:150000,...]  [--truth-max-points N]
@@ -50,7 +50,6 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     ops = Hh.native_ops("ext")
-    experiments = os.environ.get("FROSTING_EXPERIMENTS") == "1"
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_parity import _bwd_args
     for spec in a.frames.split(","):
@@ -70,18 +69,6 @@ def main():
         out2, _ = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
         b2 = _bwd_args(args, out2, gpix)
         ours["fast/auto"] = [g.clone() for g in ops.rasterize_gaussians_backward(*b2)]
-        for nm, tiles in (("fast/tile", 0), ("fast/quad", 1 << 30)):
-            _lib.set_option("bwd_quad_tiles", tiles)
-            ours[nm] = [g.clone() for g in ops.rasterize_gaussians_backward(*b2)]
-        if experiments:
-            _lib.set_option("bwd_tile_moments", 1)
-            for nm, tiles in (("r03tilemom/tile", 0), ("r03tilemom/quad", 1 << 30)):
-                _lib.set_option("bwd_quad_tiles", tiles)
-                ours[nm] = [g.clone() for g in ops.rasterize_gaussians_backward(*b2)]
-            _lib.set_option("bwd_tile_moments", 0)
-        _lib.set_option("bwd_quad_tiles", -1)
-        auto_is = "tile" if all(torch.equal(x, y) for x, y in zip(ours["fast/auto"], ours["fast/tile"])) else "quad"
-        print(f"    automatic form: {auto_is}")
         truth = None
         if scene.P <= a.truth_max_points:
             truth = G.backward_f64(truth_state(rst, scene, cam, bg), gpix.cpu().numpy())
