@@ -270,7 +270,7 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
                  uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint2* __restrict__ cutoff)
 {
     __shared__ uint32_t base[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS], cur[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS];
-    __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD];
+    __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD], a_lim[FRG_NUM_XCD], b_cnt[FRG_NUM_XCD], b_start[FRG_NUM_XCD];
     __shared__ uint32_t n_active;
     const int tid = threadIdx.x;
     if (tid < FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS) { base[tid] = 0; cur[tid] = 0; }
@@ -294,25 +294,32 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
         if (wk > (uint32_t)FRG_BWD_SEG) atomicAdd(&a_cnt[x], (wk - 1u) / FRG_BWD_SEG);
     }
     __syncthreads();
+    // bucket starts: one thread per XCD scans its 32 buckets (relative to the XCD's first entry), then one thread lines
+    // the eight XCDs up -- as a single thread's loop over all 256 buckets this was most of the kernel's 14 us
+    if (tid < FRG_NUM_XCD) {
+        uint32_t run = 0;
+        for (int k = 0; k < FRG_BWD_LEN_BUCKETS; k++) { const uint32_t c = base[tid * FRG_BWD_LEN_BUCKETS + k]; base[tid * FRG_BWD_LEN_BUCKETS + k] = run; run += c; }
+        b_cnt[tid] = run;
+    }
+    __syncthreads();
     if (tid == 0) {
-        uint32_t run = 0, arun = 0;
+        uint32_t run = 0, arun = 0, own[FRG_NUM_XCD];
         for (int x = 0; x < FRG_NUM_XCD; x++) {
             uint32_t* l = BwdHdr::xcd(hdr, x);
-            l[2] = run;
-            for (int k = 0; k < FRG_BWD_LEN_BUCKETS; k++) { const uint32_t c = base[x * FRG_BWD_LEN_BUCKETS + k]; base[x * FRG_BWD_LEN_BUCKETS + k] = run; run += c; }
-            l[3] = run - l[2];
+            b_start[x] = run; l[2] = run; l[3] = b_cnt[x]; run += b_cnt[x];
             // (the caller sizes list A for R / SEG items, which bounds their number; the clamp only guards the buffer)
             const uint32_t ac = min(a_cnt[x], list_a_cap - min(list_a_cap, arun));
-            a_base[x] = arun; l[0] = arun; l[1] = ac; arun += ac;
+            a_base[x] = arun; a_lim[x] = ac; l[0] = arun; l[1] = ac; arun += ac;
+            own[x] = ac + b_cnt[x];
         }
         // even shares: m_x = N / 8 (+ 1 for the first N % 8); donors' excess and takers' deficits line up in one pool
         const uint32_t N = run + arun;
         uint32_t taken = 0, given = 0;
         for (int x = 0; x < FRG_NUM_XCD; x++) {
             uint32_t* l = BwdHdr::xcd(hdr, x);
-            const uint32_t own = l[1] + l[3], m = N / FRG_NUM_XCD + ((uint32_t)x < N % FRG_NUM_XCD ? 1u : 0u);
+            const uint32_t m = N / FRG_NUM_XCD + ((uint32_t)x < N % FRG_NUM_XCD ? 1u : 0u);
             l[4] = m; l[5] = taken; l[6] = given; l[7] = 0;
-            if (own < m) taken += m - own; else given += own - m;
+            if (own[x] < m) taken += m - own[x]; else given += own[x] - m;
         }
         hdr[0] = 0u; hdr[1] = n_active; hdr[2] = N;
     }
@@ -322,11 +329,11 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
         if (!wk) continue;
         const int x = xcd_of_tile(t, T);
         const int k = bucket_of(wk);
-        order[base[x * FRG_BWD_LEN_BUCKETS + k] + atomicAdd(&cur[x * FRG_BWD_LEN_BUCKETS + k], 1u)] = (uint32_t)t;
+        order[b_start[x] + base[x * FRG_BWD_LEN_BUCKETS + k] + atomicAdd(&cur[x * FRG_BWD_LEN_BUCKETS + k], 1u)] = (uint32_t)t;
         if (wk > (uint32_t)FRG_BWD_SEG) {
             const uint32_t nfull = (wk - 1u) / FRG_BWD_SEG, at = atomicAdd(&a_cur[x], nfull);
             for (uint32_t sgm = 0; sgm < nfull; sgm++)
-                if (at + sgm < BwdHdr::xcd(hdr, x)[1]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
+                if (at + sgm < a_lim[x]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
         }
     }
 }
@@ -368,9 +375,9 @@ __device__ __forceinline__ float fold_two(float a, float b)
 }
 
 // BWD_BATCH: instances whose partial sums are reduced together (2 or 3: 18 / 27 matrix rows, two lanes per row)
-// One wave per workgroup, PERSISTENT: it pulls (tile, segment) items from the lists of its XCD (bwd_order_kernel) -- the
-// full segments first, then the tiles' last segments by decreasing length -- and, when those are empty, from the other
-// XCDs' lists.  An item walks the list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
+// One wave per workgroup; the waves of XCD x take that XCD's (tile, segment) items (bwd_order_kernel: the full segments
+// first, then the tiles' last segments by decreasing length) by a static rule -- see the item loop.  An item walks the
+// list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
 template <bool EXACT, int BWD_BATCH>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,

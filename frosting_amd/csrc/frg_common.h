@@ -16,7 +16,12 @@
 // The backward blend walks a tile's processed list prefix in SEGMENTS of this many entries, each segment an independent
 // work item (blend_impl.h): the forward leaves every pixel's transmittance and accumulated colour at the segment
 // boundaries it crosses (BinningState::ckpt, ImageState::final_C).  A multiple of 64 (the staging round).
-#define FRG_BWD_SEG 1024
+// Measured (same box, C3 / C4 / clustered scene, backward blend): 256 0.425 / 0.34 / 0.42 ms, 512 0.392 / 0.37 / 0.37,
+// 1024 0.397 / 0.385 / 0.39, 2048 0.40 / 0.52 / 0.39; one tile per item (round 3) 0.40 / 0.58 / 0.40.  8 bytes of checkpoint
+// space per instance at 512.
+#ifndef FRG_BWD_SEG
+#define FRG_BWD_SEG 512
+#endif
 #define FRG_BWD_HEAVY_SLOTS (4 * 896)   // four slot windows of the per-Gaussian backward (preprocess_bwd.hip)
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU

@@ -649,10 +649,10 @@ def test_backward_blend_work_items_whatever_the_grid(gpu_device, exact):
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
 @pytest.mark.parametrize("binding", ["ext"])
 def test_deep_walks_cross_many_segments_of_the_backward_blend(gpu_device, binding):
-    """The backward blend walks a tile's processed prefix in segments of FRG_BWD_SEG = 1024 entries, each an independent
+    """The backward blend walks a tile's processed prefix in segments of FRG_BWD_SEG = 512 entries, each an independent
     work item that starts from the state the FORWARD left at the segment's end (transmittance and accumulated colour per
     pixel: BinningState::ckpt, ImageState::final_C).  A translucent scene on a small image -- opacities 0.004 ... 0.03, so
-    no pixel saturates and every tile walks its whole list of several thousand entries: 4 - 9 segments per tile, every
+    no pixel saturates and every tile walks its whole list of several thousand entries: 8 - 16 segments per tile, every
     pixel continuing behind every boundary -- against the reference's own code: forward artefacts bit-identical, all
     eight gradients judged as everywhere; and bit-reproducible from run to run (the items are pulled by whichever wave
     is free: the order of the work must not reach the sums)."""

@@ -2,10 +2,14 @@
 exp / normalize of the raw parameters) -> rasterizer forward -> fused photometric loss (value + dL/dimage)
 -> rasterizer backward (gradients straight into the flat buffer) -> activations backward, in place on that
 buffer -> fused Adam over it (features_dc / features_rest rates on one SH tensor).  The raw parameters live
-in FlatAdam's flat buffer.  Prints the time of each part and of the whole step, twice: with the two activation
-launches (round 2's step), and with the activations evaluated inside the per-Gaussian kernels (SURVEY 8(f) rank 3:
-ViewParallelRasterizer(raw_params=True) -> frg_forward_ex / frg_backward_ex on the raw parameters, gradients w.r.t.
-the raw parameters straight into the optimizer's buffer, no activated tensor in memory)."""
+in FlatAdam's flat buffer.  Prints the time of each part and of the whole step, three times:
+  eager   the activations as the reference writes them -- torch.sigmoid / torch.exp / torch.nn.functional.normalize on
+          the raw parameters and their autograd backward (frosting_model.py:726-728,770,798; gaussian_model.py:48-57):
+          the baseline SURVEY 8(f) rank 3 is measured against;
+  launch  one HIP launch for the three activations, one for their backward (frosting_amd/activations.py);
+  fused   the activations evaluated inside the per-Gaussian kernels (ViewParallelRasterizer(raw_params=True) ->
+          frg_forward_ex / frg_backward_ex on the raw parameters, gradients w.r.t. the raw parameters straight into the
+          optimizer's buffer, no activated tensor in memory)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -49,7 +53,34 @@ raw_scene = scenes.Scene(opt.params["means3D"], opt.params["scales"], opt.params
 vpr_raw = ViewParallelRasterizer(raw_scene, dev, raw_params=True)
 
 
+# eager: torch leaves aliasing the optimizer's buffers, activated copies kept by autograd
+leaves = {k: opt.params[k].detach().requires_grad_(True) for k in ("opacities", "scales", "rotations")}
+eager_out = {}
+
+
+def activations_eager():
+    eager_out["o"] = torch.sigmoid(leaves["opacities"])
+    eager_out["s"] = torch.exp(leaves["scales"])
+    eager_out["q"] = torch.nn.functional.normalize(leaves["rotations"], dim=-1)
+    act[0].copy_(eager_out["o"]); act[1].copy_(eager_out["s"]); act[2].copy_(eager_out["q"])      # (what the rasterizer reads)
+
+
+def activations_backward_eager(gviews):
+    go, gs, gq = torch.autograd.grad([eager_out["o"], eager_out["s"], eager_out["q"]],
+                                     [leaves["opacities"], leaves["scales"], leaves["rotations"]],
+                                     [gviews["opacities"], gviews["scales"], gviews["rotations"]])
+    gviews["opacities"].copy_(go); gviews["scales"].copy_(gs); gviews["rotations"].copy_(gq)
+
+
 def step(raw):
+    if raw == "eager":
+        activations_eager()
+        image, _ = vpr.forward(cam_d, bg_d)
+        loss, dimg = photometric_loss_and_grad(image, target)
+        g = vpr.backward(dimg, 0)
+        activations_backward_eager(g)
+        opt.step(vpr.exchange.flat)
+        return loss
     if raw:
         image, _ = vpr_raw.forward(cam_d, bg_d)
         loss, dimg = photometric_loss_and_grad(image, target)
@@ -65,7 +96,11 @@ def step(raw):
     return loss
 
 
-for raw in (False, True):
+# every variant starts from the SAME model and optimizer state: 48 Adam steps towards the noisy target change the scene
+# (round 3 timed the variants one after the other on the drifting model: its "fused is 0.17 ms slower" was partly that)
+snapshot = (opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.steps)
+for raw in ("eager", False, True):
+    opt.flat.copy_(snapshot[0]); opt.exp_avg.copy_(snapshot[1]); opt.exp_avg_sq.copy_(snapshot[2]); opt.steps = snapshot[3]
     for _ in range(8):
         step(raw)
     torch.cuda.synchronize()
@@ -73,7 +108,14 @@ for raw in (False, True):
     n, acc = 20, [0.0] * 6
     losses = []
     for _ in range(n):
-        if raw:
+        if raw == "eager":
+            ev[0].record(); activations_eager()
+            ev[1].record(); image, _ = vpr.forward(cam_d, bg_d)
+            ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
+            ev[3].record(); g = vpr.backward(dimg, 0)
+            ev[4].record(); activations_backward_eager(g)
+            ev[5].record(); opt.step(vpr.exchange.flat)
+        elif raw:
             ev[0].record(); ev[1].record(); image, _ = vpr_raw.forward(cam_d, bg_d)
             ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
             ev[3].record(); vpr_raw.backward(dimg, 0)
@@ -94,7 +136,8 @@ for raw in (False, True):
         step(raw)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / n
-    what = "raw parameters into the rasterizer (activations inside the per-Gaussian kernels)" if raw else "activation launches around the rasterizer"
+    what = ("EAGER torch activations + autograd around the rasterizer (the reference's chain)" if raw == "eager" else
+            "raw parameters into the rasterizer (activations inside the per-Gaussian kernels)" if raw else "activation launches around the rasterizer")
     print(f"C3 native training step, P={scene.P}, {what}: activations {acc[0]/n:.3f} ms, forward {acc[1]/n:.3f} ms, loss fwd+bwd "
           f"{acc[2]/n:.3f} ms, backward {acc[3]/n:.3f} ms, activations backward {acc[4]/n:.3f} ms, Adam {acc[5]/n:.3f} ms")
     print(f"    whole step {1e3*t:.3f} ms = {1/t:.0f} steps/s (loss {losses[0]:.5f} -> {losses[-1]:.5f} over {n} steps of the same view)")
