@@ -415,7 +415,13 @@ def main():
             # the exchange launched two steps ago on this buffer: its collectives are waited for here, its
             # SH rebuild runs on a side stream under the backward below
             vpr.prefetch_exchange(slot)
-        vpr.backward(g_d, slot)              # writes straight into the flat gradient buffer
+        overlapped = ex and schedule[0] == "in-step" and not args.deferred_counters
+        if overlapped:
+            # in-step, factored plan: the all-gather of the colour-gradient payloads leaves after phase 1 of the backward
+            # (blend + slot sums) and travels while phase 2 (the per-Gaussian chain) computes
+            vpr.backward_overlapped(g_d, slot)
+        else:
+            vpr.backward(g_d, slot)          # writes straight into the flat gradient buffer
         if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
             vpr.forward(c_d, bg_d, deferred=False, keep_mask=cull_mask(c_d))
             vpr.backward(g_d, slot)
@@ -426,7 +432,7 @@ def main():
             vpr.start_exchange(slot)
             vpr.wait_exchange(slot)
         elif ex:
-            vpr.exchange_in_step(slot)
+            vpr.exchange_in_step(slot, started=overlapped)
         if ex and dstats is not None:
             dstats.update(vpr.radii, vpr.dL_dmeans2D)
 
@@ -691,6 +697,20 @@ def main():
         }
         if shell is not None:
             out["config"]["mesh_triangles"] = int(shell.faces.shape[0])
+        if do_backward and shell is None:
+            # what the view-parallel step is predicted to cost on one 8-GPU node (frosting_amd.parallel.predict_exchange:
+            # bytes / nominal xGMI link rate at 80 % efficiency -- arithmetic, not a measurement), for the plan of this run
+            # and for the alternatives; render = this run's step without the exchange
+            from frosting_amd.parallel import predict_exchange
+            render_ms = compute_only if compute_only is not None else ms_per_step
+            sched = "in-step" if schedule[0] == "in-step" else "sync"
+            out["predicted"] = {
+                "render_ms": render_ms,
+                "this_plan": {str(n): predict_exchange(P, 16, n, render_ms, args.exchange, args.reduce, sched) for n in (2, 4, 8)},
+                "at_8_gpus": {f"{pl}/{rd}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, rd, sc)["scaling_vs_1gpu"], 2)
+                              for pl in ("allreduce", "factored") for rd in ("allreduce", "direct") for sc in ("sync", "in-step")},
+                "note": "scaling = N x render / (render + exposed exchange); RCCL's all-reduce priced as a ring bound by one "
+                        "xGMI link (pessimistic), 'direct' = reduce-scatter + all-gather over all seven links; see DESIGN.md section 5"}
         if compute_only is not None:
             out["exchange_timing"] = {"schedule": schedule[0], "ms_per_step_without_exchange": compute_only,
                                       "exposed_ms_per_step": ms_per_step - compute_only, "other_schedule": other_schedule,

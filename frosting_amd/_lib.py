@@ -83,7 +83,9 @@ class BackwardArgs(C.Structure):
                 ("raw_opacities", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_rotations", C.c_void_p),
                 ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p),
                 ("dL_dshell_logits", C.c_void_p), ("dL_dshell_cell_verts", C.c_void_p),
-                ("exact_blend", C.c_int), ("shell_bary_mode", C.c_int)]
+                ("exact_blend", C.c_int), ("shell_bary_mode", C.c_int),
+                # the backward in two calls: 1 = blend + slot sums (dL_dcolor complete), 2 = the rest; 0 = one call
+                ("phase", C.c_int)]
 
 
 def build(verbose: bool = False) -> str:

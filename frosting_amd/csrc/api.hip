@@ -479,10 +479,11 @@ size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::
 // slots (36 B per instance) + the backward blend's list of full-segment work items ((tile, segment) per FRG_BWD_SEG instances)
 static size_t slots_bytes(int R) { return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256); }
 static size_t list_a_items(int R) { return (size_t)(R > 0 ? R : 1) / FRG_BWD_SEG + 8; }
+static size_t list_a_bytes(int R) { return frg::align_up(list_a_items(R) * sizeof(uint2), 256); }
+// ... + the nine per-Gaussian sums a two-call backward (frg_backward_args::phase) keeps between its calls
 size_t frg_backward_workspace_bytes(int P, int R)
 {
-    (void)P;
-    return slots_bytes(R) + frg::align_up(list_a_items(R) * sizeof(uint2), 256);
+    return slots_bytes(R) + list_a_bytes(R) + frg::align_up((size_t)(P > 0 ? P : 1) * FRG_SLOT_FLOATS * sizeof(float), 256);
 }
 
 int frg_geometry_layout_n(int P, long long* out, int n)
@@ -823,7 +824,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  char* workspace, size_t workspace_bytes, int debug, void* hip_stream,
-                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0)
+                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0, int phase = 0)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     // the arithmetic of this backward's blend pass: what the caller says (frg_backward_args::exact_blend), else what
@@ -861,6 +862,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     float* slots = reinterpret_cast<float*>(workspace);
     uint2* list_a = reinterpret_cast<uint2*>(workspace + slots_bytes(R));
     const uint32_t list_a_cap = (uint32_t)list_a_items(R);
+    float* sums = reinterpret_cast<float*>(workspace + slots_bytes(R) + list_a_bytes(R));
+    if (phase < 0 || phase > 2) return fail(FRG_EINVAL, "frg_backward_args: phase %d (0 whole | 1 blend + slot sums | 2 the rest)", phase);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
     frg::FwdInputs in{means3D, scales, rotations, nullptr, shs, cov3D_precomp, colors_precomp, viewmatrix, projmatrix, campos};
@@ -868,7 +871,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
     out.dL_dshell_logits = dL_dshell_logits;
     out.dL_dshell_verts = dL_dshell_verts;
-    const int pbw_flags = 0;
+    const int pbw_flags = phase == 1 ? FRG_PBW_SUMS_ONLY : phase == 2 ? FRG_PBW_FROM_SUMS : 0;
+    if (phase == 2) {     // the sums are in the workspace: one launch, no slot reduction, hence no 16-wave form either
+        StageScope sc_(ST_PREPROCESS_BWD, stream);
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | FRG_PBW_NO_HEAVY_LAUNCH, false, stream, sums), "preprocess_bwd (phase 2)");
+        return FRG_OK;
+    }
     const bool probe_bwd = (g_probe.load() & 2) && g_probe_side.ensure();
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
@@ -902,8 +910,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         hipStream_t s_heavy = heavy_first ? stream : hs, s_plain = heavy_first ? hs : stream;
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
         if (!skip_heavy)
-            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy), "preprocess_bwd (long runs)");
-        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain), "preprocess_bwd");
+            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy, sums), "preprocess_bwd (long runs)");
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain, sums), "preprocess_bwd");
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
     }
     return FRG_OK;
@@ -929,15 +937,16 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
 
 int frg_backward_ex(const frg_backward_args* a)
 {
-    const size_t b1 = offsetof(frg_backward_args, exact_blend);
-    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1))
-        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu)", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_backward_args), b1);
+    const size_t b1 = offsetof(frg_backward_args, exact_blend), b2 = offsetof(frg_backward_args, phase);
+    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1 && a->struct_size != b2))
+        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu, %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_backward_args), b2, b1);
     frg::RawInputs rw;
     rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
     rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
     int exact_mode = 0;
-    if (a->struct_size == sizeof(frg_backward_args)) {
+    const int phase = a->struct_size == sizeof(frg_backward_args) ? a->phase : 0;
+    if (a->struct_size >= b2) {
         if (a->exact_blend < 0 || a->exact_blend > 2 || a->shell_bary_mode < 0 || a->shell_bary_mode > 1)
             return fail(FRG_EINVAL, "frg_backward_args: mode out of range (exact_blend %d, shell_bary_mode %d)", a->exact_blend, a->shell_bary_mode);
         exact_mode = a->exact_blend;
@@ -948,7 +957,7 @@ int frg_backward_ex(const frg_backward_args* a)
                          a->tan_fovx, a->tan_fovy, a->radii, a->geom_buffer, a->binning_buffer, a->image_buffer, a->dL_dpix,
                          a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh,
                          a->dL_dscale, a->dL_drot, a->workspace, a->workspace_bytes, a->debug, a->hip_stream, rw,
-                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode);
+                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode, phase);
 }
 
 int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,

@@ -65,9 +65,11 @@ struct BwdOutputs {
 // heavy_only: false = every wave of 64 Gaussians that is not on GeomState::heavy_waves (the plain kernel), true = the
 // listed waves (the 16-wave form; any stream ordered after the blend backward).  flags:
 #define FRG_PBW_NO_HEAVY_LAUNCH 2  // the 16-wave launch is skipped: the plain kernel reduces waves of any slot count itself
+#define FRG_PBW_SUMS_ONLY 4        // phase 1 of a two-call backward: reduce the slots, store the nine sums per Gaussian (`sums`) and dL_dcolor, stop
+#define FRG_PBW_FROM_SUMS 8        // phase 2: take the nine sums from `sums` instead of reducing the slots; dL_dcolor is already written
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s);
+                                 bool heavy_only, hipStream_t s, float* sums = nullptr);
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);

@@ -62,7 +62,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
                       const float* __restrict__ sh_dir, int flags, const uint32_t* __restrict__ heavy,
-                      const uint32_t* __restrict__ sh_layout)
+                      const uint32_t* __restrict__ sh_layout, float* __restrict__ sums)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,6 +126,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // The nine loads and the ~130-instruction segmented scan run on a quarter of the batches instead of all of them.
     uint16_t* live = reinterpret_cast<uint16_t*>(shbuf + 96);           // [BWD_WIN] behind own_co / own_xy
     if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
+    if (flags & FRG_PBW_FROM_SUMS) S = 0;   // phase 2 of a two-call backward: the sums were left by phase 1
     const uint32_t nwin = (S + BWD_WIN - 1) / BWD_WIN;                   // wave-uniform
     // on the forward's list: the 16-wave launch has it -- unless the host skipped that launch (FRG_PBW_NO_HEAVY_LAUNCH:
     // its forward posted "no such wave"), in which case a wave that does own that many slots is reduced right here,
@@ -258,6 +259,26 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         }
     }
     if (HEAVY && wave != 0) continue;      // (workgroup-level loop over the handed-over waves; wave 0 does the per-Gaussian part)
+    // The backward in two calls (frg_backward_args::phase): phase 1 stops here -- the nine sums go to the workspace, and
+    // dL_dcolor, complete after the reduction, is written: with shs given and dL_dsh == NULL it is the clamp-masked colour
+    // gradient, the payload of the factored view-parallel exchange, which can travel while phase 2 computes.
+    if (flags & FRG_PBW_SUMS_ONLY) {
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) sums[(size_t)idx * FRG_SLOT_FLOATS + c] = part[c];
+            if (dL_dcolor) {
+                const bool masked = shs && !dL_dsh;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    dL_dcolor[3 * idx + ch] = (masked && !(visible && !((clamp_bits >> ch) & 1u))) ? 0.0f : part[ch];
+            }
+        }
+        continue;
+    }
+    if (flags & FRG_PBW_FROM_SUMS) {
+#pragma unroll
+        for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = valid ? sums[(size_t)idx * FRG_SLOT_FLOATS + c] : 0.0f;
+    }
     // LIVE Gaussians: those whose slot sums are not all zero.  At C3 only one visible Gaussian in seven is reached by
     // a pixel before its tiles saturate (370 000 of 2.5 M); for the others every term below is a product with these
     // zeros, so every gradient row is zero: they skip the loads (sh_dir 36 B, mean 12, scale 12, quaternion 16) and the
@@ -364,7 +385,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         dL_dopacity[idx] = (raw.raw_opacity && has_grad) ? part[8] * ((1.0f - conic_opacity[FRG_REC * idx].w) * conic_opacity[FRG_REC * idx].w) : part[8];
         // with shs given and dL_dsh == nullptr the caller wants the factor of the SH gradient instead
         // (the clamp-masked colour gradient, stored below): see frg_backward in the header
-        if (dL_dcolor && !(shs && !dL_dsh)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
+        if (dL_dcolor && !(shs && !dL_dsh) && !(flags & FRG_PBW_FROM_SUMS)) { dL_dcolor[3 * idx] = part[0]; dL_dcolor[3 * idx + 1] = part[1]; dL_dcolor[3 * idx + 2] = part[2]; }
     }
 
     // ---- 4. SH path (backward.cu:20-139) ----
@@ -384,7 +405,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
         }
-        if (!dL_dsh && valid) { dL_dcolor[3 * idx] = dRGB[0]; dL_dcolor[3 * idx + 1] = dRGB[1]; dL_dcolor[3 * idx + 2] = dRGB[2]; }
+        if (!dL_dsh && valid && !(flags & FRG_PBW_FROM_SUMS)) { dL_dcolor[3 * idx] = dRGB[0]; dL_dcolor[3 * idx + 1] = dRGB[1]; dL_dcolor[3 * idx + 2] = dRGB[2]; }
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
         if (has_grad) {
             wgt[0] = kSH0;
@@ -549,7 +570,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s)
+                                 bool heavy_only, hipStream_t s, float* sums)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
@@ -560,7 +581,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums)
     // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }

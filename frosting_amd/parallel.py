@@ -54,6 +54,53 @@ def _hip_sh_reducer(ex: "GradientExchange"):
         raise RuntimeError(f"frg_sh_grad_from_views failed ({rc}): {_lib.last_error()}")
 
 
+# ---- the 8-GPU budget -----------------------------------------------------------------------------
+XGMI_LINKS = 7                 # one node: every MI355X talks to each of the other seven over its own link
+XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task statement and SURVEY 8(e) give)
+
+
+def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "factored", reduce: str = "allreduce",
+                     schedule: str = "in-step", link_efficiency: float = 0.8, rebuild_ms_per_view: float = 0.019,
+                     split_overhead_ms: float = 0.08, per_gaussian_bwd_ms: float = 0.29):
+    """Predicted step time and scaling of the view-parallel step on ONE node of `world` MI355X: arithmetic, not a
+    measurement (no 8-GPU run is available to this repository; bench.py prints it as `predicted`).
+
+    Bytes per rank: the dense part is 11 floats per Gaussian (44 P bytes) in the factored plan, (11 + 3 K) floats in the
+    plain one; the factored plan adds an all-gather of 3 floats per Gaussian and view.  Wire time of a collective over the
+    fully connected xGMI node:
+      * direct (reduce-scatter + all-gather of 1/N shards, every link busy): 2 (N-1)/N bytes / (links in use x rate),
+        links in use = min(N - 1, 7);
+      * RCCL all-reduce is taken as a ring bound by ONE link: 2 (N-1)/N bytes / rate -- the pessimistic reading of
+        SURVEY 8(e); RCCL may do better on this topology, which is for the driver's curve to say;
+      * all-gather of the payloads: (N-1) x 12 P bytes arrive over N-1 links in parallel: 12 P bytes / rate.
+    Exposed time (what the step grows by): schedule "in-step" with the two-call backward hides the payload all-gather
+    under phase 2 of the backward (per_gaussian_bwd_ms) at the price of split_overhead_ms; the SH rebuild
+    (rebuild_ms_per_view x N, measured 0.15 ms at 8 views) runs beside the dense sum; "sync" hides nothing.
+    link_efficiency: achieved / nominal link rate.  Returns a dict."""
+    rate = XGMI_LINK_GBPS * 1e9 * link_efficiency
+    links = max(1, min(world - 1, XGMI_LINKS))
+    factored = plan == "factored"
+    dense_bytes = 4 * P * (11 if factored else 11 + 3 * K)
+    frac = 2.0 * (world - 1) / world if world > 1 else 0.0
+    dense_ms = 1e3 * frac * dense_bytes / (rate * (links if reduce == "direct" else 1))
+    gather_ms = 1e3 * (12.0 * P / rate) if (factored and world > 1) else 0.0
+    rebuild_ms = rebuild_ms_per_view * world if factored else 0.0
+    if world == 1:
+        exposed = 0.0
+    elif not factored:
+        exposed = dense_ms
+    elif schedule == "in-step":
+        exposed = split_overhead_ms + max(0.0, gather_ms - per_gaussian_bwd_ms) + max(dense_ms, rebuild_ms)
+    else:
+        exposed = gather_ms + dense_ms + rebuild_ms
+    step = render_ms + exposed
+    return {"world": world, "plan": plan, "reduce": reduce, "schedule": schedule, "dense_MB": dense_bytes / 1e6,
+            "gather_MB_in": 12.0 * P * max(world - 1, 0) / 1e6 if factored else 0.0, "dense_wire_ms": dense_ms,
+            "gather_wire_ms": gather_ms, "sh_rebuild_ms": rebuild_ms, "exposed_ms": exposed, "ms_per_step": step,
+            "scaling_vs_1gpu": world * render_ms / step, "link_GBps": XGMI_LINK_GBPS, "link_efficiency": link_efficiency,
+            "note": "arithmetic from bytes and the nominal xGMI link rate, not a measurement"}
+
+
 class GradientExchange:
     """Flat fp32 gradient buffer with named per-parameter views.  Backend-agnostic (RCCL on
     GPUs, gloo in the CPU tests).
@@ -121,19 +168,25 @@ class GradientExchange:
         self.start()
         return self.wait()
 
-    def start(self):
+    def start(self, part: str = "all"):
         """Enqueue the collectives behind the work already on the current stream and return at
         once (torch.distributed async_op): they run on the backend's own stream, so kernels
-        enqueued afterwards on the compute stream overlap with them."""
+        enqueued afterwards on the compute stream overlap with them.
+        part (factored plan): "gather" = only the all-gather of the colour-gradient payloads (they are complete after
+        phase 1 of a two-call backward), "dense" = only the sum of the dense part (after phase 2); "all" = both."""
         import torch.distributed as dist
-        self._works = []
+        if part != "dense":
+            self._works = []
         if not self._active():
             return None
         if self.factor_sh:
-            world = dist.get_world_size(self.group)
-            if self.gathered is None or self.gathered.shape[0] != world:
-                self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
-            self._works.append(dist.all_gather_into_tensor(self.gathered.view(-1), self.own, group=self.group, async_op=True))
+            if part != "dense":
+                world = dist.get_world_size(self.group)
+                if self.gathered is None or self.gathered.shape[0] != world:
+                    self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
+                self._works.append(dist.all_gather_into_tensor(self.gathered.view(-1), self.own, group=self.group, async_op=True))
+            if part == "gather":
+                return self._works
             summed = self.dense
         else:
             summed = self.flat
@@ -436,11 +489,14 @@ class ViewParallelRasterizer:
         self.true_num_rendered = n.value
         return True
 
-    def backward(self, dL_dimage, slot: int = 0, payload=None):
+    def backward(self, dL_dimage, slot: int = 0, payload=None, phase: int = 0):
         """Gradients of the last forward, written in place into exchange buffer `slot`.  In the
         factored plan under a process group, views["shs"] is only valid after wait_exchange(slot).
         payload: also fill this view's share of the factored exchange (masked colour gradient and
-        camera centre); default: only when a process group is live."""
+        camera centre); default: only when a process group is live.
+        phase (frg_backward_args::phase): 1 = the backward blend + the per-Gaussian slot sums -- the payload of the
+        factored exchange is complete when this call's kernels are, so its all-gather can be started before phase 2
+        (backward_overlapped does that); 2 = the rest; 0 = both in one call."""
         L = _lib.lib()
         s = self.scene
         cam, bg = self._view
@@ -453,24 +509,28 @@ class ViewParallelRasterizer:
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        if self.raw_params:
+        if self.raw_params or phase:
             v = lambda t: None if t is None else t.data_ptr()
+            raw = self.raw_params
             a = _lib.BackwardArgs(
                 struct_size=C.sizeof(_lib.BackwardArgs), P=self.P, D=s.sh_degree, M=self.K, R=self.num_rendered, background=v(bg),
-                width=W, height=H, means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, scales=None, scale_modifier=1.0,
-                rotations=None, cov3D_precomp=None, viewmatrix=v(cam.viewmatrix), projmatrix=v(cam.projmatrix),
+                width=W, height=H, means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, scales=None if raw else v(s.scales), scale_modifier=1.0,
+                rotations=None if raw else v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix), projmatrix=v(cam.projmatrix),
                 campos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy), radii=v(self.radii),
                 geom_buffer=v(self.geom.buf), binning_buffer=v(self.binning.buf), image_buffer=v(self.img.buf),
                 dL_dpix=v(dL_dimage), dL_dmean2D=v(self.dL_dmeans2D), dL_dconic=None, dL_dopacity=v(g["opacities"]),
                 dL_dcolor=v(ex.own_drgb) if defer_sh else (v(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
                 dL_dmean3D=v(g["means3D"]), dL_dcov3D=v(self.dL_dcov3D), dL_dsh=None if defer_sh else v(g["shs"]),
                 dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), workspace=v(work), workspace_bytes=work.numel(), debug=0,
-                hip_stream=stream.value, raw_opacities=v(s.opacities), raw_scales=v(s.scales), raw_rotations=v(s.rotations))
+                hip_stream=stream.value, raw_opacities=v(s.opacities) if raw else None, raw_scales=v(s.scales) if raw else None,
+                raw_rotations=v(s.rotations) if raw else None, phase=int(phase))
             rc = L.frg_backward_ex(C.byref(a))
         else:
             rc = self._backward_plain(L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
+        if phase == 2:
+            return g              # (the payload left with phase 1)
         if ex.factor_sh and (ex._active() if payload is None else payload):
             # this view's share of the factored SH exchange: masked colour gradient + camera centre
             if not defer_sh:   # (with deferred SH rows the backward wrote the payload itself)
@@ -495,11 +555,29 @@ class ViewParallelRasterizer:
                             _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
                             _p(work), work.numel(), 0, stream)
 
-    def exchange_in_step(self, slot: int = 0):
+    def backward_overlapped(self, dL_dimage, slot: int = 0):
+        """backward + the start of the exchange, factored plan: phase 1 (blend backward + slot sums: the colour-gradient
+        payload is complete) -> the all-gather of the payloads is enqueued -> phase 2 (the per-Gaussian chain, 0.3 ms at
+        C3) runs while they travel -> the sum of the dense part is enqueued.  Finish with
+        exchanges[slot].finish_in_step() (or exchange_in_step(slot, started=True)).  Without a live factored exchange:
+        a plain backward + start_exchange."""
+        ex = self.exchanges[slot]
+        if not (ex.factor_sh and ex._active()):
+            g = self.backward(dL_dimage, slot)
+            ex.start()
+            return g
+        self.backward(dL_dimage, slot, phase=1)
+        ex.start(part="gather")
+        g = self.backward(dL_dimage, slot, phase=2)
+        ex.start(part="dense")
+        return g
+
+    def exchange_in_step(self, slot: int = 0, started: bool = False):
         """start_exchange + GradientExchange.finish_in_step: the gradients of buffer `slot` are the sums over ranks
         when this returns (stream-ordered) -- the form a step with an optimizer update between views needs."""
         ex = self.exchanges[slot]
-        ex.start()
+        if not started:
+            ex.start()
         return ex.finish_in_step()
 
     def allreduce_grads(self, slot: int = 0):

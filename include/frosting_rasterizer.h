@@ -156,7 +156,7 @@ typedef struct frg_forward_args {
 int frg_forward_ex(const frg_forward_args* args);
 
 /* Bytes of scratch frg_backward needs for a forward that returned R instances. */
-size_t frg_backward_workspace_bytes(int P, int R);
+size_t frg_backward_workspace_bytes(int P, int R);   /* slots (36 B per instance) + the backward blend's work items + per-Gaussian sums (36 B per Gaussian) */
 
 /* Replaces Rasterizer::backward (rasterizer.h:58-84, rasterizer_impl.cu:340-434).
  * All nine gradient arrays are fully written (zero rows for culled Gaussians);
@@ -220,6 +220,14 @@ typedef struct frg_backward_args {
      * shell_bary_mode as in frg_forward_args, and equal to the forward's */
     int exact_blend;
     int shell_bary_mode;
+    /* third generation: the backward in TWO calls (0 = one call, everything).
+     *   phase 1  the backward blend and the reduction of its per-instance partials to per-Gaussian sums (kept in the
+     *            workspace); dL_dcolor is complete when this call's work is: with shs given and dL_dsh == NULL it holds
+     *            the clamp-masked colour gradient -- the 12-byte-per-Gaussian payload of the factored view-parallel
+     *            exchange, whose all-gather can then travel WHILE phase 2 runs;
+     *   phase 2  everything else (the covariance / projection / SH chain and every other output), from those sums.
+     * Same arguments and the same workspace in both calls; the two together write exactly what one call writes, bit for bit. */
+    int phase;
 } frg_backward_args;
 int frg_backward_ex(const frg_backward_args* args);
 

@@ -110,8 +110,48 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
             else:
                 assert torch.equal(outs[0], ref)     # factored == plain, bit for bit, at one view
             assert float(ref.abs().max()) > 0
+            # the in-step schedule with the backward in two calls: the payload's all-gather is enqueued between the phases
+            # (backward_overlapped), finish_in_step completes everything -- the same bits again
+            vpr.forward(cam.to(dev), bg.to(dev))
+            own_before = vpr.exchanges[0].own.clone() if factored else None
+            vpr.backward_overlapped(gpix, 0)
+            flat = vpr.exchange_in_step(0, started=True).clone()
+            torch.cuda.synchronize(dev)
+            assert torch.equal(flat, ref)
+            if factored:
+                assert torch.equal(vpr.exchanges[0].own, own_before)       # the payload phase 1 wrote = the one-call payload
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scene_kind", ["ball", "giants"])
+def test_backward_in_two_calls_equals_one_call(gpu_device, scene_kind):
+    """frg_backward_args::phase: 1 (backward blend + per-Gaussian slot sums, dL_dcolor complete) then 2 (the rest, from
+    the sums kept in the workspace) write exactly what the one-call backward writes -- every gradient, bit for bit --
+    on the uniform ball and on a frame with near-camera giants (waves of thousands of slots: the 16-wave form runs in
+    phase 1, phase 2 needs no second form)."""
+    dev = gpu_device
+    if scene_kind == "ball":
+        scene, cam, bg = scenes.config_scene("c2", 1, P=80_000)
+    else:
+        scene = scenes.make_skew_scene(20_000, 99, centres=[[0.0, 0.0, 0.0]], cluster_sigma=0.05, cluster_frac=0.2, n_big=120, big_scale=0.3)
+        cam, bg = scenes.ring_camera(0, 320, 240, 267.0, 267.0), torch.zeros(3)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev)
+    cam_d, bg_d = cam.to(dev), bg.to(dev)
+    img, _ = vpr.forward(cam_d, bg_d)
+    gpix, _ = scenes.l1_target_grad(img.cpu(), 5)
+    gpix = gpix.to(dev)
+    vpr.backward(gpix, 0)
+    want = (vpr.exchange.flat.clone(), vpr.dL_dmeans2D.clone(), vpr.dL_dcolors.clone(), vpr.dL_dcov3D.clone())
+    assert float(want[0].abs().max()) > 0
+    for t in (vpr.exchange.flat, vpr.dL_dmeans2D, vpr.dL_dcolors, vpr.dL_dcov3D):
+        t.fill_(float("nan"))
+    vpr.backward(gpix, 0, phase=1)
+    assert torch.equal(vpr.dL_dcolors, want[2])                              # complete after phase 1
+    assert bool(torch.isnan(vpr.exchange.flat).all())                         # ... and nothing else written yet
+    vpr.backward(gpix, 0, phase=2)
+    got = (vpr.exchange.flat, vpr.dL_dmeans2D, vpr.dL_dcolors, vpr.dL_dcov3D)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
 
 
 def test_deferred_counters_forward_matches_blocking_forward(gpu_device):

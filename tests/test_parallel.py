@@ -305,3 +305,24 @@ def test_densification_statistics_over_a_view_parallel_batch_gloo():
         assert (torch.from_numpy(res[r][0]) == max_r).all()
         torch.testing.assert_close(torch.from_numpy(res[r][1]), accum, rtol=1e-6, atol=1e-6)
         assert (torch.from_numpy(res[r][2]) == denom).all()
+
+
+def test_predicted_exchange_budget_arithmetic():
+    """frosting_amd.parallel.predict_exchange (the 8-GPU budget bench.py prints as `predicted`): the bytes
+    of each plan, the wire times they imply at the nominal xGMI link rate, and the orderings the design relies on."""
+    from frosting_amd.parallel import predict_exchange
+    P, K = 3_000_000, 16
+    plain = predict_exchange(P, K, 8, 1.44, "allreduce", "allreduce", "sync", link_efficiency=1.0)
+    assert abs(plain["dense_MB"] - 708.0) < 1e-6 and abs(plain["dense_wire_ms"] - 2 * 7 / 8 * 708e6 / 153e9 * 1e3) < 1e-9   # SURVEY 8(e): 8.1 ms
+    fac = predict_exchange(P, K, 8, 1.44, "factored", "direct", "sync", link_efficiency=1.0)
+    assert abs(fac["dense_MB"] - 132.0) < 1e-6 and abs(fac["gather_MB_in"] - 252.0) < 1e-6
+    assert abs(fac["dense_wire_ms"] - 2 * 7 / 8 * 132e6 / (7 * 153e9) * 1e3) < 1e-9
+    assert abs(fac["gather_wire_ms"] - 36e6 / 153e9 * 1e3) < 1e-9
+    ovl = predict_exchange(P, K, 8, 1.44, "factored", "direct", "in-step", link_efficiency=1.0)
+    assert ovl["exposed_ms"] < fac["exposed_ms"] < plain["exposed_ms"]
+    assert ovl["scaling_vs_1gpu"] > 6.0 > plain["scaling_vs_1gpu"]
+    one = predict_exchange(P, K, 1, 1.44)
+    assert one["exposed_ms"] == 0.0 and one["scaling_vs_1gpu"] == 1.0
+    for n in (2, 4, 8):           # more GPUs never cost less wire time per rank, and scaling stays below N
+        r = predict_exchange(P, K, n, 1.44, "factored", "direct", "in-step")
+        assert 0 < r["scaling_vs_1gpu"] < n
