@@ -61,6 +61,18 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     return rast, None
 
 
+def fragments(glctx, pos, tri, resolution):
+    """The three planes the reference's mesh rasterizer hands on in its nvdiffrast branch
+    (frosting_utils/mesh_rasterization.py:146-169, frosting_utils/nvdiffrast.py:53-54), in pytorch3d's `Fragments`
+    shapes: bary_coords [1,H,W,1,3] (u, v, 1 - u - v), zbuf [1,H,W,1] (z/w, NDC: the reference leaves it there, :152),
+    pix_to_face [1,H,W,1] int32 with -1 for uncovered pixels.  A plain tuple: pytorch3d is not a dependency."""
+    H, W = int(resolution[0]), int(resolution[1])
+    rast, _ = rasterize(glctx, pos, tri, resolution)
+    bary, zbuf, pix_to_face = rast[..., :2], rast[..., 2], rast[..., 3].int() - 1
+    bary = torch.cat([bary, 1.0 - bary.sum(dim=-1, keepdim=True)], dim=-1)
+    return bary.view(1, H, W, 1, 3), zbuf.view(1, H, W, 1), pix_to_face.view(1, H, W, 1)
+
+
 def install_as_nvdiffrast():
     """Make ``import nvdiffrast.torch as dr`` resolve to this module."""
     pkg = types.ModuleType("nvdiffrast")

@@ -74,8 +74,11 @@ WHOLE_FACTOR = {False: 10.0, True: 10.0}
 GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
 
 
-def _rows(a, P):
-    t = torch.as_tensor(a.detach().cpu() if isinstance(a, torch.Tensor) else a).to(torch.float64)
+def _rows(a, P, device="cpu"):
+    """[P, -1] float64 view of a gradient tensor / array on `device` (the comparisons of a 3 M-Gaussian frame -- norms and
+    top-k over 144 M-element tensors, five of them per name -- take a minute on the host and a second on the GPU)"""
+    t = a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    t = t.to(device=device, dtype=torch.float64)
     return t.reshape(P, -1) if t.numel() else t.reshape(P, 0)
 
 
@@ -116,22 +119,23 @@ def judge_gradients(ours, refs, truth, fast, label, names=None, quiet=False):
     truth: {name: float64 array}.  Asserts the two comparisons described above and returns the per-tensor report."""
     if not isinstance(ours, dict):
         ours = dict(zip(GRAD_NAMES, ours))
+    dev = next((t.device for t in ours.values() if isinstance(t, torch.Tensor) and t.is_cuda), torch.device("cpu"))
     report = {}
     for name in (names or GRAD_NAMES):
         if name not in ours or name not in truth:
             continue
         t_full = np.asarray(truth[name])
         P = t_full.shape[0]
-        t = _rows(t_full, P)
+        t = _rows(t_full, P, dev)
         if t.numel() == 0 or not bool(t.any()):
-            assert not bool(_rows(ours[name], P).any()) or t.numel() == 0, (label, name, "expected an all-zero gradient")
+            assert not bool(_rows(ours[name], P, dev).any()) or t.numel() == 0, (label, name, "expected an all-zero gradient")
             continue
-        o = _rows(ours[name], P)
-        rs = [_rows(r[name], P) for r in refs]
+        o = _rows(ours[name], P, dev)
+        rs = [_rows(r[name], P, dev) for r in refs]
         e_ref = torch.stack([(r - t).pow(2).sum(1) for r in rs]).max(0).values          # per row: the reference's worst run
         live = int((t.pow(2).sum(1) > 0).sum())
         k = max(1, int(np.ceil(TRIM_FRACTION * live)))
-        keep = torch.ones(P, dtype=torch.bool)
+        keep = torch.ones(P, dtype=torch.bool, device=dev)
         keep[torch.topk(e_ref, k).indices] = False
         tn, tkn = float(t.norm()), float(t[keep].norm())
         well_ours = float((o[keep] - t[keep]).norm()) / tkn
