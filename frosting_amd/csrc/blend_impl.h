@@ -124,10 +124,27 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  float* __restrict__ out_color, uint32_t* __restrict__ tile_work, float4* __restrict__ ckpt,
-                 float4* __restrict__ final_C)
+                 float4* __restrict__ final_C, const uint32_t* __restrict__ class_tiles, const uint32_t* __restrict__ class_count)
 {
     using M = BlendMath<EXACT>;
-    const int tile = xcd_tile_of_block(blockIdx.x, T);
+    int tile;
+    if (class_tiles) {
+        // The tiles LONGEST LIST FIRST (the sort's size classes, longest class first, eight descending buckets inside a
+        // class, the empty tiles last): a tile's four waves are a sequential walk, and in tile order the long ones start
+        // whenever their turn comes -- the kernel then ends with them.  Same box, band-by-band order (rounds 1-3, which kept
+        // neighbouring tiles on one XCD's L2) against this: C3 0.208 -> 0.198 ms, C4 0.280 -> 0.253, C2 0.040 -> 0.031,
+        // clustered scene 0.234 -> 0.177.  (option fwd_order = 0: the band order)
+        int k = (int)blockIdx.x;
+        if (k >= T) return;
+        tile = -1;
+#pragma unroll
+        for (int c = FRG_SORT_CLASSES - 1; c >= 0; c--) {
+            const int n = (int)class_count[c];
+            if (tile < 0 && k < n) tile = (int)class_tiles[(size_t)c * T + k];
+            if (tile < 0) k -= n;
+        }
+        if (tile < 0) tile = (int)class_tiles[(size_t)FRG_SORT_CLASSES * T + k];
+    } else tile = xcd_tile_of_block(blockIdx.x, T);
     if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -648,6 +665,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 
 
 // ---- launchers (instantiated by blend_exact.hip / blend_fast.hip with their arithmetic) ----------------------------------
+extern int g_fwd_order;       // tuning (frg_set_option("fwd_order")): 1 = forward blend walks the tiles longest list first
 template <bool EXACT>
 static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                      const float* bg, float* out_color, bool prefetch, hipStream_t s)
@@ -656,7 +674,7 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 #define FRG_FWD(PF)                                                                                                        \
     hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,   \
-                       out_color, img.tile_work, b.ckpt, img.final_C)
+                       out_color, img.tile_work, b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr, img.counters->class_count)
     if (prefetch) FRG_FWD(true); else FRG_FWD(false);
 #undef FRG_FWD
     return hipGetLastError();

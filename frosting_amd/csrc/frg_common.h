@@ -184,7 +184,7 @@ struct ImageState {
     bool row_order;          // scatter over cell-ordered records (needs lds_bins)
     // cells of the record order: tile row x band of band_w tile columns (nbands per row, at most FRG_MAX_TILE_ROWS cells)
     int band_w, nbands, ncells;
-    uint32_t* class_tiles;   // [FRG_SORT_CLASSES][T] tile ids per sort size class (non-empty tiles only)
+    uint32_t* class_tiles;   // [FRG_SORT_CLASSES + 1][T] tile ids per sort size class (longest first inside a class); last row: the empty tiles
     size_t zero_begin, zero_bytes;  // region [tile_count .. counters]: one memset in the global-bins path (api.hip)
     size_t bytes;
     __host__ static ImageState carve(char* base, int W, int H, bool force_global_bins = false)
@@ -206,7 +206,7 @@ struct ImageState {
         s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
         s.bwd_hdr = (uint32_t*)(base + o); o = align_up(o + 128 * 4, 256);     // (BwdHdr::words() = 72)
         s.final_C = (float4*)(base + o); o = align_up(o + T * FRG_TILE_PIX * 16, 256);
-        s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_SORT_CLASSES * T * 4, 256);
+        s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)(FRG_SORT_CLASSES + 1) * T * 4, 256);
         const size_t gy = (size_t)((H + FRG_TILE - 1) / FRG_TILE);
         s.lds_bins = T <= FRG_BIN_MAX_LDS_TILES && !force_global_bins;
         s.bin_matrix = nullptr; s.seg_sums = nullptr; s.row_matrix = nullptr; s.row_start = nullptr;

@@ -34,6 +34,7 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // to be called before launch_scatter (same arguments as launch_tile_sort's): plans the sort of the long lists
 extern int g_sort_heavy_on_caller;
 extern int g_fwd_prefetch;
+extern int g_fwd_order;
 extern int g_bwd_waves;         // tuning: single-wave workgroups of the backward blend (0: the default, 16 per CU)
 hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* class_count_dev, const uint32_t* class_tiles,
                             const uint2* ranges, uint32_t* big_plan, uint32_t R, hipStream_t stream, int fork_mode = 0);

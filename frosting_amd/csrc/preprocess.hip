@@ -556,6 +556,7 @@ struct ScanShared {
     uint32_t wtot[16];
     uint32_t cls[FRG_SORT_CLASSES];
     uint32_t sub[FRG_SORT_CLASSES * 8], cur[FRG_SORT_CLASSES * 8];
+    uint32_t nempty;
 };
 #define SCAN_K 10
 
@@ -613,7 +614,7 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
                                            Mailbox* mail, uint32_t seq)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { sh.carry = 0; sh.maxc = 0; }
+    if (tid == 0) { sh.carry = 0; sh.maxc = 0; sh.nempty = 0; }
     if (tid < FRG_SORT_CLASSES) sh.cls[tid] = 0;
     if (tid < FRG_SORT_CLASSES * 8) { sh.sub[tid] = 0; sh.cur[tid] = 0; }
     // totals -> LDS: coalesced, all requests of a round in flight together.  (Images of more tiles than the LDS holds
@@ -715,7 +716,10 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
 #pragma unroll 1
     for (int i = tid; i < T; i += NT) {
         const uint32_t c = tot[i];
-        if (!c) continue;
+        if (!c) {   // the empty tiles, listed behind the classes: the forward blend can then walk the tiles longest list first
+            class_tiles[(size_t)FRG_SORT_CLASSES * T + atomicAdd(&sh.nempty, 1u)] = (uint32_t)i;
+            continue;
+        }
         const int key = sort_subclass_of(c);
         class_tiles[(size_t)(key >> 3) * T + sh.sub[key] + atomicAdd(&sh.cur[key], 1u)] = (uint32_t)i;
     }

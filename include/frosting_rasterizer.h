@@ -260,6 +260,8 @@ int frg_backward_ex(const frg_backward_args* args);
  * given, or the previous forward of the calling thread saw less than three quarters of a model of the same size -- the SH
  * pass streams the coefficient rows of the VISIBLE Gaussians only (0: always the rows of every 16-Gaussian block with a
  * visible one).  Same arithmetic per Gaussian: every output bit-identical.
+ * "fwd_order" (default 1): the forward blend takes the tiles longest list first (the size classes the scan builds for the
+ * sort); 0 = in tile order, one band of tile rows per XCD.  Scheduling only, outputs bit-identical.
  * "fwd_prefetch" (default 1): the forward blend requests the next 64 list entries' records while it processes the
  * current ones (0: plain loop).  Scheduling only, outputs bit-identical.
  * "bwd_heavy_first" (default 1): when the forward posted that some 64-Gaussian waves own thousands of backward slots,

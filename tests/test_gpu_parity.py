@@ -43,6 +43,7 @@ GRAD_NAMES = Hh.GRAD_NAMES
 def _reset_options():
     yield
     _lib.set_option("bwd_waves", 0)
+    _lib.set_option("fwd_order", 1)
     _lib.set_option("counter_mailbox", 1)
     _lib.set_option("sparse_sh", 1)
     _lib.set_option("exact_blend", 0)
@@ -972,3 +973,33 @@ def test_heavy_waves_are_reduced_whatever_the_host_believes(gpu_device):
     r = subprocess.run([sys.executable, "-c", _HEAVY_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "HEAVY-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_forward_tile_order_changes_nothing(gpu_device):
+    """Option fwd_order: the forward blend's workgroups take the tiles longest list first (default; the size-class lists of
+    the scan, the empty tiles last) or band by band in tile order (rounds 1-3).  Scheduling only: image, per-pixel
+    bookkeeping, checkpoints-driven backward -- every bit the same, on a full frame, on a frame with most tiles empty, on a
+    ragged image and on an image without any instance."""
+    scene, cam, bg = scenes.config_scene("c2", 6, P=70_000)
+    corner = scenes.Scene(scene.means3D * 0.1 + torch.tensor([0.8, -0.7, 0.0]), scene.scales, scene.rotations, scene.opacities,
+                          scene.shs, scene.sh_degree)
+    nothing = scenes.Scene(scene.means3D * 0.0 + cam.campos, scene.scales, scene.rotations, scene.opacities, scene.shs, scene.sh_degree)
+    ragged = scenes.ring_camera(2, 333, 201, 300.0, 300.0)
+    for label, sc, cm in (("full", scene, cam), ("corner", corner, cam), ("ragged", scene, ragged), ("empty", nothing, cam)):
+        res = {}
+        for order in (1, 0):
+            _lib.set_option("fwd_order", order)
+            out, args = Hh.run_ours_native(sc, cm, bg, gpu_device)
+            st = State(sc.P, cm.image_width, cm.image_height, out[0], out[3], out[4], out[5])
+            gpix, _ = scenes.l1_target_grad(out[1].cpu(), 17)
+            grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+            res[order] = (out[0], out[1].clone(), out[2].clone(), st.final_T.clone(), st.n_contrib.clone(), [g.clone() for g in grads])
+            del st
+        _lib.set_option("fwd_order", 1)
+        a, b = res[1], res[0]
+        assert a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:5], b[1:5])), label
+        assert all(torch.equal(x, y) for x, y in zip(a[5], b[5])), label
+        if label == "empty":
+            assert a[0] == 0 and torch.equal(a[1], bg.to(gpu_device)[:, None, None].expand_as(a[1]))
+        if label == "corner":
+            assert int((res[1][4] > 0).sum()) > 0
