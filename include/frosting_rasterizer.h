@@ -253,7 +253,7 @@ int frg_backward_ex(const frg_backward_args* args);
  * host mailbox the scan workgroups post to with system-scope stores -- the scatter is enqueued while the scan stage
  * still runs -- instead of a copy + stream synchronisation behind the scan (0).  The binning callback is then asked
  * for frg_binning_bytes(num_rendered, 8193) (8193 = "longest tile list unknown": scratch of every sort path, as it is not
- * known yet), ~21 instead of 12 bytes per instance.  Not used with `debug`.  Same counters, same results.
+ * known yet), ~29 instead of 20 bytes per instance.  Not used with `debug`.  Same counters, same results.
  * "clear_image_state" (default 0): 1 = clear the image chunk's per-tile cursors and counters with a memset in front of
  * every forward even where the kernels initialise them on their way (images whose tiles fit the LDS bins).
  * "sparse_sh" (default 1): when a view is expected to see only a part of the model -- an occlusion mask (keep_mask) is
