@@ -123,6 +123,19 @@ def test_extended_entry_points_validate_arguments_without_a_gpu():
     a.struct_size = 8                                     # a caller built against another header
     assert L.frg_forward_ex(C.byref(a)) == -1 and "struct_size" in _lib.last_error()
     assert L.frg_forward_ex(None) == -1
+    # frg_backward_args: three generations, told apart by struct_size (up to shell_*, + exact_blend / shell_bary_mode,
+    # + phase); the ctypes mirror is the newest.  P == 0 returns before any pointer is looked at.
+    b = _lib.BackwardArgs(P=0, width=8, height=8)
+    for size in (C.sizeof(_lib.BackwardArgs), _lib.BackwardArgs.phase.offset, _lib.BackwardArgs.exact_blend.offset):
+        b.struct_size = size
+        assert L.frg_backward_ex(C.byref(b)) == 0, (size, _lib.last_error())
+    b.struct_size = C.sizeof(_lib.BackwardArgs) + 8
+    assert L.frg_backward_ex(C.byref(b)) == -1 and "struct_size" in _lib.last_error()
+    b.struct_size = C.sizeof(_lib.BackwardArgs)
+    b.P, b.phase = 5, 3
+    assert L.frg_backward_ex(C.byref(b)) == -1      # (null pointers or the phase: refused either way, before any HIP call)
+    # the workspace covers the slots, the backward blend's work items and the per-Gaussian sums of a two-call backward
+    assert L.frg_backward_workspace_bytes(1000, 100_000) >= 100_000 * 36 + (100_000 // 512) * 8 + 1000 * 36
     n = C.c_int(-7)
     assert L.frg_forward_finish(None, 0, C.byref(n)) == -1 and "pending" in _lib.last_error()
     # deferred forward needs a positive capacity
