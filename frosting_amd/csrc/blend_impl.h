@@ -682,7 +682,10 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 
 // list_a: room for list_a_cap (tile, segment) items behind the slots (frg_backward_workspace_bytes); waves: the persistent
 // single-wave workgroups of the segmented form (16 per CU fit the LDS)
-#define FRG_BWD_MAX_WAVES 8192      // measured at C3 / C4: 2048 0.69 / 0.56 ms, 4096 (= what is resident at once) 0.55 / 0.39 with a queue, 8192 and 16384 0.41 / 0.39
+// measured, backward blend at C3 / C4: segments of 1024 -- 2048 waves 0.69 / 0.56 ms, 4096 (= what is resident at once) with a
+// queue 0.55 / 0.39, 8192 0.41 / 0.39; segments of 512 (13 000 items at C3) -- 8192 waves 0.386 / 0.370, 16384 0.363 / 0.368,
+// 32768 0.366 / 0.371: one item per wave and the hardware's dispatcher, while the items fit the grid
+#define FRG_BWD_MAX_WAVES 16384
 extern int g_bwd_waves;       // tuning (frg_set_option("bwd_waves")): single-wave workgroups of the backward blend (0: the default)
 template <bool EXACT>
 static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,

@@ -245,7 +245,7 @@ int frg_backward_ex(const frg_backward_args* args);
  * (forward.cu:236-255), about twice as many.  num_rendered, radii, the image and all gradients are
  * bit-identical either way; the tile lists become order-preserving sub-lists of the reference's.
  * Default 0: lists identical to the reference's, entry for entry.
- * "bwd_waves" (default 0 = one single-wave workgroup per work item, at most 8192): workgroups of the backward blend.
+ * "bwd_waves" (default 0 = one single-wave workgroup per work item, at most 16384): workgroups of the backward blend.
  * A work item is a SEGMENT of 512 entries of a tile's processed list prefix (the forward leaves every pixel's state at
  * the segment boundaries in the binning / image chunks); the assignment of items to waves is static, so the gradients
  * do not depend on this number.  Scheduling only.
