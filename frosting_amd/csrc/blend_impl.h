@@ -286,6 +286,10 @@ static __global__ void __launch_bounds__(1024)
 bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order, uint2* __restrict__ list_a,
                  uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint2* __restrict__ cutoff)
 {
+    // One workgroup, on the backward's critical path: its latency is what counts.  The tiles' walk depths are loaded ONCE,
+    // as one batch of independent requests per thread (up to BWD_ORDER_K x 1024 tiles stay in registers between the
+    // counting and the placing pass; larger images read the rest again), the 256 bucket counters are scanned by 256 lanes.
+    constexpr int BWD_ORDER_K = 10;
     __shared__ uint32_t base[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS], cur[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS];
     __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD], a_lim[FRG_NUM_XCD], b_cnt[FRG_NUM_XCD], b_start[FRG_NUM_XCD];
     __shared__ uint32_t n_active;
@@ -293,30 +297,36 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
     if (tid < FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS) { base[tid] = 0; cur[tid] = 0; }
     if (tid < FRG_NUM_XCD) { a_cnt[tid] = 0; a_cur[tid] = 0; }
     if (tid == 0) n_active = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (int t = tid; t < T; t += 1024) {
-        if (tile_work[t]) mine++;
-        else cutoff[t] = make_uint2(0u, 0u);
-    }
-    if (mine) atomicAdd(&n_active, mine);
+    uint32_t wkr[BWD_ORDER_K];
+#pragma unroll
+    for (int i = 0; i < BWD_ORDER_K; i++) { const int t = tid + i * 1024; wkr[i] = t < T ? tile_work[t] : 0u; }
     __syncthreads();
     // last segment of tile t: entries (tile_work - 1) % SEG + 1; bucket 0 = the longest
     auto bucket_of = [](uint32_t wk) { return (FRG_BWD_LEN_BUCKETS - 1) - (((wk - 1u) % FRG_BWD_SEG) * FRG_BWD_LEN_BUCKETS) / FRG_BWD_SEG; };
-    for (int t = tid; t < T; t += 1024) {
-        const uint32_t wk = tile_work[t];
-        if (!wk) continue;
+    auto count = [&](int t, uint32_t wk) {
+        // a tile in which the forward blended nothing processes no instance: its cutoff key says so HERE (the per-Gaussian
+        // backward must not find the key an earlier frame left for it)
+        if (!wk) { cutoff[t] = make_uint2(0u, 0u); return 0u; }
         const int x = xcd_of_tile(t, T);
         atomicAdd(&base[x * FRG_BWD_LEN_BUCKETS + bucket_of(wk)], 1u);
         if (wk > (uint32_t)FRG_BWD_SEG) atomicAdd(&a_cnt[x], (wk - 1u) / FRG_BWD_SEG);
-    }
+        return 1u;
+    };
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < BWD_ORDER_K; i++) { const int t = tid + i * 1024; if (t < T) mine += count(t, wkr[i]); }
+    for (int t = tid + BWD_ORDER_K * 1024; t < T; t += 1024) mine += count(t, tile_work[t]);
+    if (mine) atomicAdd(&n_active, mine);
     __syncthreads();
-    // bucket starts: one thread per XCD scans its 32 buckets (relative to the XCD's first entry), then one thread lines
-    // the eight XCDs up -- as a single thread's loop over all 256 buckets this was most of the kernel's 14 us
-    if (tid < FRG_NUM_XCD) {
-        uint32_t run = 0;
-        for (int k = 0; k < FRG_BWD_LEN_BUCKETS; k++) { const uint32_t c = base[tid * FRG_BWD_LEN_BUCKETS + k]; base[tid * FRG_BWD_LEN_BUCKETS + k] = run; run += c; }
-        b_cnt[tid] = run;
+    // bucket starts relative to the XCD's first entry: lane = (XCD, bucket), two XCDs per wave
+    if (tid < FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS) {
+        static_assert(FRG_BWD_LEN_BUCKETS == 32, "two XCDs' buckets per wave");
+        const uint32_t c = base[tid];
+        const uint32_t incl = wave_incl_scan_dpp(c);
+        const uint32_t lower = (uint32_t)__shfl((int)incl, 31, 64);          // total of the wave's first XCD
+        const bool upper = (tid & 32) != 0;
+        base[tid] = incl - c - (upper ? lower : 0u);
+        if ((tid & 31) == 31) b_cnt[tid >> 5] = incl - (upper ? lower : 0u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -341,9 +351,8 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
         hdr[0] = 0u; hdr[1] = n_active; hdr[2] = N;
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint32_t wk = tile_work[t];
-        if (!wk) continue;
+    auto place = [&](int t, uint32_t wk) {
+        if (!wk) return;
         const int x = xcd_of_tile(t, T);
         const int k = bucket_of(wk);
         order[b_start[x] + base[x * FRG_BWD_LEN_BUCKETS + k] + atomicAdd(&cur[x * FRG_BWD_LEN_BUCKETS + k], 1u)] = (uint32_t)t;
@@ -352,7 +361,10 @@ bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __rest
             for (uint32_t sgm = 0; sgm < nfull; sgm++)
                 if (at + sgm < a_lim[x]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
         }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < BWD_ORDER_K; i++) { const int t = tid + i * 1024; if (t < T) place(t, wkr[i]); }
+    for (int t = tid + BWD_ORDER_K * 1024; t < T; t += 1024) place(t, tile_work[t]);
 }
 
 // 4-bit version for the tile-per-wave backward: bit q <=> quadrant q may be touched
