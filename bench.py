@@ -71,10 +71,12 @@ def parse_args():
                     help="N>1: 'allreduce' = all 59 floats per Gaussian are summed across ranks; 'factored' = the 11 non-SH "
                          "floats are summed + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
                          "every rank (frosting_amd/parallel.py)")
-    ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "direct"],
-                    help="N>1: how the summed part travels: 'allreduce' = one RCCL all-reduce; 'direct' = all-to-all of "
-                         "1/N shards over every xGMI link at once + local sum + all-gather (reduce-scatter / all-gather "
-                         "form of SURVEY 8(e))")
+    ap.add_argument("--reduce", default="auto", choices=["auto", "allreduce", "direct"],
+                    help="N>1: how the summed part travels: 'allreduce' = one RCCL all-reduce; 'direct' = one RCCL reduce-scatter "
+                         "of 1/N shards + one all-gather (every GPU talks to every other over its own xGMI link: SURVEY 8(e)); "
+                         "'auto' (default) = both are timed on this run's buffers before the warm-up (RCCL backend, N>1) and the "
+                         "faster one is used -- which of the two RCCL serves better on a fully connected xGMI node is not "
+                         "something the arithmetic of DESIGN.md section 5 can settle; single rank / gloo: allreduce")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only for functional tests of the multi-rank path on one GPU")
     ap.add_argument("--force-exchange", action="store_true",
@@ -355,9 +357,19 @@ def main():
     _lib.set_option("profile", 0 if args.no_stage_timers else 1)
     _lib.set_option("tight_binning", 1 if args.tight_binning else 0)
     scene_d = scene.to(dev)
+    reduce_probe = None
+    auto_reduce = args.reduce == "auto"
+    if auto_reduce:
+        args.reduce = "allreduce"
     vpr = ViewParallelRasterizer(scene_d, dev, process_group=dist.group.WORLD if dist else None,
                                  factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters,
                                  reduce=args.reduce)
+    if auto_reduce and dist is not None and world > 1 and args.backend == "nccl":
+        # the sum of the dense part timed both ways on this run's buffers, max over ranks; the faster plan is used
+        from frosting_amd.parallel import probe_reduce_plan
+        reduce_probe, args.reduce = probe_reduce_plan(vpr.exchanges)
+        for ex in vpr.exchanges:
+            ex.flat.zero_()
     exchanging = dist is not None and do_backward
     cams_d = [c.to(dev) for c in cams]
     cam_d = cams_d[0]
@@ -684,6 +696,7 @@ def main():
                                               "buffers; one-step-stale gradients only)"}[schedule[0]] +
                                     (", + densification statistics (radii MAX, grad-norm / count SUM)" if dstats is not None else "")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
+                       "reduce_probe_ms": reduce_probe,
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"],
                        "outputs_written": "all nine gradient tensors of SURVEY 8(d)'s 284 B / Gaussian except dL_dconic (an "
                                           "intermediate the reference's binding never returns, rasterize_points.cu:195): "

@@ -319,6 +319,44 @@ class GradientExchange:
             self._joined = None
 
 
+def probe_reduce_plan(exchanges, iters: int = 5, warm: int = 3):
+    """Time the sum of the dense part both ways -- the backend's all-reduce, and reduce-scatter + all-gather of 1/N shards
+    ("direct") -- on the exchange buffers as they are (contents are summed over and over: garbage in, garbage out; the
+    caller zeroes or overwrites them afterwards) and set every exchange to the faster plan.  Collective: every rank of the
+    group must call it.  Returns ({"allreduce": ms, "direct": ms} with the MAX over ranks, the plan chosen) -- the same on
+    every rank, because the choice is made from the reduced times."""
+    import time
+    import torch.distributed as dist
+    ex = exchanges[0]
+    dev = ex.flat.device
+    times = {}
+    for mode in ("allreduce", "direct"):
+        for e in exchanges:
+            e.reduce = mode
+        t0 = 0.0
+        for it in range(warm + iters):
+            if it == warm:
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                dist.barrier(group=ex.group)
+                t0 = time.perf_counter()
+            ex.start(part="dense")
+            for w in ex._works:
+                w.wait()
+            ex._works = []
+            if mode == "direct":
+                ex._finish_direct()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        tm = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX, group=ex.group)
+        times[mode] = 1e3 * float(tm.item())
+    best = min(times, key=times.get)
+    for e in exchanges:
+        e.reduce = best
+    return times, best
+
+
 class DensificationStats:
     """The per-Gaussian statistics vanilla 3DGS densification keeps (gaussian_splatting/train.py:116-117,
     gaussian_splatting/scene/gaussian_model.py:404-407), over a view-parallel batch: every rank holds one view's

@@ -326,3 +326,45 @@ def test_predicted_exchange_budget_arithmetic():
     for n in (2, 4, 8):           # more GPUs never cost less wire time per rank, and scaling stays below N
         r = predict_exchange(P, K, n, 1.44, "factored", "direct", "in-step")
         assert 0 < r["scaling_vs_1gpu"] < n
+
+
+def _probe_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from frosting_amd.parallel import probe_reduce_plan
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = dict(means3D=(301, 3), scales=(301, 3), rotations=(301, 4), opacities=(301, 1), shs=(301, 16, 3))
+    exs = [GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=f, sh_reducer=lambda ex: None) for f in (True, True)]
+    times, best = probe_reduce_plan(exs, iters=2, warm=1)
+    # ... and the exchange still works afterwards, with the chosen plan
+    for ex in exs:
+        ex.flat.fill_(float(rank + 1))
+    exs[0].means3D = torch.zeros(301, 3)
+    exs[0].start()
+    exs[0].wait()
+    q.put((rank, times, best, exs[0].reduce, exs[1].reduce, float(exs[0].views["means3D"][0, 0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_probe_of_the_reduce_plans_gloo():
+    """bench.py --reduce auto: frosting_amd.parallel.probe_reduce_plan times the dense sum both ways on live exchange
+    buffers and sets every exchange to the faster plan -- the same plan on every rank (the times are reduced first), and
+    the exchange sums correctly afterwards."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    (_, t0, b0, r00, r01, v0), (_, t1, b1, r10, r11, v1) = sorted(res)
+    assert t0 == t1 and b0 == b1 and b0 in ("allreduce", "direct") and set(t0) == {"allreduce", "direct"}
+    assert r00 == r01 == r10 == r11 == b0
+    assert v0 == v1 == 3.0                       # 1 + 2: the dense part summed over the two ranks
