@@ -429,7 +429,7 @@ int frg_set_option(const char* name, int value)
         if (strcmp(name, "ablate") == 0) return g_ablate.exchange(value);
         if (strcmp(name, "probe") == 0) return g_probe.exchange(value);
         if (strcmp(name, "assume_no_heavy") == 0) return g_assume_no_heavy.exchange(value ? 1 : 0);
-        const int old = frg::g_rows_grid; frg::g_rows_grid = value < 8 ? 8 : value; return old;
+        const int old = frg::g_rows_grid; frg::g_rows_grid = value <= 0 ? 0 : value < 8 ? 8 : value; return old;
     }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");

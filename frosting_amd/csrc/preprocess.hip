@@ -1069,7 +1069,7 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 
 // ---- host launchers -----------------------------------------------------------
 // workgroups of the cell-ordered scatter (tuning knob: frg_set_option("rows_grid")), 2 per CU by default
-int g_rows_grid = 512;
+int g_rows_grid = 0;     // 0: by the model's size (launch_scatter); > 0: timing experiments
 
 // The scatter runs over cell-ordered records (reorder_kernel + scatter_rows_kernel) in the reference-identical
 // binning mode; tight binning keeps the scatter in the caller's order (it would evaluate the per-instance tile test in
@@ -1183,7 +1183,11 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
         // two workgroups per CU, each with one contiguous share of the records (their number is only known on the
         // device: at most P); more workgroups only when a share would exceed FRG_ROWS_SUB sub-slices
         const int need = (P + FRG_ROWS_SUB * FRG_BIN_THREADS - 1) / (FRG_ROWS_SUB * FRG_BIN_THREADS);
-        const int grid = ((std::max(need, g_rows_grid) + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD;
+        // ... and fewer for small models: a share's fixed costs (its LDS difference array over the tiles, one reserved run
+        // per touched tile) do not shrink with it -- C2 (100 k Gaussians, 70 k records), same box: 512 workgroups 19 us,
+        // 256 16, 128 15, 64 18
+        const int by_size = std::min(512, std::max(64, P / 768));
+        const int grid = ((std::max(need, g_rows_grid > 0 ? g_rows_grid : by_size) + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD;
         hipError_t e = allow_big_lds(scatter_rows_kernel, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(FRG_BIN_THREADS), lds, s, T, vp.gx, vp.gy, g.row_records,
