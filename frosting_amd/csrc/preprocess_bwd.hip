@@ -287,6 +287,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 #pragma unroll
     for (int c = 0; c < FRG_SLOT_FLOATS; c++) has_grad |= part[c] != 0.0f;
     has_grad &= visible;
+    if (ablate & 8) has_grad = false;   // TIMING EXPERIMENT ONLY: no per-Gaussian mathematics, zero rows
     // d(colour)/d(direction), left by the forward's SH pass (GeomState::sh_dir): the backward does not read the 192-byte SH rows
     float shd[9];
 #pragma unroll
