@@ -408,10 +408,10 @@ __device__ __forceinline__ float fold_two(float a, float b)
 // first, then the tiles' last segments by decreasing length) by a static rule -- see the item loop.  An item walks the
 // list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
 template <bool EXACT, int BWD_BATCH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, EXACT ? 3 : 4)      // default arithmetic: 128 VGPRs without a spill instead of 130 -- the 16th wave per CU
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
-                 const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
+                 const float4* __restrict__ conic_opacity, const float4* rgb_clamped /* one byte of .w is written: no restrict */,
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                  const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order,
@@ -557,6 +557,11 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                 float* dst = slots + (size_t)my_slot * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) dst[c] = 0.0f;
+            } else if (!(__float_as_uint(col.w) & FRG_REACHED_MASK)) {
+                // "this Gaussian has a slot that may hold a gradient": byte 1 of the record's flag word (the forward writes
+                // the word, clamp flags in byte 0, with every record).  The per-Gaussian backward reduces the slots of the
+                // marked Gaussians only.  Every writer stores the same value; a stale mark only costs that kernel time.
+                reinterpret_cast<uint8_t*>(const_cast<float4*>(rgb_clamped + FRG_REC * id))[13] = 1;
             }
         }
         const uint64_t keep = wave_ballot(m != 0);

@@ -13,6 +13,7 @@
 #ifndef FRG_SLOT_STRIDE
 #define FRG_SLOT_STRIDE 9   // floats from one instance's slot to the next in the backward workspace
 #endif
+#define FRG_REACHED_MASK 0xFF00u   // byte 1 of rgb_clamped[].w: set by the backward blend for Gaussians with a slot that may hold a gradient
 // The backward blend walks a tile's processed list prefix in SEGMENTS of this many entries, each segment an independent
 // work item (blend_impl.h): the forward leaves every pixel's transmittance and accumulated colour at the segment
 // boundaries it crosses (BinningState::ckpt, ImageState::final_C).  A multiple of 64 (the staging round).
@@ -52,7 +53,7 @@ __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a -
 struct GeomState {
     float4* xydr;            // pixel x, pixel y, view depth, radius (as float, exact integer)
     float4* conic_opacity;   // conic a, b, c, opacity          (forward.cu:253)
-    float4* rgb_clamped;     // r, g, b, clamp flags in the bit pattern of .w
+    float4* rgb_clamped;     // r, g, b, flag word in the bit pattern of .w: bits 0-2 clamp flags (forward), byte 1 "reached" (backward blend)
     uint32_t* tiles_touched;
     // what the scatter needs of a visible Gaussian, compact (12 bytes, streamed): depth bits, tile rectangle
     // x0 | y0 << 16, x1 | y1 << 16 -- the records above are laid out for the blend kernels' gathers

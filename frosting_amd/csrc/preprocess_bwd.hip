@@ -29,7 +29,7 @@ namespace frg {
 #define BWD_THREADS 256
 #define BWD_SUB 16                       // Gaussians per SH transpose step
 #define BWD_ROW_F4 13                    // 12 float4 of SH + 1 pad (odd stride: conflict-free b128)
-#define BWD_LDS_WORDS (68 + 256 + 576 + BWD_SUB * BWD_ROW_F4 * 4)
+#define BWD_LDS_WORDS (68 + 256 + 576 + BWD_SUB * BWD_ROW_F4 * 4 + 64)
 // Slots are reduced in WINDOWS of BWD_WIN slots of the wave's run; a wave whose 64 Gaussians own more than
 // four windows (a handful of near-camera Gaussians covering hundreds of tiles each: one wave walked 38 000 slots while
 // the average wave has 400, and the kernel waited for it -- 0.99 instead of 0.28 ms on the clustered scene) leaves its
@@ -71,6 +71,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     int4* own_info = reinterpret_cast<int4*>(lds + 68);          // [64] x0, y0, rect width, depth bits
     float* wacc = reinterpret_cast<float*>(lds + 68 + 256);      // [64][9] per-owner sums of the current window
     float4* shbuf = reinterpret_cast<float4*>(lds + 68 + 256 + 576);  // [BWD_SUB][BWD_ROW_F4]
+    uint32_t* own_base = lds + 68 + 256 + 576 + BWD_SUB * BWD_ROW_F4 * 4;   // [64] first slot of the Gaussian, relative to the wave's first
 
     // heavy[0] = number of listed waves, heavy[1 + k] = their wave numbers (GeomState::heavy_waves, left by the forward)
   uint32_t heavy_item = HEAVY ? blockIdx.x : 0u;
@@ -98,10 +99,23 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     const uint32_t incl = valid ? point_offsets[idx] : 0u;
     const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
     const uint32_t wave_base = (uint32_t)__shfl((int)base, 0, 64);
-    uint32_t S = valid ? incl - wave_base : 0u;  // run length = max over valid lanes
+    uint32_t S_all = valid ? incl - wave_base : 0u;  // the wave's slots: run length = max over valid lanes
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) S = max(S, (uint32_t)__shfl_xor((int)S, d, 64));
-    own_start[lane] = valid ? base - wave_base : S;
+    for (int d = 32; d >= 1; d >>= 1) S_all = max(S_all, (uint32_t)__shfl_xor((int)S_all, d, 64));
+    // The run that is REDUCED holds the slots of the Gaussians the backward blend marked (FRG_REACHED_MASK: it staged one of
+    // their instances with a non-empty quadrant mask) -- a third of the slots at C3; the others' slots hold zeros or
+    // nothing.  Position sl of that run belongs to owner o = the last lane with own_start[o] <= sl and is the slot
+    // own_base[o] + (sl - own_start[o]) of the wave's slots.
+    const uint32_t n_own = (visible && (clamp_bits & FRG_REACHED_MASK)) ? incl - base : 0u;
+    uint32_t S = n_own;                              // inclusive scan over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)S, d, 64);
+        if (lane >= d) S += up;
+    }
+    own_start[lane] = S - n_own;
+    own_base[lane] = base - wave_base;
+    S = (uint32_t)__shfl((int)S, 63, 64);            // (invalid lanes: n_own = 0, their start is the run's end)
     if (lane == 0) own_start[64] = S;
     own_info[lane] = make_int4(x0, y0, x1 - x0, (int)__float_as_uint(g.z));
     // Slots of instances that provably touch no pixel of their tile (tile_hit false) hold nothing: with tight binning
@@ -131,7 +145,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // on the forward's list: the 16-wave launch has it -- unless the host skipped that launch (FRG_PBW_NO_HEAVY_LAUNCH:
     // its forward posted "no such wave"), in which case a wave that does own that many slots is reduced right here,
     // window after window: whatever the host believed, no Gaussian is left without its gradients
-    if (!HEAVY && S > (uint32_t)FRG_BWD_HEAVY_SLOTS && !(flags & FRG_PBW_NO_HEAVY_LAUNCH)) return;
+    // (the forward listed the waves by ALL their slots: the same number decides here)
+    if (!HEAVY && S_all > (uint32_t)FRG_BWD_HEAVY_SLOTS && !(flags & FRG_PBW_NO_HEAVY_LAUNCH)) return;
     // HEAVY: round r gives window 16 r + wave to this wave; non-heavy: window after window
     for (uint32_t wr = 0; wr < (HEAVY ? (nwin + BWD_HEAVY_WAVES - 1) / BWD_HEAVY_WAVES : nwin); wr++) {
         const uint32_t w0 = (HEAVY ? wr * BWD_HEAVY_WAVES + (uint32_t)wave : wr) * BWD_WIN;
@@ -192,7 +207,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 const uint32_t e = live[b0 + lane];
                 owner = (int)(e >> 10);
                 const uint32_t sl = w0 + (e & 1023u);
-                const float* sp = slots + (size_t)(wave_base + sl) * FRG_SLOT_STRIDE;
+                const float* sp = slots + (size_t)(wave_base + own_base[owner] + (sl - own_start[owner])) * FRG_SLOT_STRIDE;
 #pragma unroll
                 for (int c = 0; c < FRG_SLOT_FLOATS; c++) part[c] = sp[c];
             }
