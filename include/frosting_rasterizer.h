@@ -172,7 +172,10 @@ size_t frg_backward_workspace_bytes(int P, int R);   /* slots (36 B per instance
  * receives the clamp-masked colour gradient (backward.cu:31-34), i.e. the per-Gaussian factor dRGB of
  * dL_dsh[i][ch] = basis_i * dRGB[ch], from which frg_sh_grad_from_views rebuilds the row.  Summation order is fixed, so
  * results are bit-reproducible run to run (the reference's atomics are not).  The blend pass uses the arithmetic
- * (exact_blend) of the forward that filled the buffers -- see frg_backward_args::exact_blend. */
+ * (exact_blend) of the forward that filled the buffers -- see frg_backward_args::exact_blend.
+ * geom_buffer is WRITTEN: one byte per Gaussian ("an instance of it was reached by a pixel's walk") that the next
+ * forward on the buffer clears; a second backward on the same forward state finds the same marks.  Do not run two
+ * backwards on one geometry buffer concurrently with a forward on it (the reference's buffers have the same rule). */
 int frg_backward(int P, int D, int M, int R,
                  const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
