@@ -560,7 +560,9 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
             } else if (!(__float_as_uint(col.w) & FRG_REACHED_MASK)) {
                 // "this Gaussian has a slot that may hold a gradient": byte 1 of the record's flag word (the forward writes
                 // the word, clamp flags in byte 0, with every record).  The per-Gaussian backward reduces the slots of the
-                // marked Gaussians only.  Every writer stores the same value; a stale mark only costs that kernel time.
+                // marked Gaussians only.  Every writer stores the same value, and the set of marks is a function of the
+                // forward state alone (the cull bound and the pixels' last contributors, neither depends on the blend
+                // arithmetic or on dL/dpixel): a backward repeated on the same state finds exactly the marks it would set.
                 reinterpret_cast<uint8_t*>(const_cast<float4*>(rgb_clamped + FRG_REC * id))[13] = 1;
             }
         }

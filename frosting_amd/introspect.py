@@ -29,7 +29,8 @@ class State:
         self.conic_opacity = rec[:, 4:8]
         rgbc = rec[:, 8:12]
         self.rgb = rgbc[:, :3]
-        self.clamp_bits = rgbc[:, 3].contiguous().view(torch.int32) & 7      # (byte 1 of the word: the backward blend's "reached" mark)
+        self.flag_words = rgbc[:, 3].view(torch.int32)     # a VIEW (strided) of the records' flag words: byte 0 clamp flags, byte 1 the backward blend's "reached" mark
+        self.clamp_bits = self.flag_words.contiguous() & 7
         self.tiles_touched = _view(geom, off[3], torch.int32, P)
         self.point_offsets = _view(geom, off[4], torch.int32, P)
         L.frg_image_layout(W, H, off)

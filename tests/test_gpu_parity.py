@@ -928,6 +928,51 @@ def test_backward_uses_the_blend_arithmetic_of_its_forward(gpu_device):
         assert all(torch.equal(a, b) for a, b in zip(want[1 - exact][1], got2)), exact
 
 
+def test_reached_marks_prune_work_not_results(gpu_device):
+    """The backward blend marks the Gaussians it staged with a non-empty quadrant mask (byte 1 of the record's flag word)
+    and the per-Gaussian backward reduces the slots of the marked ones only.  The marks are a function of the forward
+    state alone, set by every backward itself: a repeated backward, or one that starts from cleared marks, gives the same
+    bits.  With EVERY Gaussian marked (the reduction before round 4's pruning) the same slots are added, grouped differently
+    into the scan's batches of 64: the same gradients to float32 rounding.  The next forward on the buffers clears the marks."""
+    from frosting_amd.introspect import State
+    scene, cam, bg = scenes.config_scene("c3", 1, P=150_000)
+    out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
+    W, H = cam.image_width, cam.image_height
+    st = State(scene.P, W, H, out[0], out[3], out[4], out[5])
+    assert int(((st.flag_words >> 8) & 0xFF).ne(0).sum()) == 0                  # a forward leaves no mark
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 13)
+    b = _bwd_args(args, out, gpix.to(gpu_device))
+    want = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
+    marked = ((st.flag_words >> 8) & 0xFF).ne(0)
+    visible = out[2] > 0
+    n_marked, n_visible = int(marked.sum()), int(visible.sum())
+    assert 0 < n_marked < n_visible, (n_marked, n_visible)                       # the marks do prune (and only visible ones carry them)
+    assert not bool((marked & ~visible).any())
+    with_grad = torch.zeros(scene.P, dtype=torch.bool, device=gpu_device)
+    for g in want:
+        with_grad |= g.reshape(scene.P, -1).ne(0).any(1)
+    assert not bool((with_grad & ~marked).any())                                 # every Gaussian with a gradient was marked
+    again = _C.rasterize_gaussians_backward(*b)                                 # the marks of the first backward are still there
+    assert all(torch.equal(x, y) for x, y in zip(want, again))
+    st.flag_words.bitwise_or_(0x100)                                             # every Gaussian marked: nothing pruned
+    for x, y in zip(want, _C.rasterize_gaussians_backward(*b)):
+        assert float((x.double() - y.double()).norm()) <= 1e-6 * float(x.double().norm())
+    st.flag_words.bitwise_and_(0xFF)                                             # none marked: this backward marks its own
+    assert all(torch.equal(x, y) for x, y in zip(want, _C.rasterize_gaussians_backward(*b)))
+    assert torch.equal(((st.flag_words >> 8) & 0xFF).ne(0), marked)
+    # a rasterizer that keeps its buffers: the next forward clears the marks of the last backward
+    from frosting_amd.parallel import ViewParallelRasterizer
+    vpr = ViewParallelRasterizer(scene.to(gpu_device), gpu_device)
+    cam_d, bg_d = cam.to(gpu_device), bg.to(gpu_device)
+    img, _ = vpr.forward(cam_d, bg_d)
+    assert torch.equal(img, out[1])
+    vpr.backward(gpix.to(gpu_device), 0)
+    stv = lambda: State(scene.P, W, H, vpr.true_num_rendered, vpr.geom.buf, vpr.binning.buf, vpr.img.buf)
+    assert torch.equal(((stv().flag_words >> 8) & 0xFF).ne(0), marked)
+    vpr.forward(cam_d, bg_d)
+    assert int(((stv().flag_words >> 8) & 0xFF).ne(0).sum()) == 0
+
+
 _HEAVY_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
