@@ -935,7 +935,7 @@ def test_reached_marks_prune_work_not_results(gpu_device):
     bits.  With EVERY Gaussian marked (the reduction before round 4's pruning) the same slots are added, grouped differently
     into the scan's batches of 64: the same gradients to float32 rounding.  The next forward on the buffers clears the marks."""
     from frosting_amd.introspect import State
-    scene, cam, bg = scenes.config_scene("c3", 1, P=150_000)
+    scene, cam, bg = scenes.config_scene("c3", 1, P=1_000_000)     # (a third of the visible Gaussians stay unreached: tools/reached_fraction.py)
     out, args = Hh.run_ours_native(scene, cam, bg, gpu_device)
     W, H = cam.image_width, cam.image_height
     st = State(scene.P, W, H, out[0], out[3], out[4], out[5])
@@ -946,7 +946,7 @@ def test_reached_marks_prune_work_not_results(gpu_device):
     marked = ((st.flag_words >> 8) & 0xFF).ne(0)
     visible = out[2] > 0
     n_marked, n_visible = int(marked.sum()), int(visible.sum())
-    assert 0 < n_marked < n_visible, (n_marked, n_visible)                       # the marks do prune (and only visible ones carry them)
+    assert 0.3 * n_visible < n_marked < 0.8 * n_visible, (n_marked, n_visible)   # the marks do prune (and only visible ones carry them)
     assert not bool((marked & ~visible).any())
     with_grad = torch.zeros(scene.P, dtype=torch.bool, device=gpu_device)
     for g in want:
@@ -955,8 +955,17 @@ def test_reached_marks_prune_work_not_results(gpu_device):
     again = _C.rasterize_gaussians_backward(*b)                                 # the marks of the first backward are still there
     assert all(torch.equal(x, y) for x, y in zip(want, again))
     st.flag_words.bitwise_or_(0x100)                                             # every Gaussian marked: nothing pruned
-    for x, y in zip(want, _C.rasterize_gaussians_backward(*b)):
-        assert float((x.double() - y.double()).norm()) <= 1e-6 * float(x.double().norm())
+    # the nine sums per Gaussian agree to rounding; the chain behind them (covariance, scales, quaternions) amplifies that
+    # on the few ill-conditioned Gaussians every scene has (section 3 of DESIGN.md), so those tensors are compared on all
+    # rows but the ceil(1e-4 P) farthest -- the same rule the gradient bars use
+    drop = -(-scene.P // 10_000)
+    report = []
+    for i, (x, y) in enumerate(zip(want, _C.rasterize_gaussians_backward(*b))):
+        d2 = (x.double() - y.double()).reshape(scene.P, -1).pow(2).sum(1)
+        kept = d2.sum() - torch.topk(d2, drop).values.sum()
+        report.append((i, float(d2.sum().sqrt() / x.double().norm()), float(kept.clamp_min(0).sqrt() / x.double().norm())))
+    assert all(r[2] <= 2e-6 for r in report), report
+    assert all(r[1] <= 2e-6 for r in report[:3]), report                         # dL_dmeans2D, dL_dcolors, dL_dopacity: no amplification
     st.flag_words.bitwise_and_(0xFF)                                             # none marked: this backward marks its own
     assert all(torch.equal(x, y) for x, y in zip(want, _C.rasterize_gaussians_backward(*b)))
     assert torch.equal(((st.flag_words >> 8) & 0xFF).ne(0), marked)
