@@ -51,6 +51,7 @@ std::atomic<int> g_global_bins{0};    // test hook: force the large-image (globa
 std::atomic<int> g_ablate{0};         // TIMING EXPERIMENTS ONLY: kernels skip parts of their work (results are wrong)
 std::atomic<int> g_async_sh{0};       // SH colours on a side stream beside the binning stages (0: inside preprocess)
 std::atomic<int> g_bwd_batch{3};      // tuning: instances per reduction step of the backward blend (2 | 3)
+std::atomic<int> g_bwd_seg_log{0};    // 0: the backward blend's segment length by the frame's instance count (frg_common.h) | 8 .. 10: pinned
 std::atomic<int> g_tight_binning{0};  // drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 in the tile
 // TIMING EXPERIMENTS ONLY (results are those of the previous frame's lists / slots): bit 0 launches the forward blend
 // beside the sort, bit 1 the per-Gaussian backward beside the backward blend -- an upper bound on what overlapping
@@ -217,7 +218,7 @@ std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every fo
 // forward, not whatever frg_set_option says by then.  A ring of kFwdNotes entries: with more forwards than that
 // outstanding the oldest are forgotten -- their backward then launches both forms of the per-Gaussian backward (as if
 // nothing had been posted) and takes the process-wide blend mode.  The pinned mailboxes are never freed.
-struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; };
+struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; int rendered = -1; };
 constexpr int kFwdNotes = 64;
 std::mutex g_heavy_mu;
 FwdNote g_fwd_notes[kFwdNotes];
@@ -226,8 +227,21 @@ unsigned g_fwd_next = 0;
 void note_forward(const void* geom, int exact)
 {
     std::lock_guard<std::mutex> lk(g_heavy_mu);
-    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = nullptr; n.seq = 0; n.exact = exact; return; }
-    g_fwd_notes[g_fwd_next++ % kFwdNotes] = FwdNote{geom, nullptr, 0, exact};
+    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = nullptr; n.seq = 0; n.exact = exact; n.rendered = -1; return; }
+    g_fwd_notes[g_fwd_next++ % kFwdNotes] = FwdNote{geom, nullptr, 0, exact, -1};
+}
+// the blocking forward on `geom` rendered R instances (a deferred forward does not know)
+void note_rendered(const void* geom, int R)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.rendered = R; return; }
+}
+// -> the instance count of the forward that last filled `geom`, or -1 when it is not remembered
+int forward_rendered(const void* geom)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (const auto& n : g_fwd_notes) if (n.geom == geom) return n.rendered;
+    return -1;
 }
 void note_heavy_post(const void* geom, const frg::Mailbox* mail, uint32_t seq)
 {
@@ -263,6 +277,31 @@ int heavy_waves_posted(const void* geom)
         if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return -1;
         cpu_relax();
     }
+}
+
+// Two-call backward (frg_backward_args::phase): phase 2 reads the nine per-Gaussian sums phase 1 left in the workspace.
+// What phase 1 was called with is remembered per workspace pointer; a phase 2 that does not match (an arena that grew or
+// was reused between the calls, another frame's buffers) is refused instead of producing garbage gradients.
+struct PhaseNote { const void* workspace = nullptr; const void* geom = nullptr; const void* image = nullptr; int P = 0, R = 0; };
+constexpr int kPhaseNotes = 16;
+PhaseNote g_phase_notes[kPhaseNotes];
+unsigned g_phase_next = 0;
+void note_phase1(const void* workspace, const void* geom, const void* image, int P, int R)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (auto& n : g_phase_notes) if (n.workspace == workspace) { n = PhaseNote{workspace, geom, image, P, R}; return; }
+    g_phase_notes[g_phase_next++ % kPhaseNotes] = PhaseNote{workspace, geom, image, P, R};
+}
+bool phase1_matches(const void* workspace, const void* geom, const void* image, int P, int R)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (auto& n : g_phase_notes)
+        if (n.workspace == workspace) {
+            const bool ok = n.geom == geom && n.image == image && n.P == P && n.R == R;
+            n = PhaseNote{};      // the sums are consumed once
+            return ok;
+        }
+    return false;
 }
 
 // Spin until the kernel's post arrives.  false: the stream failed, or it drained without the post becoming visible.
@@ -411,6 +450,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.exchange(value ? 1 : 0);
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.exchange(value == 2 ? 2 : 3);
+    if (name && strcmp(name, "bwd_seg_log") == 0) return g_bwd_seg_log.exchange(value >= FRG_BWD_SEG_LOG_MIN && value <= FRG_BWD_SEG_LOG_MAX ? value : 0);
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.exchange(value ? 1 : 0);
     if (name && strcmp(name, "fwd_prefetch") == 0) { const int old = frg::g_fwd_prefetch; frg::g_fwd_prefetch = value ? 1 : 0; return old; }
@@ -467,6 +507,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "global_bins") == 0) return g_global_bins.load();
     if (name && strcmp(name, "tight_binning") == 0) return g_tight_binning.load();
     if (name && strcmp(name, "bwd_batch") == 0) return g_bwd_batch.load();
+    if (name && strcmp(name, "bwd_seg_log") == 0) return g_bwd_seg_log.load();
     if (name && strcmp(name, "bwd_waves") == 0) return frg::g_bwd_waves;
     if (name && strcmp(name, "fwd_order") == 0) return frg::g_fwd_order;
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
@@ -481,15 +522,14 @@ int frg_get_option(const char* name)
 
 size_t frg_geometry_bytes(int P) { return frg::GeomState::carve(nullptr, P).bytes; }
 size_t frg_image_bytes(int width, int height) { return frg::ImageState::carve(nullptr, width, height, g_global_bins.load() != 0).bytes; }
-size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count).bytes; }
-// slots (36 B per instance) + the backward blend's list of full-segment work items ((tile, segment) per FRG_BWD_SEG instances)
+size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::carve(nullptr, R, max_tile_count, g_bwd_seg_log.load()).bytes; }
+// slots (36 B per instance) ...
 static size_t slots_bytes(int R) { return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256); }
-static size_t list_a_items(int R) { return (size_t)(R > 0 ? R : 1) / FRG_BWD_SEG + 8; }
-static size_t list_a_bytes(int R) { return frg::align_up(list_a_items(R) * sizeof(uint2), 256); }
-// ... + the nine per-Gaussian sums a two-call backward (frg_backward_args::phase) keeps between its calls
+// ... + the nine per-Gaussian sums a two-call backward (frg_backward_args::phase) keeps between its calls.  (The backward
+// blend's work items are listed by the forward, in its own chunks: frg_common.h, BinningState::bwd_full, ImageState::bwd_last.)
 size_t frg_backward_workspace_bytes(int P, int R)
 {
-    return slots_bytes(R) + list_a_bytes(R) + frg::align_up((size_t)(P > 0 ? P : 1) * FRG_SLOT_FLOATS * sizeof(float), 256);
+    return slots_bytes(R) + frg::align_up((size_t)(P > 0 ? P : 1) * FRG_SLOT_FLOATS * sizeof(float), 256);
 }
 
 int frg_geometry_layout_n(int P, long long* out, int n)
@@ -541,6 +581,8 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     hipStream_t stream = (hipStream_t)hip_stream;
     const FwdModes md = modes ? *modes : default_modes();
     const int exact = md.exact;
+    const int seg_forced = g_bwd_seg_log.load();      // (read once: the size asked of the callback and the carve must agree)
+    auto bin_bytes = [seg_forced](int R_, int longest) { return frg::BinningState::carve(nullptr, R_, longest, seg_forced).bytes; };
     if (P < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (!out_color) return fail(FRG_EINVAL, "out_color is null");
     if (P == 0) {  // rasterize_points.cu:68,81: zero image, background not applied
@@ -645,9 +687,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
         FRG_HIP(hipStreamWaitEvent(pend->copy_stream, pend->scanned, 0));
         FRG_HIP(hipMemcpyAsync(pend->host, img.counters, sizeof(frg::Counters), hipMemcpyDeviceToHost, pend->copy_stream));
         FRG_HIP(hipEventRecord(pend->ev, pend->copy_stream));
-        char* bin_chunk = binning_alloc(user, frg_binning_bytes(capacity, FRG_SORT_LDS_CAP + 1));
+        char* bin_chunk = binning_alloc(user, bin_bytes(capacity, FRG_SORT_LDS_CAP + 1));
         if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
-        const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1);
+        const frg::BinningState b = frg::BinningState::carve(bin_chunk, capacity, FRG_SORT_LDS_CAP + 1, seg_forced);
         FRG_STAGE(frg::launch_sort_plan(T, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)capacity, stream), "sort plan");
         { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load()), "scatter"); }
         { const int rc_ = fork_sh(3); if (rc_ < 0) return rc_; }
@@ -674,9 +716,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
             if (r > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
             if (r > 0) {
                 R = (int)r;
-                char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, FRG_SORT_LDS_CAP + 1));
+                char* bin_chunk = binning_alloc(user, bin_bytes(R, FRG_SORT_LDS_CAP + 1));
                 if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
-                b = frg::BinningState::carve(bin_chunk, R, FRG_SORT_LDS_CAP + 1);
+                b = frg::BinningState::carve(bin_chunk, R, FRG_SORT_LDS_CAP + 1, seg_forced);
                 if (g_mail.long_lists)
                     FRG_STAGE(frg::launch_sort_plan(T, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream, 1), "sort plan");
                 { StageScope sc_(ST_SCATTER, stream); FRG_STAGE(frg::launch_scatter(P, vp, radii, g, img, b, stream, g_ablate.load(), mail, mail_seq), "scatter"); }
@@ -701,11 +743,12 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (c.num_rendered > 0x7fffffffu) return fail(FRG_EINVAL, "num_rendered overflows int32");
     R = (int)c.num_rendered;
     const int max_tile = (int)c.max_tile_count;
+    note_rendered(geom_chunk, R);
 
     if (!early) {
-        char* bin_chunk = binning_alloc(user, frg_binning_bytes(R, max_tile));
+        char* bin_chunk = binning_alloc(user, bin_bytes(R, max_tile));
         if (!bin_chunk) return fail(FRG_EALLOC, "binning allocation callback returned null");
-        b = frg::BinningState::carve(bin_chunk, R, max_tile);
+        b = frg::BinningState::carve(bin_chunk, R, max_tile, seg_forced);
     }
     const bool forked_plan = early && g_mail.long_lists;
     if (mail) g_mail.long_lists = c.class_count[4] > 0;
@@ -855,6 +898,14 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         return fail(FRG_EINVAL, "null gradient output for a provided input");
     if (workspace_bytes < frg_backward_workspace_bytes(P, R) || !workspace)
         return fail(FRG_EALLOC, "workspace too small: need %zu bytes", frg_backward_workspace_bytes(P, R));
+    // R sizes the slots and the backward blend's item list: fewer than the forward rendered would overrun them.  (More is
+    // fine -- a deferred forward's capacity: where the forward's checkpoints lie in the binning chunk is taken from what the
+    // forward stamped, Counters::carved_R, not from R.)
+    {
+        const int rendered = forward_rendered(geom_buffer);
+        if (rendered >= 0 && R < rendered)
+            return fail(FRG_EINVAL, "R = %d, but the forward that filled this geometry buffer rendered %d instances", R, rendered);
+    }
     (void)colors_precomp;  // forward copied precomputed colours into the geometry state
 
     // Nothing here depends on the process-wide binning options: every field of the three chunks that the
@@ -866,9 +917,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const frg::ImageState img = frg::ImageState::carve(image_buffer, width, height, false);
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
-    uint2* list_a = reinterpret_cast<uint2*>(workspace + slots_bytes(R));
-    const uint32_t list_a_cap = (uint32_t)list_a_items(R);
-    float* sums = reinterpret_cast<float*>(workspace + slots_bytes(R) + list_a_bytes(R));
+    float* sums = reinterpret_cast<float*>(workspace + slots_bytes(R));
     if (phase < 0 || phase > 2) return fail(FRG_EINVAL, "frg_backward_args: phase %d (0 whole | 1 blend + slot sums | 2 the rest)", phase);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
@@ -879,24 +928,27 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     out.dL_dshell_verts = dL_dshell_verts;
     const int pbw_flags = phase == 1 ? FRG_PBW_SUMS_ONLY : phase == 2 ? FRG_PBW_FROM_SUMS : 0;
     if (phase == 2) {     // the sums are in the workspace: one launch, no slot reduction, hence no 16-wave form either
+        if (!phase1_matches(workspace, geom_buffer, image_buffer, P, R))
+            return fail(FRG_EINVAL, "backward phase 2 without a matching phase 1 on this workspace (same P, R, geometry and image buffers)");
         StageScope sc_(ST_PREPROCESS_BWD, stream);
         FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | FRG_PBW_NO_HEAVY_LAUNCH, false, stream, sums), "preprocess_bwd (phase 2)");
         return FRG_OK;
     }
+    if (phase == 1) note_phase1(workspace, geom_buffer, image_buffer, P, R);
     const bool probe_bwd = (g_probe.load() & 2) && g_probe_side.ensure();
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
         FRG_HIP(hipStreamWaitEvent(g_probe_side.stream, g_probe_side.fork, 0));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, false, g_probe_side.stream));
-        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, g_probe_side.stream));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, false, g_probe_side.stream, sums));
+        FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, g_probe_side.stream, sums));
         FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
     }
     {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream), "blend_bwd");
         else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, list_a, list_a_cap, g_bwd_batch.load(), stream), "blend_bwd");
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
     {

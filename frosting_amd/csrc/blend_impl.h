@@ -5,7 +5,7 @@
 //     quadrants of one tile; its waves never synchronise with each other), one pixel per
 //     lane: 45 VGPRs, so 8 waves per SIMD hide the LDS / transcendental latency of the
 //     per-Gaussian dependent chain, and a quadrant that saturates retires on its own;
-//   * BACKWARD: one wave per SEGMENT of a tile's processed list prefix (FRG_BWD_SEG entries; the forward
+//   * BACKWARD: one wave per SEGMENT of a tile's processed list prefix (256 / 512 entries by frame; the forward
 //     leaves the pixels' state at the boundaries, so a segment starts anywhere), four pixels per lane
 //     (one per quadrant): the nine gradient components of a (tile, Gaussian) pair are first summed over
 //     the lane's pixels, so the cross-lane reduction -- the single most expensive step -- is paid once
@@ -68,6 +68,17 @@ struct BlendMath<false> {
     // The staging lane folds the -1/2 of the exponent and the log2(e) of exp -> exp2 into the conic once per
     // Gaussian (stage()); per pixel: power' = dx (a' dx + b' dy) + c' dy^2 in log2 units, G = exp2(power').
     // Seven instructions and one v_exp instead of ten and one; `power > 0` keeps its sign.
+    // FRG_AB_* (tools/build_variants.sh, A/B builds only): one ingredient of the default arithmetic at a time replaced by
+    // the EXACT form, to attribute its distance to the float64 gradient ("which instruction").
+#if defined(FRG_AB_POWER)
+    static __device__ __forceinline__ float4 stage(float4 co) { return co; }
+    static __device__ __forceinline__ float power(float x, float y, float4 co, float px, float py, float& dx, float& dy)
+    {
+        dx = x - px; dy = y - py;
+        return -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+    }
+    static __device__ __forceinline__ float expo(float p) { return __builtin_amdgcn_exp2f(1.4426950408889634f * p); }
+#else
     static __device__ __forceinline__ float4 stage(float4 co)
     {
         const float l2e = 1.4426950408889634f;
@@ -79,9 +90,28 @@ struct BlendMath<false> {
         const float t = __builtin_fmaf(sc.x, dx, sc.y * dy);
         return __builtin_fmaf(t, dx, (sc.z * dy) * dy);
     }
+#if defined(FRG_AB_EXP)
+    static __device__ __forceinline__ float expo(float p) { return exp2f(p); }          // libm's exp2f instead of the raw v_exp_f32
+#else
     static __device__ __forceinline__ float expo(float p) { return __builtin_amdgcn_exp2f(p); }
+#endif
+#endif
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
+#if defined(FRG_AB_RCP)
+    static __device__ __forceinline__ float recip(float x) { return 1.0f / x; }
+#else
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
+#endif
+#if defined(FRG_AB_NOFMA)
+    static __device__ __forceinline__ float mad(float a, float b, float c) { return a * b + c; }
+    static __device__ __forceinline__ float attenuate(float T, float alpha) { return T * (1 - alpha); }
+    static __device__ __forceinline__ void accumulate(float4 c, float alpha, float T, float& C0, float& C1, float& C2)
+    {
+        C0 = mad(c.x * alpha, T, C0);
+        C1 = mad(c.y * alpha, T, C1);
+        C2 = mad(c.z * alpha, T, C2);
+    }
+#else
     static __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     // T (1 - alpha) as one FMA; the weight alpha T once per pixel and one FMA per channel (four instructions
     // instead of six, one instead of two: 3 of the forward blend's 24 vector instructions per list entry)
@@ -93,6 +123,7 @@ struct BlendMath<false> {
         C1 = __builtin_fmaf(c.y, w, C1);
         C2 = __builtin_fmaf(c.z, w, C2);
     }
+#endif
 };
 
 #define BLEND_THREADS 256   // 4 waves = the 4 quadrants of one tile
@@ -124,9 +155,17 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  float* __restrict__ out_color, uint32_t* __restrict__ tile_work, float4* __restrict__ ckpt,
-                 float4* __restrict__ final_C, const uint32_t* __restrict__ class_tiles, const uint32_t* __restrict__ class_count)
+                 float4* __restrict__ final_C, const uint32_t* __restrict__ class_tiles, const uint32_t* __restrict__ class_count,
+                 int seg_log, uint32_t* __restrict__ bwd_cnt, uint32_t* __restrict__ bwd_last, uint32_t cap_b,
+                 uint2* __restrict__ bwd_full, uint32_t cap_a, uint2* __restrict__ cutoff, Counters* __restrict__ counters)
 {
     using M = BlendMath<EXACT>;
+    const int SEG = 1 << seg_log;      // entries per segment of the backward blend (frg_common.h: bwd_seg_log)
+    // how deep the tile was walked, over its four quadrant waves: the last of them to finish lists the tile's backward items
+    __shared__ uint32_t s_deep, s_done;
+    if (threadIdx.x == 0) { s_deep = 0u; s_done = 0u; }
+    __syncthreads();                   // the only workgroup barrier of the kernel: the four waves start together anyway
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters->bwd_seg_log = (uint32_t)seg_log;
     int tile;
     if (class_tiles) {
         // The tiles LONGEST LIST FIRST (the sort's size classes, longest class first, eight descending buckets inside a
@@ -180,17 +219,17 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         col_n = rgb_clamped[FRG_REC * id];
     };
     if (PREFETCH && n > 0) fetch(0);
-    // The list is walked segment by segment (FRG_BWD_SEG entries: the work items of the backward blend).  At every
+    // The list is walked segment by segment (SEG entries: the work items of the backward blend).  At every
     // boundary the quadrant crosses, the state of its pixels BEFORE the segment's first entry is left for the backward's
     // item of the segment that ends there (a pixel that has stopped leaves stale values nobody reads: its last contributor
     // lies in front of the boundary): 1 KB per quadrant and boundary, contiguous.  The inner loop is the loop of rounds 1-3.
     bool saturated = false;
-    for (int sbase = 0; sbase < n && !saturated; sbase += FRG_BWD_SEG) {
+    for (int sbase = 0; sbase < n && !saturated; sbase += SEG) {
     if (sbase != 0) {
         if (wave_ballot(alive != 0.0f) == 0ull) break;
-        ckpt[((size_t)(rg.x / FRG_BWD_SEG) + (size_t)(sbase / FRG_BWD_SEG)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
+        ckpt[((size_t)(rg.x >> seg_log) + (size_t)(sbase >> seg_log)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
     }
-    const int send = min(n, sbase + FRG_BWD_SEG);
+    const int send = min(n, sbase + SEG);
     for (int base = sbase; base < send; base += 64) {
         if (wave_ballot(alive != 0.0f) == 0ull) { saturated = true; break; }   // this quadrant is saturated
         const int cnt = min(64, n - base);
@@ -249,123 +288,98 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         out_color[plane + pid] = M::mad(Tr, bg[1], C1);
         out_color[2 * plane + pid] = M::mad(Tr, bg[2], C2);
     }
-    // how deep this tile's list was walked: the backward blend's work per tile (bwd_order_kernel cuts it into segments)
+    // how deep this quadrant walked the tile's list
     uint32_t deepest = inside ? last : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, d, 64));
-    if (lane == 0 && deepest) atomicMax(&tile_work[tile], deepest);
     // a pixel whose last contributor lies behind a segment boundary: the backward needs the colour it ended with
-    if (deepest > (uint32_t)FRG_BWD_SEG) final_C[(size_t)tile * FRG_TILE_PIX + q * 64 + lane] = make_float4(C0, C1, C2, 0.0f);
+    if (deepest > (uint32_t)SEG) final_C[(size_t)tile * FRG_TILE_PIX + q * 64 + lane] = make_float4(C0, C1, C2, 0.0f);
+    // ---- the tile's work items for the backward blend (see "Work items" below) ----
+    // The tile's processed prefix = the deepest walk of its four waves; the wave that finishes LAST (LDS counter) lists
+    //   * its last segment in the length bucket of its XCD band (bwd_last, bwd_cnt[x][bucket]),
+    //   * its full segments (tile, k) in the band's list (bwd_full, bwd_cnt[x][FRG_BWD_LEN_BUCKETS]),
+    // with one relaxed device-scope atomic each: ~13 000 of them spread over the kernel's 0.2 ms at C3.  The order inside
+    // a list is the order in which the tiles finished -- it differs from run to run, the backward's results do not
+    // (every slot is written once, whoever processes its item: test_backward_blend_work_items_whatever_the_grid).
+    // A tile in which nothing was blended gets its cutoff key cleared here (the per-Gaussian backward must not find
+    // the key an earlier frame left for it).
+    uint32_t prev = 0;
+    if (lane == 0) {
+        if (deepest) atomicMax(&s_deep, deepest);                // ds_max_u32
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        prev = atomicAdd(&s_done, 1u);                           // ds_add_rtn_u32
+    }
+    prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+    if (prev != BLEND_THREADS / 64 - 1) return;                 // wave-uniform: not the last wave of the tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t wk = __hip_atomic_load(&s_deep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) tile_work[tile] = wk;
+    if (wk == 0u) { if (lane == 0) cutoff[tile] = make_uint2(0u, 0u); return; }
+    const int xb = xcd_of_tile(tile, T);
+    const uint32_t nfull = (wk - 1u) >> seg_log;
+    uint32_t at = 0;
+    if (lane == 0) {
+        const uint32_t bucket = (uint32_t)(FRG_BWD_LEN_BUCKETS - 1) - ((((wk - 1u) & (uint32_t)(SEG - 1)) * FRG_BWD_LEN_BUCKETS) >> seg_log);
+        uint32_t* cnt = bwd_cnt + xb * (FRG_BWD_LEN_BUCKETS + 1);
+        const uint32_t slot = __hip_atomic_fetch_add(&cnt[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < cap_b) bwd_last[((size_t)xb * FRG_BWD_LEN_BUCKETS + bucket) * cap_b + slot] = (uint32_t)tile;
+        if (nfull) at = __hip_atomic_fetch_add(&cnt[FRG_BWD_LEN_BUCKETS], nfull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (nfull) {
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        for (uint32_t sgm = (uint32_t)lane; sgm < nfull; sgm += 64u)
+            if (at + sgm < cap_a) bwd_full[(size_t)xb * cap_a + at + sgm] = make_uint2((uint32_t)tile, sgm);
+    }
 }
 
 // Work items of the backward blend.  A tile's processed prefix (tile_work[t] entries: up to the last contributor of its
-// last pixel) is cut into SEGMENTS of FRG_BWD_SEG entries; every segment is one work item of one wave.  Round 1-3 gave
+// last pixel) is cut into SEGMENTS of 1 << seg_log entries; every segment is one work item of one wave.  Round 1-3 gave
 // a whole tile to one wave (or, on frames with few active tiles, to four): 324..1077 entries at C3, but 10^3..5 10^3 at
 // the limb of a shell seen from outside (C4) and 10^4..10^5 in a cluster -- the frame then waited for its deepest tile
 // (C4: 0.58 ms for 2.9 M tile-entries, when C3's 4.3 M take 0.39).  A segment can start anywhere because the forward left the
 // state there (BinningState::ckpt): the walk is a scan, and a scan can be restarted from a stored prefix.
-// bwd_order_kernel (one workgroup) builds, per XCD band of tiles (neighbouring tiles share their Gaussians: same L2),
+// The items are listed by the FORWARD blend's tile workgroups as they finish (blend_fwd_kernel's tail; round 4 had a
+// single-workgroup ordering kernel in front of the backward: 17 us of cold-code latency chain per step), per XCD band of
+// tiles (neighbouring tiles share their Gaussians: same L2):
 //   list A  the FULL segments (tile, k), k < nseg - 1: all the same length, longest items of the frame, pulled first;
-//   list B  every active tile's LAST segment, by decreasing length in 32 buckets;
-// and the header blend_bwd_kernel's waves find their items through (BwdHdr).  The assignment is STATIC: XCD x's waves
-// stride over its items (A then B, one index space) -- no work queue: 4096 waves pulling from eight cursors with
-// device-scope atomics, which execute behind the XCDs' L2s one at a time per address, took 0.55 instead of 0.41 ms at C3.
-// What keeps the XCDs even is the header's pool: every XCD is given the same number of items (m = N / 8), an XCD with
-// more than that donates its LAST (shortest) ones, one with fewer takes from the pool.  Tiles in which the forward
-// blended nothing get their cutoff key cleared here (the per-Gaussian backward must not find an earlier frame's).
-struct BwdHdr {
-    // word 0: unused | 1: active tiles | 2: items in all
-    // words 8 + 8 x ..: A start, A count, B start, B count, m (items this XCD's waves process), its first pool index
-    //                   (when it has fewer than m of its own), the pool index of its first donated item (when more)
-    __host__ __device__ static int words() { return 8 + 8 * FRG_NUM_XCD; }
-    __device__ static const uint32_t* xcd(const uint32_t* h, int x) { return h + 8 + 8 * x; }
-    __device__ static uint32_t* xcd(uint32_t* h, int x) { return h + 8 + 8 * x; }
+//   list B  every active tile's LAST segment, in 32 buckets by decreasing length.
+// Every backward wave derives from the 8 x 33 counters what round 4's kernel wrote into a header (BwdShares below).  The
+// assignment is STATIC: XCD x's waves stride over its items (A then B, one index space) -- no work queue: 4096 waves
+// pulling from eight cursors with device-scope atomics, which execute behind the XCDs' L2s one at a time per address,
+// took 0.55 instead of 0.41 ms at C3.  What keeps the XCDs even is the pool: every XCD is given the same number of items
+// (m = N / 8), an XCD with more than that donates its LAST (shortest) ones, one with fewer takes from the pool.
+struct BwdShares {
+    uint32_t cnt[FRG_NUM_XCD * (FRG_BWD_LEN_BUCKETS + 1)];   // the forward's counters, as loaded
+    uint32_t own[FRG_NUM_XCD];      // items of the XCD's own band (A + B)
+    uint32_t m[FRG_NUM_XCD];        // items its waves process
+    uint32_t pool[FRG_NUM_XCD];     // own < m: its first index in the pool | own > m: the pool index of its first donated item
+    // one wave: load the counters and derive the shares (s points to LDS)
+    static __device__ __forceinline__ void build(BwdShares* s, const uint32_t* __restrict__ bwd_cnt, int lane)
+    {
+        constexpr int NCNT = FRG_NUM_XCD * (FRG_BWD_LEN_BUCKETS + 1);
+        for (int i = lane; i < NCNT; i += 64) s->cnt[i] = bwd_cnt[i];
+        __syncthreads();
+        if (lane < FRG_NUM_XCD) {
+            uint32_t sum = 0;
+#pragma unroll 1
+            for (int k = 0; k <= FRG_BWD_LEN_BUCKETS; k++) sum += s->cnt[lane * (FRG_BWD_LEN_BUCKETS + 1) + k];
+            s->own[lane] = sum;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t N = 0;
+            for (int x = 0; x < FRG_NUM_XCD; x++) N += s->own[x];
+            // even shares: m_x = N / 8 (+ 1 for the first N % 8); donors' excess and takers' deficits line up in one pool
+            uint32_t taken = 0, given = 0;
+            for (int x = 0; x < FRG_NUM_XCD; x++) {
+                const uint32_t m = N / FRG_NUM_XCD + ((uint32_t)x < N % FRG_NUM_XCD ? 1u : 0u), own = s->own[x];
+                s->m[x] = m;
+                if (own < m) { s->pool[x] = taken; taken += m - own; } else { s->pool[x] = given; given += own - m; }
+            }
+        }
+        __syncthreads();
+    }
 };
-#define FRG_BWD_LEN_BUCKETS 32
-static __global__ void __launch_bounds__(1024)
-bwd_order_kernel(int T, const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order, uint2* __restrict__ list_a,
-                 uint32_t list_a_cap, uint32_t* __restrict__ hdr, uint2* __restrict__ cutoff)
-{
-    // One workgroup, on the backward's critical path: its latency is what counts.  The tiles' walk depths are loaded ONCE,
-    // as one batch of independent requests per thread (up to BWD_ORDER_K x 1024 tiles stay in registers between the
-    // counting and the placing pass; larger images read the rest again), the 256 bucket counters are scanned by 256 lanes.
-    constexpr int BWD_ORDER_K = 10;
-    __shared__ uint32_t base[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS], cur[FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS];
-    __shared__ uint32_t a_cnt[FRG_NUM_XCD], a_base[FRG_NUM_XCD], a_cur[FRG_NUM_XCD], a_lim[FRG_NUM_XCD], b_cnt[FRG_NUM_XCD], b_start[FRG_NUM_XCD];
-    __shared__ uint32_t n_active;
-    const int tid = threadIdx.x;
-    if (tid < FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS) { base[tid] = 0; cur[tid] = 0; }
-    if (tid < FRG_NUM_XCD) { a_cnt[tid] = 0; a_cur[tid] = 0; }
-    if (tid == 0) n_active = 0;
-    uint32_t wkr[BWD_ORDER_K];
-#pragma unroll
-    for (int i = 0; i < BWD_ORDER_K; i++) { const int t = tid + i * 1024; wkr[i] = t < T ? tile_work[t] : 0u; }
-    __syncthreads();
-    // last segment of tile t: entries (tile_work - 1) % SEG + 1; bucket 0 = the longest
-    auto bucket_of = [](uint32_t wk) { return (FRG_BWD_LEN_BUCKETS - 1) - (((wk - 1u) % FRG_BWD_SEG) * FRG_BWD_LEN_BUCKETS) / FRG_BWD_SEG; };
-    auto count = [&](int t, uint32_t wk) {
-        // a tile in which the forward blended nothing processes no instance: its cutoff key says so HERE (the per-Gaussian
-        // backward must not find the key an earlier frame left for it)
-        if (!wk) { cutoff[t] = make_uint2(0u, 0u); return 0u; }
-        const int x = xcd_of_tile(t, T);
-        atomicAdd(&base[x * FRG_BWD_LEN_BUCKETS + bucket_of(wk)], 1u);
-        if (wk > (uint32_t)FRG_BWD_SEG) atomicAdd(&a_cnt[x], (wk - 1u) / FRG_BWD_SEG);
-        return 1u;
-    };
-    uint32_t mine = 0;
-#pragma unroll
-    for (int i = 0; i < BWD_ORDER_K; i++) { const int t = tid + i * 1024; if (t < T) mine += count(t, wkr[i]); }
-    for (int t = tid + BWD_ORDER_K * 1024; t < T; t += 1024) mine += count(t, tile_work[t]);
-    if (mine) atomicAdd(&n_active, mine);
-    __syncthreads();
-    // bucket starts relative to the XCD's first entry: lane = (XCD, bucket), two XCDs per wave
-    if (tid < FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS) {
-        static_assert(FRG_BWD_LEN_BUCKETS == 32, "two XCDs' buckets per wave");
-        const uint32_t c = base[tid];
-        const uint32_t incl = wave_incl_scan_dpp(c);
-        const uint32_t lower = (uint32_t)__shfl((int)incl, 31, 64);          // total of the wave's first XCD
-        const bool upper = (tid & 32) != 0;
-        base[tid] = incl - c - (upper ? lower : 0u);
-        if ((tid & 31) == 31) b_cnt[tid >> 5] = incl - (upper ? lower : 0u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0, arun = 0, own[FRG_NUM_XCD];
-        for (int x = 0; x < FRG_NUM_XCD; x++) {
-            uint32_t* l = BwdHdr::xcd(hdr, x);
-            b_start[x] = run; l[2] = run; l[3] = b_cnt[x]; run += b_cnt[x];
-            // (the caller sizes list A for R / SEG items, which bounds their number; the clamp only guards the buffer)
-            const uint32_t ac = min(a_cnt[x], list_a_cap - min(list_a_cap, arun));
-            a_base[x] = arun; a_lim[x] = ac; l[0] = arun; l[1] = ac; arun += ac;
-            own[x] = ac + b_cnt[x];
-        }
-        // even shares: m_x = N / 8 (+ 1 for the first N % 8); donors' excess and takers' deficits line up in one pool
-        const uint32_t N = run + arun;
-        uint32_t taken = 0, given = 0;
-        for (int x = 0; x < FRG_NUM_XCD; x++) {
-            uint32_t* l = BwdHdr::xcd(hdr, x);
-            const uint32_t m = N / FRG_NUM_XCD + ((uint32_t)x < N % FRG_NUM_XCD ? 1u : 0u);
-            l[4] = m; l[5] = taken; l[6] = given; l[7] = 0;
-            if (own[x] < m) taken += m - own[x]; else given += own[x] - m;
-        }
-        hdr[0] = 0u; hdr[1] = n_active; hdr[2] = N;
-    }
-    __syncthreads();
-    auto place = [&](int t, uint32_t wk) {
-        if (!wk) return;
-        const int x = xcd_of_tile(t, T);
-        const int k = bucket_of(wk);
-        order[b_start[x] + base[x * FRG_BWD_LEN_BUCKETS + k] + atomicAdd(&cur[x * FRG_BWD_LEN_BUCKETS + k], 1u)] = (uint32_t)t;
-        if (wk > (uint32_t)FRG_BWD_SEG) {
-            const uint32_t nfull = (wk - 1u) / FRG_BWD_SEG, at = atomicAdd(&a_cur[x], nfull);
-            for (uint32_t sgm = 0; sgm < nfull; sgm++)
-                if (at + sgm < a_lim[x]) list_a[a_base[x] + at + sgm] = make_uint2((uint32_t)t, sgm);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < BWD_ORDER_K; i++) { const int t = tid + i * 1024; if (t < T) place(t, wkr[i]); }
-    for (int t = tid + BWD_ORDER_K * 1024; t < T; t += 1024) place(t, tile_work[t]);
-}
 
 // 4-bit version for the tile-per-wave backward: bit q <=> quadrant q may be touched
 __device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float4 co, int tx, int ty)
@@ -404,9 +418,9 @@ __device__ __forceinline__ float fold_two(float a, float b)
 }
 
 // BWD_BATCH: instances whose partial sums are reduced together (2 or 3: 18 / 27 matrix rows, two lanes per row)
-// One wave per workgroup; the waves of XCD x take that XCD's (tile, segment) items (bwd_order_kernel: the full segments
-// first, then the tiles' last segments by decreasing length) by a static rule -- see the item loop.  An item walks the
-// list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
+// One wave per workgroup; the waves of XCD x take that XCD's (tile, segment) items (listed by the forward blend: the full
+// segments first, then the tiles' last segments by decreasing length) by a static rule -- see the item loop.  An item walks
+// the list positions [seg * SEG, min((seg + 1) * SEG, walked)) back to front.
 template <bool EXACT, int BWD_BATCH>
 __global__ void __launch_bounds__(64, EXACT ? 3 : 4)      // default arithmetic: 128 VGPRs without a spill instead of 130 -- the 16th wave per CU
 blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ ranges,
@@ -414,12 +428,21 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const float4* __restrict__ conic_opacity, const float4* rgb_clamped /* one byte of .w is written: no restrict */,
                  const uint32_t* __restrict__ point_offsets, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ hdr, const uint2* __restrict__ list_a, const uint32_t* __restrict__ tile_work,
-                 const float4* __restrict__ ckpt, const float4* __restrict__ final_C)
+                 const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff,
+                 const uint32_t* __restrict__ bwd_cnt, const uint32_t* __restrict__ bwd_last, uint32_t cap_b,
+                 const uint32_t* __restrict__ tile_work,
+                 const char* __restrict__ binning_base, const Counters* __restrict__ counters, const float4* __restrict__ final_C)
 {
     using M = BlendMath<EXACT>;
     const int lane = threadIdx.x;
+    // The forward's checkpoints and its list of full-segment items: behind point_list and pairs of the chunk as the FORWARD
+    // carved it (Counters::carved_R) -- the R this backward was called with may be the frame's instance count or a deferred
+    // forward's capacity; the segment length is the one the forward blend stamped.
+    const uint32_t carved_R = counters->carved_R;
+    const int seg_log = (int)counters->bwd_seg_log;
+    const float4* __restrict__ ckpt = reinterpret_cast<const float4*>(binning_base + BinningState::ckpt_offset(carved_R));
+    const uint2* __restrict__ bwd_full = reinterpret_cast<const uint2*>(binning_base + BinningState::full_offset(carved_R));
+    const uint32_t cap_a = (uint32_t)BinningState::full_cap(carved_R > 0u ? carved_R : 1u);
 
     __shared__ float4 s_a[64];     // x, y, quadrant mask, 0-based list position
     __shared__ float4 s_co[64];
@@ -430,47 +453,63 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
     // is worth more than the conflicts: 0.389 -> 0.407 ms; an XOR swizzle of the chunks by the row number keeps
     // the size but needs eight address registers: 130 VGPRs, three waves per SIMD.)
     __shared__ __attribute__((aligned(16))) float s_red[BWD_BATCH * FRG_SLOT_FLOATS * 64];   // reduction matrix, one column per lane
+    // the XCDs' shares of the frame's items (BwdShares) live in the reduction matrix's space, which no item uses before
+    // its first batch: built at the head of every round of the item loop (one round for nearly every wave)
+    static_assert(sizeof(BwdShares) <= sizeof(float) * BWD_BATCH * FRG_SLOT_FLOATS * 64, "BwdShares must fit the reduction matrix");
+    BwdShares* sh = reinterpret_cast<BwdShares*>(s_red);
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t plane = (size_t)H * W;
 
-    // ---- the item loop: static, no queue (see BwdHdr) ----
+    // ---- the item loop: static, no queue (see BwdShares) ----
     // Wave w of the W waves of XCD x takes the items k = r W + w (r even) / r W + (W - 1 - w) (r odd) of its XCD's m
     // items, r = 0, 1, ...: the items are in decreasing length, so the boustrophedon gives the wave with the longest
     // item of one round the shortest of the next.  The grid is usually larger than the frame has items (every wave then
     // has at most one: the hardware's dispatcher does the balancing, as it did with one workgroup per tile).
     const int my_xcd = (int)(blockIdx.x % FRG_NUM_XCD);
     const uint32_t W_ = gridDim.x / FRG_NUM_XCD, w_ = blockIdx.x / FRG_NUM_XCD;
-    const uint32_t* mine = BwdHdr::xcd(hdr, my_xcd);
-    const uint32_t my_own = mine[1] + mine[3], my_m = mine[4], my_pool = mine[5];
+    uint32_t my_m = 1u;               // (known after the first build)
   for (uint32_t round = 0; round * W_ < my_m; round++) {
+    __syncthreads();               // the previous item's readers of the reduction matrix and the staging arrays are done
+    BwdShares::build(sh, bwd_cnt, lane);
+    my_m = sh->m[my_xcd];
+    const uint32_t my_own = sh->own[my_xcd], my_pool = sh->pool[my_xcd];
     const uint32_t k = round * W_ + ((round & 1u) ? W_ - 1u - w_ : w_);
-    if (k >= my_m) continue;        // (the last, partial round)
     // item k of this XCD: one of its own, or -- an XCD with fewer than its share -- one from the pool of the others' excess
-    int src = my_xcd;
+    int src = k < my_m ? my_xcd : -1;  // (k >= my_m: the last, partial round)
     uint32_t ks = k;
-    if (k >= my_own) {
-        uint32_t j = my_pool + (k - my_own);
+    if (src >= 0 && k >= my_own) {
+        const uint32_t j = my_pool + (k - my_own);
         src = -1;
         for (int d = 0; d < FRG_NUM_XCD; d++) {
-            const uint32_t* o = BwdHdr::xcd(hdr, d);
-            const uint32_t own = o[1] + o[3], m = o[4];
-            if (own > m && j >= o[6] && j < o[6] + (own - m)) { src = d; ks = m + (j - o[6]); }
+            const uint32_t own = sh->own[d], m = sh->m[d], first = sh->pool[d];
+            if (own > m && j >= first && j < first + (own - m)) { src = d; ks = m + (j - first); }
         }
     }
     int tile = -1;
-    uint32_t seg = 0, walked = 0;
+    uint32_t seg = 0xFFFFFFFFu;        // 0xFFFFFFFF: the tile's last segment
     if (src >= 0) {
-        const uint32_t* l = BwdHdr::xcd(hdr, src);
-        if (ks < l[1]) { const uint2 it = list_a[l[0] + ks]; tile = (int)it.x; seg = it.y; walked = tile_work[tile]; }
-        else { tile = (int)order[l[2] + (ks - l[1])]; walked = tile_work[tile]; seg = (walked - 1u) / FRG_BWD_SEG; }
+        const uint32_t* c = sh->cnt + src * (FRG_BWD_LEN_BUCKETS + 1);
+        const uint32_t na = c[FRG_BWD_LEN_BUCKETS];             // (<= cap_a: the forward sized the list for R / SEG items, and clamps)
+        if (ks < na) { if (ks < cap_a) { const uint2 it = bwd_full[(size_t)src * cap_a + ks]; tile = (int)it.x; seg = it.y; } }
+        else {
+            uint32_t j = ks - na;
+#pragma unroll 1
+            for (int bk = 0; bk < FRG_BWD_LEN_BUCKETS; bk++) {
+                const uint32_t cb = c[bk];
+                if (j < cb) { if (j < cap_b) tile = (int)bwd_last[((size_t)src * FRG_BWD_LEN_BUCKETS + bk) * cap_b + j]; break; }
+                j -= cb;
+            }
+        }
     }
-    if (tile < 0) continue;         // (cannot happen: the pool is exactly the excess)
+    __syncthreads();                   // the shares are dead: the reduction matrix is free
+    if (tile < 0) continue;            // wave-uniform (the last, partial round; cannot happen otherwise: the pool is exactly the excess)
+    const uint32_t walked = tile_work[tile];
+    if (seg == 0xFFFFFFFFu) seg = (walked - 1u) >> seg_log;
     const int tx = tile % gx, ty = tile / gx;
     const uint2 rg = ranges[tile];
-    const int seg_lo = (int)(seg * FRG_BWD_SEG);
-    const uint32_t seg_end = min(walked, (seg + 1u) * FRG_BWD_SEG);     // exclusive; == walked for the tile's last segment
+    const int seg_lo = (int)(seg << seg_log);
+    const uint32_t seg_end = min(walked, (seg + 1u) << seg_log);        // exclusive; == walked for the tile's last segment
     const bool last_seg = seg_end == walked;
-    __syncthreads();               // the previous item's readers of the staging arrays are done
 
     // Per-pixel state of the back-to-front walk.  The reference carries the colour
     // composited behind the current Gaussian (accum_rec, last_color, last_alpha:
@@ -496,7 +535,7 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
         S[q] = Tr[q] * M::mad(bg2, dLp[q][2], M::mad(bg1, dLp[q][1], bg0 * dLp[q][0]));
     }
     if (!last_seg) {               // wave-uniform: some pixel may go on behind this segment
-        const float4* ck = ckpt + ((size_t)(rg.x / FRG_BWD_SEG) + (size_t)(seg + 1u)) * FRG_TILE_PIX;
+        const float4* ck = ckpt + ((size_t)(rg.x >> seg_log) + (size_t)(seg + 1u)) * FRG_TILE_PIX;
         const float4* fc = final_C + (size_t)tile * FRG_TILE_PIX;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -693,14 +732,16 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 #define FRG_FWD(PF)                                                                                                        \
     hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,   \
-                       out_color, img.tile_work, b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr, img.counters->class_count)
+                       out_color, img.tile_work, b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr,             \
+                       img.counters->class_count, b.seg_log, img.bwd_cnt, img.bwd_last, img.bwd_cap_b, b.bwd_full,         \
+                       (uint32_t)BinningState::full_cap(b.carved_R), img.cutoff, img.counters)
     if (prefetch) FRG_FWD(true); else FRG_FWD(false);
 #undef FRG_FWD
     return hipGetLastError();
 }
 
-// list_a: room for list_a_cap (tile, segment) items behind the slots (frg_backward_workspace_bytes); waves: the persistent
-// single-wave workgroups of the segmented form (16 per CU fit the LDS)
+// R: the instance count the caller sized the slots for -- an upper bound on the frame's items: one last segment per tile +
+// R / (shortest segment) full ones; waves: the single-wave workgroups of the segmented form (16 per CU fit the LDS)
 // measured, backward blend at C3 / C4: segments of 1024 -- 2048 waves 0.69 / 0.56 ms, 4096 (= what is resident at once) with a
 // queue 0.55 / 0.39, 8192 0.41 / 0.39; segments of 512 (13 000 items at C3) -- 8192 waves 0.386 / 0.370, 16384 0.363 / 0.368,
 // 32768 0.366 / 0.371: one item per wave and the hardware's dispatcher, while the items fit the grid
@@ -708,19 +749,18 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 extern int g_bwd_waves;       // tuning (frg_set_option("bwd_waves")): single-wave workgroups of the backward blend (0: the default)
 template <bool EXACT>
 static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                     const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                     int batch, hipStream_t s)
+                                     const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s)
 {
     const int T = vp.gx * vp.gy;
-    // waves: one per item while the frame has at most FRG_BWD_MAX_WAVES items (an upper bound on their number: one last
-    // segment per tile + R / SEG full ones), beyond that the waves stride
-    const int bound = (int)std::min<size_t>((size_t)T + list_a_cap, (size_t)FRG_BWD_MAX_WAVES);
+    // waves: one per item while the frame has at most FRG_BWD_MAX_WAVES items (an upper bound on their number), beyond
+    // that the waves stride
+    const int bound = (int)std::min<size_t>((size_t)T + BinningState::full_cap(R), (size_t)FRG_BWD_MAX_WAVES);
     const int nwaves = ((g_bwd_waves > 0 ? g_bwd_waves : bound) + 7) / 8 * 8;
-    hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, s, T, img.tile_work, img.bwd_order, list_a, list_a_cap, img.bwd_hdr, img.cutoff);
 #define FRG_BWD(B)                                                                                                         \
     hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B>), dim3(nwaves), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H,               \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
-                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_order, img.bwd_hdr, list_a, img.tile_work, b.ckpt, img.final_C)
+                       img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_cnt, img.bwd_last, img.bwd_cap_b, img.tile_work,     \
+                       reinterpret_cast<const char*>(b.point_list), img.counters, img.final_C)
     if (batch == 2) FRG_BWD(2); else FRG_BWD(3);
 #undef FRG_BWD
     return hipGetLastError();

@@ -14,15 +14,18 @@
 #define FRG_SLOT_STRIDE 9   // floats from one instance's slot to the next in the backward workspace
 #endif
 #define FRG_REACHED_MASK 0xFF00u   // byte 1 of rgb_clamped[].w: set by the backward blend for Gaussians with a slot that may hold a gradient
-// The backward blend walks a tile's processed list prefix in SEGMENTS of this many entries, each segment an independent
-// work item (blend_impl.h): the forward leaves every pixel's transmittance and accumulated colour at the segment
-// boundaries it crosses (BinningState::ckpt, ImageState::final_C).  A multiple of 64 (the staging round).
-// Measured (same box, C3 / C4 / clustered scene, backward blend): 256 0.425 / 0.34 / 0.42 ms, 512 0.392 / 0.37 / 0.37,
-// 1024 0.397 / 0.385 / 0.39, 2048 0.40 / 0.52 / 0.39; one tile per item (round 3) 0.40 / 0.58 / 0.40.  8 bytes of checkpoint
-// space per instance at 512.
-#ifndef FRG_BWD_SEG
-#define FRG_BWD_SEG 512
-#endif
+// The backward blend walks a tile's processed list prefix in SEGMENTS, each segment an independent work item
+// (blend_impl.h): the forward leaves every pixel's transmittance and accumulated colour at the segment boundaries it
+// crosses (BinningState::ckpt, ImageState::final_C).  A multiple of 64 (the staging round), a power of two.
+// Measured (round 4, same box, C3 / C4 / clustered scene, backward blend): 256 0.425 / 0.34 / 0.42 ms, 512 0.392 / 0.37 / 0.37,
+// 1024 0.397 / 0.385 / 0.39, 2048 0.40 / 0.52 / 0.39; one tile per item (round 3) 0.40 / 0.58 / 0.40 -- the best length is the
+// one that gives the frame about as many items as the GPU holds single-wave workgroups (16 384): a frame of 5 M instances
+// (C4) wants 256, one of 16 M (C3) 512.  Round 5: the length is chosen per FRAME by the forward from the instance count
+// its binning chunk is carved for (bwd_seg_log below; option "bwd_seg_log" pins it) and stamped into the image chunk's
+// counters, where the backward finds it.  16 / 8 bytes of checkpoint space per instance at 256 / 512.
+#define FRG_BWD_SEG_LOG_MIN 8
+#define FRG_BWD_SEG_LOG_MAX 10
+#define FRG_BWD_SEG_SWITCH (1u << 23)   // instances (as carved) from which the segments are 512 entries long
 #define FRG_BWD_HEAVY_SLOTS (4 * 896)   // four slot windows of the per-Gaussian backward (preprocess_bwd.hip)
 #define FRG_BIN_THREADS 1024     // binning workgroup = chunk of Gaussians
 #define FRG_BIN_MAX_BLOCKS 256   // rows of the (workgroup x tile) count matrix: one persistent workgroup per CU
@@ -41,6 +44,12 @@ struct Dims {
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// log2 of the backward blend's segment length for a binning chunk carved for R instances (forced: option "bwd_seg_log", 0 = by R)
+__host__ __device__ inline int bwd_seg_log(size_t R, int forced = 0)
+{
+    if (forced >= FRG_BWD_SEG_LOG_MIN && forced <= FRG_BWD_SEG_LOG_MAX) return forced;
+    return R < (size_t)FRG_BWD_SEG_SWITCH ? 8 : 9;
+}
 
 // ---- geometry chunk ---------------------------------------------------------
 // One 48-byte RECORD per Gaussian = three float4, contiguous: the blend kernels gather all three per list entry,
@@ -109,6 +118,7 @@ __device__ __forceinline__ int sh_slot_of(uint64_t vis, int lane, bool sparse_la
 }
 
 // ---- image chunk ----------------------------------------------------------
+#define FRG_BWD_LEN_BUCKETS 32   // length buckets of the tiles' last segments (backward blend items, longest first)
 #define FRG_SORT_CLASSES 5    // tile-list size classes of the sort: <=512, <=2048, <=4096, <=8192, >8192
 struct Counters {            // written by the scan kernel, 48 bytes read back by the host
     uint32_t num_rendered;
@@ -120,7 +130,12 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
     // THESE, not the process-wide options at the time it is called
     uint32_t tight_binning;
     uint32_t num_visible;    // Gaussians with at least one tile (records in GeomState::row_records)
-    uint32_t pad2[1];
+    // the instance count the forward CARVED its binning chunk with (num_rendered; the capacity of a deferred-counters
+    // forward), stamped by the chunk scan: BinningState::ckpt sits behind point_list and pairs, at an offset that depends
+    // on it, and the backward blend takes the offset from HERE -- not from the R its caller passes, which may be either
+    // of the two (a wrong offset would silently read other tiles' checkpoints for every walk deeper than FRG_BWD_SEG)
+    uint32_t carved_R;
+    uint32_t bwd_seg_log;    // log2 of the segment length the forward blend left its checkpoints at (stamped by blend_fwd_kernel)
 };
 // Pinned HOST memory the scan workgroups write with system-scope stores, polled by the forward's host thread: the
 // instance count as soon as the chunk scan has it (the host sizes the binning buffer and enqueues the scatter while the
@@ -129,8 +144,8 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
 // seq_*: the forward's sequence number, stored last.
 struct Mailbox {
     uint32_t seq_r, num_rendered, pad0[14];      // one 64-byte line per stage
-    uint32_t seq_c, pad1[3];
-    Counters c;
+    uint32_t seq_c, pad1[1];
+    Counters c;                                  // (8 + 56 bytes: the second line)
     // third post, by the scatter (not waited for): how many 64-Gaussian waves own more than FRG_BWD_HEAVY_SLOTS
     // backward slots -- a backward that finds its forward's post here and reads 0 skips the 16-wave launch of the
     // per-Gaussian backward and its fork / join (~11 us per step at C3)
@@ -166,11 +181,16 @@ struct ImageState {
     uint2* ranges;           // per tile [start,end) into point_list; (0,0) when empty
     uint32_t* tile_count;    // instances per tile: written by the tile scan (LDS bins) | cleared by the forward's memset and counted with atomics (global bins)
     uint32_t* tile_fill;     // scatter cursor; zero at the start of every forward (colsum_kernel, or the memset of the global-bins path)
-    uint32_t* tile_work;     // list entries the forward blend walked (max over the tile's pixels); zeroed like tile_fill
-    uint32_t* bwd_order;     // [T + 8] the active tiles, per XCD band, by decreasing length of their LAST segment (bwd_order_kernel)
-    // written by bwd_order_kernel for the backward blend's waves (blend_impl.h, BwdHdr): per XCD the start / count of its
-    // full-segment items and of its last-segment items, its share of the frame's items and its place in the pool that evens the shares
-    uint32_t* bwd_hdr;
+    uint32_t* tile_work;     // list entries the forward blend walked (max over the tile's pixels): stored by the tile's last wave
+    // Work items of the backward blend, listed by the FORWARD blend's tile workgroups as they finish (round 5: there is no
+    // ordering kernel in front of the backward any more): per XCD band of tiles (frg_common.h: xcd_of_tile)
+    //   bwd_cnt  [8][FRG_BWD_LEN_BUCKETS + 1]  tiles per length bucket of their LAST segment (bucket 0 = the longest), and in
+    //            [x][FRG_BWD_LEN_BUCKETS] the number of full-segment items of the band (BinningState::bwd_full);
+    //            zero at the start of every forward (colsum_kernel / the memset of the global-bins path)
+    //   bwd_last [8][FRG_BWD_LEN_BUCKETS][bwd_cap_b]  the tiles of each bucket, in the order their workgroups finished
+    uint32_t* bwd_cnt;
+    uint32_t* bwd_last;
+    uint32_t bwd_cap_b;      // tiles per XCD band, at most
     // accumulated colour (without the background term) of every pixel of a tile whose walk crossed a segment boundary:
     // float4[T * 256], quadrant-major like BinningState::ckpt.  The backward blend starts a segment that is not a
     // pixel's last from S = dL/dC . (final_C - colour accumulated at the segment's end) + T_final (bg . dL/dC)
@@ -202,10 +222,11 @@ struct ImageState {
         s.tile_count = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
         s.tile_fill = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
         s.tile_work = (uint32_t*)(base + o); o = align_up(o + T * 4, 256);
+        s.bwd_cnt = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_NUM_XCD * (FRG_BWD_LEN_BUCKETS + 1) * 4, 256);
         s.counters = (Counters*)(base + o); o = align_up(o + sizeof(Counters), 256);
         s.zero_bytes = o - s.zero_begin;
-        s.bwd_order = (uint32_t*)(base + o); o = align_up(o + (T + FRG_NUM_XCD) * 4, 256);
-        s.bwd_hdr = (uint32_t*)(base + o); o = align_up(o + 128 * 4, 256);     // (BwdHdr::words() = 72)
+        s.bwd_cap_b = (uint32_t)(T / FRG_NUM_XCD + 1);
+        s.bwd_last = (uint32_t*)(base + o); o = align_up(o + (size_t)FRG_NUM_XCD * FRG_BWD_LEN_BUCKETS * s.bwd_cap_b * 4, 256);
         s.final_C = (float4*)(base + o); o = align_up(o + T * FRG_TILE_PIX * 16, 256);
         s.class_tiles = (uint32_t*)(base + o); o = align_up(o + (size_t)(FRG_SORT_CLASSES + 1) * T * 4, 256);
         const size_t gy = (size_t)((H + FRG_TILE - 1) / FRG_TILE);
@@ -277,7 +298,25 @@ struct BinningState {
     // entries has floor((n - 1) / SEG) boundaries and the next list starts n instances later.  256 float4 per record,
     // quadrant-major (the forward's wave q writes [q * 64, q * 64 + 64)).  4 bytes per instance; written only where crossed.
     float4* ckpt;
-    __host__ __device__ static size_t ckpt_records(size_t R) { return R / FRG_BWD_SEG + 2; }
+    __host__ __device__ static size_t ckpt_records(size_t R, int seg_log) { return (R >> seg_log) + 2; }
+    // The backward blend's FULL-segment items (tile, segment), listed per XCD band by the forward blend as its tiles finish:
+    // [8][full_cap(R)] -- a band may hold every long list of the frame, and all lists together have at most R / segment
+    // boundaries.  Sized for the shortest segment length.  R / 4 bytes.
+    uint2* bwd_full;
+    __host__ __device__ static size_t full_cap(size_t R) { return (R >> FRG_BWD_SEG_LOG_MIN) + 2; }
+    // byte offsets inside a chunk carved for R instances -- the one place that knows them: carve() and the backward blend,
+    // which evaluates them on the device from Counters::carved_R (the R a backward is CALLED with may be the frame's
+    // instance count or a deferred forward's capacity)
+    __host__ __device__ static size_t full_offset(size_t R)
+    {
+        const size_t Rr = R > 0 ? R : 1;
+        return align_up(Rr * 4, 256) + align_up(Rr * 8, 256);
+    }
+    __host__ __device__ static size_t ckpt_offset(size_t R)
+    {
+        const size_t Rr = R > 0 ? R : 1;
+        return full_offset(Rr) + align_up((size_t)FRG_NUM_XCD * full_cap(Rr) * 8, 256);
+    }
     uint2* pairs_tmp;        // second pair buffer (sorted chunks / ping-pong), only when some tile exceeds the LDS capacity
     uint32_t* big_hist;      // digit counters of the LSD sort of lists beyond FRG_SORT_MID_MAX: one 256-entry row per 1024 elements
     uint32_t* big_plan;      // BigPlan of the splitter sort
@@ -286,14 +325,20 @@ struct BinningState {
     // unique and increasing, because only lists longer than 8192 = 2^13 entries own rows
     __host__ __device__ static size_t big_hist_rows(size_t R) { return (R >> 10) + (R >> 13) + 2; }
     __host__ __device__ static size_t big_hist_row(uint32_t first, uint32_t r) { return (size_t)(first >> 10) + (first >> 13) + r; }
-    __host__ static BinningState carve(char* base, int R, int max_tile_count)
+    int seg_log;             // log2 of the segment length ckpt is sized for
+    size_t carved_R;         // the instance count this chunk was carved for (>= 1)
+    __host__ static BinningState carve(char* base, int R, int max_tile_count, int forced_seg_log = 0)
     {
         BinningState s;
         size_t Rr = (size_t)(R > 0 ? R : 1);
         size_t o = 0;
+        s.seg_log = bwd_seg_log(Rr, forced_seg_log);
+        s.carved_R = Rr;
         s.point_list = (uint32_t*)(base + o); o = align_up(o + Rr * 4, 256);
         s.pairs = (uint2*)(base + o); o = align_up(o + Rr * 8, 256);
-        s.ckpt = (float4*)(base + o); o = align_up(o + ckpt_records(Rr) * FRG_TILE_PIX * 16, 256);
+        s.bwd_full = (uint2*)(base + full_offset(Rr));
+        s.ckpt = (float4*)(base + ckpt_offset(Rr));
+        o = ckpt_offset(Rr) + align_up(ckpt_records(Rr, s.seg_log) * FRG_TILE_PIX * 16, 256);
         s.pairs_tmp = nullptr;
         s.big_hist = nullptr;
         s.big_plan = nullptr;

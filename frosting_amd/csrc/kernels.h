@@ -48,13 +48,11 @@ hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, cons
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                  const float* bg, float* out_color, hipStream_t s);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
-// list_a / list_a_cap: room for the (tile, segment) items of the full segments, behind the slots in the backward workspace
+// R: the instance count the caller sized the slots for (bounds the number of work items: the grid)
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                  int batch, hipStream_t s);
+                                  const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, uint2* list_a, uint32_t list_a_cap,
-                                 int batch, hipStream_t s);
+                                 const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;

@@ -597,6 +597,7 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
         // (written either way: in the LDS-bins paths nothing clears the counters before the forward)
         const uint32_t ovf = (capacity && sh.carry > capacity) ? 1u : 0u;
         sh.ovf = ovf; counters->overflow = ovf;
+        counters->carved_R = capacity ? capacity : sh.carry;    // what the host carves the binning chunk with (api.hip)
         if (mail) { mail->num_rendered = sh.carry; mailbox_post(&mail->seq_r, seq); }
     }
     __syncthreads();
@@ -734,7 +735,7 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
         c.max_tile_count = sh.maxc;
         c.tight_binning = tight;
         c.num_visible = 0;
-        c.pad2[0] = 0;
+        c.carved_R = __hip_atomic_load(&counters->carved_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int k = 0; k < FRG_SORT_CLASSES; k++) c.class_count[k] = sh.cls[k];
         mail->c = c;
         mailbox_post(&mail->seq_c, seq);
@@ -765,7 +766,8 @@ __global__ void __launch_bounds__(256)
 colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums,
               uint32_t* __restrict__ row_matrix, uint32_t* __restrict__ row_total, int gy,
               int nchunks, uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, uint32_t capacity,
-              Mailbox* mail, uint32_t seq, uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ tile_work)
+              Mailbox* mail, uint32_t seq, uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ tile_work,
+              uint32_t* __restrict__ bwd_cnt)
 {
     if (blockIdx.y == FRG_BIN_SEGS + 1) {
         if (blockIdx.x != 0) return;
@@ -798,6 +800,9 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
         if (lane == 63) row_total[r] = inc;
         return;
     }
+    // the counters of the backward blend's item lists (filled by the forward blend's tile workgroups) start at zero
+    if (blockIdx.y == 0 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < FRG_NUM_XCD * (FRG_BWD_LEN_BUCKETS + 1); i += 256) bwd_cnt[i] = 0u;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
     // the scatter's fill cursor and the forward blend's depth mark of every tile start at zero: cleared here, on the way,
@@ -1151,7 +1156,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     if (img.lds_bins)
         hipLaunchKernelGGL(colsum_kernel, dim3(std::max((T + 255) / 256, cells ? (img.ncells + 3) / 4 : 0), FRG_BIN_SEGS + (cells ? 2 : 0)),
                            dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums, img.row_matrix, img.row_start, img.ncells,
-                           nchunks, g.block_sums, img.counters, capacity, mail, seq, img.tile_fill, img.tile_work);
+                           nchunks, g.block_sums, img.counters, capacity, mail, seq, img.tile_fill, img.tile_work, img.bwd_cnt);
     if (cells) {
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,

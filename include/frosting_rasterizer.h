@@ -249,9 +249,14 @@ int frg_backward_ex(const frg_backward_args* args);
  * bit-identical either way; the tile lists become order-preserving sub-lists of the reference's.
  * Default 0: lists identical to the reference's, entry for entry.
  * "bwd_waves" (default 0 = one single-wave workgroup per work item, at most 16384): workgroups of the backward blend.
- * A work item is a SEGMENT of 512 entries of a tile's processed list prefix (the forward leaves every pixel's state at
- * the segment boundaries in the binning / image chunks); the assignment of items to waves is static, so the gradients
- * do not depend on this number.  Scheduling only.
+ * A work item is a SEGMENT of a tile's processed list prefix (the forward leaves every pixel's state at the segment
+ * boundaries in the binning / image chunks, and lists the items as its tiles finish); the assignment of items to waves
+ * is static, so the gradients do not depend on this number.  Scheduling only.
+ * "bwd_seg_log" (default 0): log2 of the segment length.  0 = chosen per frame by the forward from the instance count its
+ * binning chunk is carved for (256 entries below 2^23 instances, 512 from there: about as many items as the GPU holds
+ * single-wave workgroups); 8, 9, 10 pin it.  Read by FORWARDS (it sizes the checkpoint space of frg_binning_bytes); a
+ * backward follows what its forward stamped.  Gradients agree between lengths to float32 rounding of the checkpointed
+ * state, not bit for bit.
  * "counter_mailbox" (default 1): the blocking forward learns num_rendered and the sort's class sizes from a pinned
  * host mailbox the scan workgroups post to with system-scope stores -- the scatter is enqueued while the scan stage
  * still runs -- instead of a copy + stream synchronisation behind the scan (0).  The binning callback is then asked

@@ -66,11 +66,33 @@ def native_ops(binding: str):
 #     distribution (two draws were seen 3.6 x apart) and ours must merely not be out of the reference's league at it -- a
 #     wrong clamp, a NaN, a lost slot would be off by orders of magnitude.
 # No per-scene factors: the bars of rounds 1-3 (floors x 2 ... x 8 by scene, a flat 5e-3 for one case) are gone.
+# Round 5 pins the yardstick itself and tightens the rest:
+#   * WELL_REF_MAX: on the computable rows the float64 gradient and the reference's own runs must AGREE (<= 2e-4 per
+#     tensor; the worst ever measured is 1.0e-4, dL_drotations of C4's edge-on shell) -- asserted in every comparison, so a
+#     regression of the float64 oracle cannot silently widen every bar at once;
+#   * the whole-tensor clause's second arm is 3 x the reference's worst run where the tensor has no ill-conditioned rows
+#     (the rows set aside do not dominate the reference's own error: all_ref <= 2 x well_ref) and 5 x where they do
+#     (there every evaluation is a draw; two draws of the reference itself were seen 3.6 x apart, ours 3.7 x from it:
+#     profiles/r04_pytest_gpu.log, "principal=+0.1,-0.1" dL_drotations) -- it was 10 x everywhere;
+#   * WELL_FLOOR of the default arithmetic 3e-5 -> 2e-5 (measured worst that needs it: dL_dmeans2D 1.6e-5 at C3);
+#   * regression guards: WELL_OURS_MAX[fast][name], 2.5 x the largest well_ours of profiles/r04_pytest_gpu.log over every
+#     GPU test -- a 10 - 30 x regression on a tensor where the reference sits at 1e-7 ... 1e-6 no longer hides under the gate.
 GATE = 1e-4
 TRIM_FRACTION = 1e-4
+WELL_REF_MAX = 2e-4
 WELL_FACTOR = {False: 3.0, True: 5.0}        # [fast]: ours vs the reference's own distance to float64, computable rows
-WELL_FLOOR = {False: 1e-5, True: 3e-5}       # ... below which that factor is not asked for (the reference itself sits at 1e-7 ... 1e-5)
-WHOLE_FACTOR = {False: 10.0, True: 10.0}
+WELL_FLOOR = {False: 1e-5, True: 2e-5}       # ... below which that factor is not asked for (the reference itself sits at 1e-7 ... 1e-5)
+WHOLE_FACTOR = 3.0                           # whole tensor vs the reference's worst run, no ill-conditioned rows ...
+WHOLE_FACTOR_ILL = 5.0                       # ... and where the rows set aside dominate the reference's own error
+# 2.5 x the largest well_ours over all 144 GPU tests of round 4 (profiles/r04_pytest_gpu.log; printed there with two
+# digits), by arithmetic and tensor.  A scene on which the reference itself is farther keeps the 1.5 x well_ref bar.
+_R04_WELL_OURS = {
+    False: dict(dL_dmeans2D=2.6e-6, dL_dcolors=6.7e-7, dL_dopacity=1.2e-6, dL_dmeans3D=4.9e-6, dL_dcov3D=2.6e-5, dL_dsh=6.8e-7,
+                dL_dscales=4.7e-5, dL_drotations=1.0e-4),
+    True: dict(dL_dmeans2D=1.6e-5, dL_dcolors=2.5e-6, dL_dopacity=1.5e-6, dL_dmeans3D=1.1e-5, dL_dcov3D=9.3e-6, dL_dsh=2.5e-6,
+               dL_dscales=5.2e-5, dL_drotations=7.4e-5),
+}
+WELL_OURS_MAX = {fast: {k: 2.5 * v for k, v in d.items()} for fast, d in _R04_WELL_OURS.items()}
 GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
 
 
@@ -113,7 +135,7 @@ def truth_from_oracle_state(st, dL_dimage):
     return G.backward_f64(state, np.asarray(dL_dimage))
 
 
-def judge_gradients(ours, refs, truth, fast, label, names=None, quiet=False):
+def judge_gradients(ours, refs, truth, fast, label, names=None, quiet=False, guard=True):
     """ours: {name: tensor} (or the 8-tuple of rasterize_gaussians_backward); refs: list of {name: tensor / array} -- runs
     of a float32 reference on the same forward state (the reference's atomics, a stored fixture, the C oracle);
     truth: {name: float64 array}.  Asserts the two comparisons described above and returns the per-tensor report."""
@@ -152,10 +174,17 @@ def judge_gradients(ours, refs, truth, fast, label, names=None, quiet=False):
             print(f"    {name[3:]:11s} {r['well_ours']:.1e} ({r['well_ref']:.1e}; {r['trimmed']} rows set aside) | {r['all_ours']:.1e} "
                   f"({r['all_ref']:.1e}), {r['d_ref']:.1e} ({r['noise']:.1e})")
     for name, r in report.items():
-        msg = (label, "fast" if fast else "exact", name, r)
+        ratio = r["well_ours"] / max(r["well_ref"], 1e-300)
+        msg = (label, "fast" if fast else "exact", name, f"ours / reference on the computable rows = {ratio:.2f}", r)
+        # the yardstick: float64 and the reference's own runs agree on the float32-computable rows
+        assert r["well_ref"] <= WELL_REF_MAX, ("the float64 yardstick and the reference disagree",) + msg
         assert r["well_ours"] <= max(GATE, 1.5 * r["well_ref"]), msg
         assert r["well_ours"] <= max(WELL_FACTOR[fast] * r["well_ref"], WELL_FLOOR[fast]), msg
-        assert r["d_ref"] < max(5.0 * r["noise"], GATE) or r["all_ours"] <= max(WHOLE_FACTOR[fast] * r["all_ref"], GATE), msg
+        cap = WELL_OURS_MAX[fast].get(name)
+        assert guard is False or cap is None or r["well_ours"] <= max(cap, 1.5 * r["well_ref"]), ("regression guard (2.5 x the r04 record)",) + msg
+        ill = r["all_ref"] > 2.0 * r["well_ref"]
+        whole = WHOLE_FACTOR_ILL if ill else WHOLE_FACTOR
+        assert r["d_ref"] < max(5.0 * r["noise"], GATE) or r["all_ours"] <= max(whole * r["all_ref"], GATE), msg
     return report
 
 

@@ -152,6 +152,14 @@ def test_backward_in_two_calls_equals_one_call(gpu_device, scene_kind):
     vpr.backward(gpix, 0, phase=2)
     got = (vpr.exchange.flat, vpr.dL_dmeans2D, vpr.dL_dcolors, vpr.dL_dcov3D)
     assert all(torch.equal(a, b) for a, b in zip(want, got))
+    # the sums phase 1 left are consumed once, and only by a phase 2 with the same buffers: anything else is refused
+    # instead of turning stale workspace contents into gradients
+    with pytest.raises(RuntimeError, match="phase 2 without a matching phase 1"):
+        vpr.backward(gpix, 0, phase=2)
+    vpr.backward(gpix, 0, phase=1)
+    vpr.work.buf = torch.empty(vpr.work.buf.numel() + 4096, dtype=torch.uint8, device=dev)    # the arena "grew" between the calls
+    with pytest.raises(RuntimeError, match="phase 2 without a matching phase 1"):
+        vpr.backward(gpix, 0, phase=2)
 
 
 def test_deferred_counters_forward_matches_blocking_forward(gpu_device):

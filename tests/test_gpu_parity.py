@@ -43,6 +43,7 @@ GRAD_NAMES = Hh.GRAD_NAMES
 def _reset_options():
     yield
     _lib.set_option("bwd_waves", 0)
+    _lib.set_option("bwd_seg_log", 0)
     _lib.set_option("fwd_order", 1)
     _lib.set_option("counter_mailbox", 1)
     _lib.set_option("sparse_sh", 1)
@@ -622,7 +623,8 @@ def test_backward_follows_the_forwards_modes_not_the_process_options(gpu_device)
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
 @pytest.mark.parametrize("exact", [1, 0])
 def test_backward_blend_work_items_whatever_the_grid(gpu_device, exact):
-    """The backward blend's work items (tile, segment) are dealt to its waves statically (bwd_order_kernel + BwdHdr):
+    """The backward blend's work items (tile, segment) -- listed by the forward blend as its tiles finish, in whatever order
+    that happens -- are dealt to the backward's waves statically (blend_impl.h, BwdShares):
     whatever the number of waves (option bwd_waves: fewer than items -> the waves stride, more -> most find nothing), every
     slot is written once with the same value -- gradients identical bit for bit -- on a sparse 60 k-Gaussian frame and on a
     frame that covers one corner of the image (all its items belong to the tiles of one or two XCD bands: most waves take
@@ -648,15 +650,17 @@ def test_backward_blend_work_items_whatever_the_grid(gpu_device, exact):
 
 
 @pytest.mark.skipif(not REF.available("exact"), reason="oracle/_ref not built")
-@pytest.mark.parametrize("binding", ["ext"])
-def test_deep_walks_cross_many_segments_of_the_backward_blend(gpu_device, binding):
-    """The backward blend walks a tile's processed prefix in segments of FRG_BWD_SEG = 512 entries, each an independent
+@pytest.mark.parametrize("binding,seg_log", [("ext", 0), ("ext", 9), ("ctypes", 10)])
+def test_deep_walks_cross_many_segments_of_the_backward_blend(gpu_device, binding, seg_log):
+    """The backward blend walks a tile's processed prefix in segments of 256 / 512 entries (by frame), each an independent
     work item that starts from the state the FORWARD left at the segment's end (transmittance and accumulated colour per
     pixel: BinningState::ckpt, ImageState::final_C).  A translucent scene on a small image -- opacities 0.004 ... 0.03, so
     no pixel saturates and every tile walks its whole list of several thousand entries: 8 - 16 segments per tile, every
     pixel continuing behind every boundary -- against the reference's own code: forward artefacts bit-identical, all
     eight gradients judged as everywhere; and bit-reproducible from run to run (the items are pulled by whichever wave
-    is free: the order of the work must not reach the sums)."""
+    is free: the order of the work must not reach the sums).  seg_log: the segment length the forward chooses by itself
+    (0: 256 entries on a frame of this size) and the two longer ones, pinned -- 6 - 28 segments per tile."""
+    _lib.set_option("bwd_seg_log", seg_log)
     scene, _, bg = scenes.config_scene("c2", 0, P=600_000)
     scene = scenes.Scene(scene.means3D, scene.scales * 3.0, scene.rotations, (0.004 + 0.026 * scene.opacities).contiguous(), scene.shs, 3)
     cam = scenes.ring_camera(1, 160, 128, 222.0, 222.0)
@@ -670,6 +674,46 @@ def test_deep_walks_cross_many_segments_of_the_backward_blend(gpu_device, bindin
     g1 = [g.clone() for g in _C.rasterize_gaussians_backward(*b)]
     for _ in range(3):
         assert all(torch.equal(x, y) for x, y in zip(g1, _C.rasterize_gaussians_backward(*b)))
+    # a backward follows the segment length its FORWARD stamped, whatever the option says by then
+    _lib.set_option("bwd_seg_log", 9 if seg_log != 9 else 8)
+    assert all(torch.equal(x, y) for x, y in zip(g1, _C.rasterize_gaussians_backward(*b)))
+
+
+def test_backward_finds_the_forwards_checkpoints_whatever_r_it_is_called_with(gpu_device):
+    """the forward blend's checkpoints sit behind point_list and pairs of the binning chunk, at an
+    offset that depends on the instance count the chunk was CARVED for -- the capacity of a deferred-counters forward,
+    not the frame's instance count.  The backward takes that offset (and the segment length) from what the forward
+    stamped into the image chunk's counters: called with the capacity or with the true count, a deep-walk frame (every
+    tile crosses 6+ segment boundaries) gives the gradients of the plain forward, bit for bit; called with FEWER
+    instances than a blocking forward rendered, it is refused."""
+    from frosting_amd.parallel import ViewParallelRasterizer
+    dev = gpu_device
+    scene, _, bg = scenes.config_scene("c2", 0, P=300_000)
+    scene = scenes.Scene(scene.means3D, scene.scales * 3.0, scene.rotations, (0.004 + 0.026 * scene.opacities).contiguous(), scene.shs, 3)
+    cam = scenes.ring_camera(1, 160, 128, 222.0, 222.0).to(dev)
+    ref = ViewParallelRasterizer(scene.to(dev), dev)
+    img, _ = ref.forward(cam, bg.to(dev))
+    gpix, _ = scenes.l1_target_grad(img.cpu(), 5)
+    gpix = gpix.to(dev)
+    ref.backward(gpix)
+    want = ref.exchange.flat.clone()
+    assert float(want.abs().max()) > 0
+    true_R = ref.num_rendered
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, deferred_counters=True, capacity_slack=1.37)
+    vpr.forward(cam, bg.to(dev))                    # synchronous first view: sizes the arenas, sets the capacity
+    vpr.forward(cam, bg.to(dev))                    # deferred: carved for the capacity
+    assert vpr.num_rendered == vpr.capacity > true_R
+    vpr.backward(gpix)                              # R = the capacity (what the deferred forward returned)
+    assert vpr.finish() is True and vpr.true_num_rendered == true_R
+    assert torch.equal(vpr.exchange.flat, want)
+    vpr.exchange.flat.zero_()
+    vpr.num_rendered = true_R                       # R = the frame's instance count: another carve, the same checkpoints
+    vpr.backward(gpix)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(vpr.exchange.flat, want)
+    ref.num_rendered = true_R - 1                   # fewer than the forward rendered: slots and item lists would overrun
+    with pytest.raises(RuntimeError, match="rendered"):
+        ref.backward(gpix)
 
 
 def test_per_call_modes_of_two_rasterizers_on_two_threads(gpu_device):

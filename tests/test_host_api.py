@@ -39,7 +39,7 @@ def test_state_size_queries_and_options():
     assert _lib.get_option("exact_blend") == 1
     _lib.set_option("exact_blend", old)
     # every documented option answers get / set and returns the previous value (include/frosting_rasterizer.h)
-    for name, default in (("tight_binning", 0), ("global_bins", 0), ("bwd_waves", 0), ("fwd_order", 1), ("counter_mailbox", 1),
+    for name, default in (("tight_binning", 0), ("global_bins", 0), ("bwd_waves", 0), ("bwd_seg_log", 0), ("fwd_order", 1), ("counter_mailbox", 1),
                           ("clear_image_state", 0), ("sort_heavy_on_caller", 1), ("bwd_heavy_first", 1), ("fwd_prefetch", 1), ("sparse_sh", 1), ("profile", 0), ("profile_stage", -1)):
         assert _lib.get_option(name) == default, name
         assert _lib.set_option(name, default) == default and _lib.get_option(name) == default, name
@@ -134,8 +134,13 @@ def test_extended_entry_points_validate_arguments_without_a_gpu():
     b.struct_size = C.sizeof(_lib.BackwardArgs)
     b.P, b.phase = 5, 3
     assert L.frg_backward_ex(C.byref(b)) == -1      # (null pointers or the phase: refused either way, before any HIP call)
-    # the workspace covers the slots, the backward blend's work items and the per-Gaussian sums of a two-call backward
-    assert L.frg_backward_workspace_bytes(1000, 100_000) >= 100_000 * 36 + (100_000 // 512) * 8 + 1000 * 36
+    # the workspace covers the slots and the per-Gaussian sums of a two-call backward; the backward blend's work items are
+    # listed by the forward in its own chunks (8 bands x R / 256 full-segment items behind point_list and pairs, the
+    # checkpoints behind them: 16 / 8 B per instance for segments of 256 / 512 entries)
+    assert L.frg_backward_workspace_bytes(1000, 100_000) >= 100_000 * 36 + 1000 * 36
+    assert L.frg_binning_bytes(100_000, 10) >= 100_000 * (4 + 8 + 16) + 8 * (100_000 // 256) * 8
+    assert L.frg_binning_bytes(1 << 24, 10) >= (1 << 24) * (4 + 8 + 8) + 8 * ((1 << 24) // 256) * 8
+    assert L.frg_binning_bytes(1 << 24, 10) < (1 << 24) * (4 + 8 + 9 + 1)
     n = C.c_int(-7)
     assert L.frg_forward_finish(None, 0, C.byref(n)) == -1 and "pending" in _lib.last_error()
     # deferred forward needs a positive capacity

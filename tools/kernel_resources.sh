@@ -13,7 +13,7 @@ extra=()
 case "$base" in
   preprocess|preprocess_bwd|view_exchange|adam) extra=(-ffp-contract=off) ;;
   blend_exact) extra=(-ffp-contract=off -fno-slp-vectorize) ;;
-  blend_fast) extra=(-fno-slp-vectorize) ;;
+  blend_fast) extra=(-ffp-contract=off -fno-slp-vectorize) ;;
 esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I"$ROOT/frosting_amd/csrc" -I"$ROOT/include" \
     "${extra[@]}" "$@" --cuda-device-only --no-gpu-bundle-output -c "$src" -o "$OUT/$base.co"
