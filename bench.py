@@ -67,10 +67,15 @@ def parse_args():
     ap.add_argument("--deferred-counters", action="store_true",
                     help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
                          "which like the reference blocks on a read-back of num_rendered")
-    ap.add_argument("--exchange", default="factored", choices=["factored", "allreduce"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "sparse", "factored", "allreduce"],
                     help="N>1: 'allreduce' = all 59 floats per Gaussian are summed across ranks; 'factored' = the 11 non-SH "
                          "floats are summed + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
-                         "every rank (frosting_amd/parallel.py)")
+                         "every rank; 'sparse' = only the ROWS of the Gaussians with a gradient travel -- (index, 11 floats, "
+                         "dRGB), one visible Gaussian in seven at C3: counts, one padded all-gather, scatter-add in view order, "
+                         "SH rebuild (frosting_amd/parallel.py); 'auto' (default) = N>1 on RCCL: 'factored' and 'sparse' are "
+                         "both timed for a few steps before the warm-up and the faster one runs (the arithmetic of DESIGN.md "
+                         "section 5 puts them within 10 % of each other, the order depending on the collective bandwidth RCCL "
+                         "reaches on the node); otherwise 'factored'")
     ap.add_argument("--reduce", default="auto", choices=["auto", "allreduce", "direct"],
                     help="N>1: how the summed part travels: 'allreduce' = one RCCL all-reduce; 'direct' = one RCCL reduce-scatter "
                          "of 1/N shards + one all-gather (every GPU talks to every other over its own xGMI link: SURVEY 8(e)); "
@@ -358,13 +363,17 @@ def main():
     _lib.set_option("tight_binning", 1 if args.tight_binning else 0)
     scene_d = scene.to(dev)
     reduce_probe = None
+    auto_exchange = args.exchange == "auto"
+    if auto_exchange:
+        args.exchange = "factored"
+    exchange_probe = None
     auto_reduce = args.reduce == "auto"
     if auto_reduce:
         args.reduce = "allreduce"
     vpr = ViewParallelRasterizer(scene_d, dev, process_group=dist.group.WORLD if dist else None,
-                                 factor_sh=(args.exchange == "factored"), deferred_counters=args.deferred_counters,
-                                 reduce=args.reduce)
-    if auto_reduce and dist is not None and world > 1 and args.backend == "nccl":
+                                 factor_sh=(args.exchange in ("factored", "sparse")), deferred_counters=args.deferred_counters,
+                                 reduce=args.reduce, sparse=(args.exchange == "sparse"))
+    if auto_reduce and dist is not None and world > 1 and args.backend == "nccl" and args.exchange != "sparse":
         # the sum of the dense part timed both ways on this run's buffers, max over ranks; the faster plan is used
         from frosting_amd.parallel import probe_reduce_plan
         reduce_probe, args.reduce = probe_reduce_plan(vpr.exchanges)
@@ -472,6 +481,19 @@ def main():
     for _ in range(max(0, args.spinup_steps)):
         step()
     drain()
+    if auto_exchange and exchanging and world > 1 and args.backend == "nccl" and schedule[0] != "stale":
+        # both row-level plans timed on this run's scene, max over ranks; the faster one runs (the same on every rank: the
+        # choice is made from the reduced times)
+        exchange_probe = {}
+        for plan in ("factored", "sparse"):
+            vpr.set_exchange_plan(plan, reduce=args.reduce)
+            timed(3)
+            t_, _ = timed(6)
+            tt = torch.tensor([t_ / 6], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exchange_probe[plan] = 1e3 * float(tt.item())
+        args.exchange = min(exchange_probe, key=exchange_probe.get)
+        vpr.set_exchange_plan(args.exchange, reduce=args.reduce)
     for w in range(args.warmup):
         if timers and w == args.warmup - 1:
             drain()
@@ -685,9 +707,12 @@ def main():
                        "parallelism": f"view-parallel x{world}", "ranks": world, "backend": (args.backend if dist else "none"),
                        "exchange": ("none" if not exchanging else
                                     ("all 59 floats/Gaussian summed" if args.exchange == "allreduce" else
+                                     "sparse: rows (index, 11 floats, dRGB: 64 B) of the Gaussians with a gradient -- counts, "
+                                     "one padded all-gather, scatter-add in view order, summed SH gradient rebuilt per rank"
+                                     if args.exchange == "sparse" else
                                      "factored: 11 floats/Gaussian summed + all-gather of dRGB (3 floats), "
                                      "summed SH gradient rebuilt per rank") +
-                                    (", RCCL all-reduce" if args.reduce == "allreduce" else
+                                    ("" if args.exchange == "sparse" else ", RCCL all-reduce" if args.reduce == "allreduce" else
                                      ", direct: all-to-all of 1/N shards + local sum + all-gather") +
                                     {"in-step": ", in-step schedule: complete before the step ends (valid with a parameter update between "
                                                 "views); SH rebuild beside the dense sum",
@@ -696,7 +721,7 @@ def main():
                                               "buffers; one-step-stale gradients only)"}[schedule[0]] +
                                     (", + densification statistics (radii MAX, grad-norm / count SUM)" if dstats is not None else "")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
-                       "reduce_probe_ms": reduce_probe,
+                       "reduce_probe_ms": reduce_probe, "exchange_probe_ms_per_step": exchange_probe,
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"],
                        "outputs_written": "all nine gradient tensors of SURVEY 8(d)'s 284 B / Gaussian except dL_dconic (an "
                                           "intermediate the reference's binding never returns, rasterize_points.cu:195): "
@@ -717,13 +742,22 @@ def main():
             from frosting_amd.parallel import predict_exchange
             render_ms = compute_only if compute_only is not None else ms_per_step
             sched = "in-step" if schedule[0] == "in-step" else "sync"
+            rows_frac = (vpr.exchange.sparse_stats["rows_max"] / P) if (exchanging and args.exchange == "sparse" and vpr.exchange.sparse_stats["rows_max"]) else 0.124
+            plans = [("allreduce", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync",)] + \
+                    [("factored", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync", "in-step")] + [("sparse", "allgather", "sync")]
             out["predicted"] = {
-                "render_ms": render_ms,
-                "this_plan": {str(n): predict_exchange(P, 16, n, render_ms, args.exchange, args.reduce, sched) for n in (2, 4, 8)},
-                "at_8_gpus": {f"{pl}/{rd}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, rd, sc)["scaling_vs_1gpu"], 2)
-                              for pl in ("allreduce", "factored") for rd in ("allreduce", "direct") for sc in ("sync", "in-step")},
-                "note": "scaling = N x render / (render + exposed exchange); RCCL's all-reduce priced as a ring bound by one "
-                        "xGMI link (pessimistic), 'direct' = reduce-scatter + all-gather over all seven links; see DESIGN.md section 5"}
+                "render_ms": render_ms, "rows_fraction": rows_frac,
+                "this_plan": {str(n): predict_exchange(P, 16, n, render_ms, args.exchange, args.reduce, sched, rows_fraction=rows_frac) for n in (2, 4, 8)},
+                "at_8_gpus": {f"{pl}/{rd}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, rd, sc, rows_fraction=rows_frac)["scaling_vs_1gpu"], 2)
+                              for pl, rd, sc in plans},
+                # the same with every collective priced at ONE bus bandwidth per GPU, whatever its algorithm: the sum of the
+                # seven links, what RCCL usually reaches of it, and a pessimistic figure
+                "at_8_gpus_by_bus_GBps": {str(bw): {f"{pl}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, "direct", sc, bus_GBps=bw, rows_fraction=rows_frac)["scaling_vs_1gpu"], 2)
+                                                    for pl, sc in (("allreduce", "sync"), ("factored", "in-step"), ("sparse", "sync"))}
+                                          for bw in (1071, 450, 300)},
+                "note": "scaling = N x render / (render + exposed exchange); link arithmetic: RCCL's all-reduce priced as a ring "
+                        "bound by one xGMI link (pessimistic), 'direct' = reduce-scatter + all-gather over all seven links; bus "
+                        "arithmetic: incoming bytes / bus bandwidth; see DESIGN.md section 5"}
         if compute_only is not None:
             out["exchange_timing"] = {"schedule": schedule[0], "ms_per_step_without_exchange": compute_only,
                                       "exposed_ms_per_step": ms_per_step - compute_only, "other_schedule": other_schedule,

@@ -1042,6 +1042,31 @@ int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
     return FRG_OK;
 }
 
+int frg_pack_grad_rows(int P, const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations, const float* dL_dopacity,
+                       const float* drgb, float* rows, long long capacity_rows, unsigned int* count, void* hip_stream)
+{
+    if (P < 0 || capacity_rows < 0 || capacity_rows > 0xffffffffLL) return fail(FRG_EINVAL, "bad sizes P=%d capacity=%lld", P, capacity_rows);
+    if (!count) return fail(FRG_EINVAL, "null pointer");
+    if (P == 0) { FRG_HIP(hipMemsetAsync(count, 0, sizeof(unsigned int), (hipStream_t)hip_stream)); return FRG_OK; }
+    if (!dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_dopacity || !drgb || (!rows && capacity_rows > 0)) return fail(FRG_EINVAL, "null pointer");
+    if (reinterpret_cast<uintptr_t>(rows) % 16 != 0) return fail(FRG_EINVAL, "rows must be 16-byte aligned");
+    FRG_HIP(frg::launch_pack_grad_rows(P, dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacity, drgb, rows, (unsigned int)capacity_rows, count,
+                                       (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_dmeans3D, float* dL_dscales, float* dL_drotations,
+                          float* dL_dopacity, float* drgb_dense, void* hip_stream)
+{
+    if (P < 0 || n_rows < 0 || n_rows > 0xffffffffLL) return fail(FRG_EINVAL, "bad sizes P=%d rows=%lld", P, n_rows);
+    if (n_rows == 0 || P == 0) return FRG_OK;
+    if (!rows || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_dopacity) return fail(FRG_EINVAL, "null pointer");
+    if (reinterpret_cast<uintptr_t>(rows) % 16 != 0) return fail(FRG_EINVAL, "rows must be 16-byte aligned");
+    FRG_HIP(frg::launch_scatter_grad_rows((unsigned int)n_rows, P, rows, dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacity, drgb_dense,
+                                          (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
 int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                   const long long* segment_ends, const float* segment_lrs, const int* segment_period,
                   const int* segment_head, const float* segment_head_lrs, int n_segments,

@@ -76,6 +76,12 @@ hipError_t launch_sh_grad_from_views(int P, int D, int M, int n_views, const flo
                                      long long campos_stride, const float* drgb, long long view_stride, float* dL_dsh,
                                      hipStream_t s);
 
+// sparse form of the exchange: rows (index, 11 dense floats, dRGB; 16 floats) of the Gaussians with a gradient
+hipError_t launch_pack_grad_rows(int P, const float* g_means3D, const float* g_scales, const float* g_rot, const float* g_opac,
+                                 const float* drgb, float* rows, unsigned int capacity, unsigned int* count, hipStream_t s);
+hipError_t launch_scatter_grad_rows(unsigned int n, int P, const float* rows, float* g_means3D, float* g_scales, float* g_rot,
+                                    float* g_opac, float* drgb_dense, hipStream_t s);
+
 // fused Adam over the flat parameter layout (adam.hip)
 #ifndef FRG_ADAM_MAX_SEGMENTS
 #define FRG_ADAM_MAX_SEGMENTS 8

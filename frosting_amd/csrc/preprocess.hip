@@ -607,7 +607,8 @@ __device__ __forceinline__ void scan_chunks(ScanShared& sh, int nchunks, uint32_
 // code ran at an instruction-cache miss per 64 bytes, ~30 us at C3, twice that beside a streaming kernel), not to
 // data.  So only the load batch is unrolled; the totals then sit in LDS (tot, T words) and everything else is a
 // rolled loop of a few dozen instructions.  USE_SEGS: 0 totals in tile_count | 1 sum the segments and turn them into
-// start offsets for colbase_kernel | 2 sum the segments only.
+// start offsets for colbase_kernel | 2 sum the segments only | 3 the summed difference arrays are in tile_count (one word
+// per tile from colsum_kernel: the load batch of this latency chain is an eighth of form 2's).
 template <int NT, int USE_SEGS>
 __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool ovf, int T, int gx, uint32_t* __restrict__ tile_count,
                                            uint32_t* __restrict__ seg_sums, uint2* __restrict__ ranges,
@@ -630,7 +631,7 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
             const int i = base + k * NT + tid;
             v[k] = 0;
             if (i < T) {
-                if (USE_SEGS) {
+                if (USE_SEGS == 1 || USE_SEGS == 2) {
 #pragma unroll
                     for (int sg = 0; sg < FRG_BIN_SEGS; sg++) v[k] += seg_sums[(size_t)sg * T + i];
                 } else v[k] = tile_count[i];
@@ -643,7 +644,7 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
         }
     }
     __syncthreads();
-    if (USE_SEGS == 2) {
+    if (USE_SEGS >= 2) {
         // the staged totals are the summed DIFFERENCE arrays of the preprocess (BIN_CELLS): instances per tile = their
         // 2-D prefix sum, along x (one wave per tile row) and then along y (one thread per tile column)
         const int gy = T / gx;
@@ -754,28 +755,31 @@ scan_kernel(int nchunks, uint32_t* __restrict__ block_sums, int T, uint32_t* __r
     else scan_tiles<1024, 0>(sh, lds_tot ? scan_tot : tile_count, sh.ovf != 0, T, 0, tile_count, seg_sums, ranges, class_tiles, counters, tight, mail, seq);
 }
 
-// Column sums of the count matrix, split into FRG_BIN_SEGS row segments:
-// seg_sums[s][t] = sum over the rows of segment s.  grid (ceil(T/256), FRG_BIN_SEGS).
-// With cell-ordered records (row_matrix given) two more rows of workgroups ride along:
-//   blockIdx.y == FRG_BIN_SEGS      one wave per cell turns the counts of visible Gaussians per (workgroup, cell) into
-//                                   each workgroup's offset inside the cell's block of records (the workgroups of one
-//                                   XCD next to each other) and leaves the cell's total in row_total (reorder_kernel
-//                                   scans the totals);
-//   blockIdx.y == FRG_BIN_SEGS + 1  one workgroup scans the chunk totals (scan_chunks).
+// Column sums of the count matrix.
+//   one_total == 0 (scatter in the caller's order): split into FRG_BIN_SEGS row segments, seg_sums[s][t] = sum over the
+//                  rows of segment s; grid (ceil(T / 256), FRG_BIN_SEGS);
+//   one_total == 1 (cell-ordered records): ONE total per tile -> tile_count[t] (the summed difference arrays; the tile scan
+//                  turns them into counts): a workgroup takes 64 tiles, its four waves a quarter of the rows each; grid
+//                  (ceil(T / 64), 3), and two more rows of workgroups ride along:
+//                    blockIdx.y == 1  one wave per cell turns the counts of visible Gaussians per (workgroup, cell) into
+//                                     each workgroup's offset inside the cell's block of records (the workgroups of one
+//                                     XCD next to each other) and leaves the cell's total in row_total (reorder_kernel
+//                                     scans the totals);
+//                    blockIdx.y == 2  one workgroup scans the chunk totals (scan_chunks).
 __global__ void __launch_bounds__(256)
 colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ seg_sums,
               uint32_t* __restrict__ row_matrix, uint32_t* __restrict__ row_total, int gy,
               int nchunks, uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, uint32_t capacity,
               Mailbox* mail, uint32_t seq, uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ tile_work,
-              uint32_t* __restrict__ bwd_cnt)
+              uint32_t* __restrict__ bwd_cnt, int one_total, uint32_t* __restrict__ tile_count)
 {
-    if (blockIdx.y == FRG_BIN_SEGS + 1) {
+    if (one_total && blockIdx.y == 2) {
         if (blockIdx.x != 0) return;
         __shared__ ScanShared sh;
         scan_chunks<256>(sh, nchunks, block_sums, counters, capacity, mail, seq);
         return;
     }
-    if (blockIdx.y == FRG_BIN_SEGS) {
+    if (one_total && blockIdx.y == 1) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int r = blockIdx.x * 4 + wave;
         if (r >= gy) return;
@@ -803,10 +807,27 @@ colsum_kernel(int T, int nrows, const uint32_t* __restrict__ bin_matrix, uint32_
     // the counters of the backward blend's item lists (filled by the forward blend's tile workgroups) start at zero
     if (blockIdx.y == 0 && blockIdx.x == 0)
         for (int i = threadIdx.x; i < FRG_NUM_XCD * (FRG_BWD_LEN_BUCKETS + 1); i += 256) bwd_cnt[i] = 0u;
+    if (one_total) {
+        __shared__ uint32_t part[4][64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int t = blockIdx.x * 64 + lane;
+        uint32_t s = 0;
+        if (t < T) {
+#pragma unroll 8
+            for (int r = wave; r < nrows; r += 4) s += bin_matrix[(size_t)r * T + t];
+        }
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && t < T) {
+            tile_count[t] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            // the scatter's fill cursor and the forward blend's depth mark of every tile start at zero: cleared here, on
+            // the way, instead of by a memset launch in front of every forward
+            tile_fill[t] = 0u; tile_work[t] = 0u;
+        }
+        return;
+    }
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    // the scatter's fill cursor and the forward blend's depth mark of every tile start at zero: cleared here, on the way,
-    // instead of by a memset launch in front of every forward
     if (blockIdx.y == 0) { tile_fill[t] = 0u; tile_work[t] = 0u; }
     // segment s = the workgroups the dispatcher places on XCD s (round robin, FRG_BIN_SEGS == 8):
     // a tile's runs written by one XCD are then adjacent in memory, so partially written lines
@@ -928,7 +949,7 @@ reorder_kernel(int P, int nblocks, int ncells, int band_w, int nbands, const uin
         // front of it.  Nothing in the reorder depends on it.
         __shared__ ScanShared sh;
         extern __shared__ __attribute__((aligned(16))) uint32_t scan_tot[];    // T words (dynamic LDS of this launch)
-        scan_tiles<FRG_BIN_THREADS, 2>(sh, scan_tot, counters->overflow != 0, T, gx, tile_count, seg_sums, ranges, class_tiles, counters, tight, mail, seq);
+        scan_tiles<FRG_BIN_THREADS, 3>(sh, scan_tot, counters->overflow != 0, T, gx, tile_count, seg_sums, ranges, class_tiles, counters, tight, mail, seq);
         return;
     }
     __shared__ uint32_t cursor[FRG_MAX_TILE_ROWS];
@@ -1154,9 +1175,10 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
     const int nb = bin_blocks(P);
     const bool cells = cell_order(img, vp);
     if (img.lds_bins)
-        hipLaunchKernelGGL(colsum_kernel, dim3(std::max((T + 255) / 256, cells ? (img.ncells + 3) / 4 : 0), FRG_BIN_SEGS + (cells ? 2 : 0)),
+        hipLaunchKernelGGL(colsum_kernel, cells ? dim3(std::max((T + 63) / 64, (img.ncells + 3) / 4), 3) : dim3((T + 255) / 256, FRG_BIN_SEGS),
                            dim3(256), 0, s, T, nb, img.bin_matrix, img.seg_sums, img.row_matrix, img.row_start, img.ncells,
-                           nchunks, g.block_sums, img.counters, capacity, mail, seq, img.tile_fill, img.tile_work, img.bwd_cnt);
+                           nchunks, g.block_sums, img.counters, capacity, mail, seq, img.tile_fill, img.tile_work, img.bwd_cnt,
+                           cells ? 1 : 0, img.tile_count);
     if (cells) {
         // the records in cell order (+ point_offsets); its extra workgroup scans the tile totals
         hipLaunchKernelGGL(reorder_kernel, dim3(nb + 1), dim3(FRG_BIN_THREADS), (size_t)T * 4, s, P, nb, img.ncells, img.band_w, img.nbands,

@@ -133,6 +133,89 @@ sh_grad_from_views_kernel(int P, int D, int M, int n_views, const float* __restr
     }
 }
 
+// ---- sparse exchange of the dense part (round 5) --------------------------------------------------------------------------
+// Per view only the Gaussians some pixel reached before its tile saturated carry a gradient -- one visible Gaussian in
+// seven at C3 -- so the rows that travel are (index, 11 dense floats, dRGB): 64 bytes per Gaussian WITH a gradient instead
+// of 56 per Gaussian.  pack: every row that is not all zero, compacted (wave ballot + one atomic per wave: the order of the
+// rows is whatever the waves' atomics made it -- indices are unique per view, so nothing downstream depends on it).
+// scatter: one view's rows added into the dense gradient arrays (and its dRGB laid out densely for the SH rebuild above);
+// one launch per view, in view order, on one stream: every element receives its terms in view order -- the sum is the
+// single-process accumulation bit for bit.
+#define FRG_ROW_FLOATS 16
+__global__ void __launch_bounds__(256)
+pack_grad_rows_kernel(int P, const float* __restrict__ g_means3D, const float* __restrict__ g_scales,
+                      const float* __restrict__ g_rot, const float* __restrict__ g_opac, const float* __restrict__ drgb,
+                      float4* __restrict__ rows, unsigned int capacity, unsigned int* __restrict__ count)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float v[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) v[i] = 0.0f;
+    if (idx < P) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { v[i] = g_means3D[3 * (size_t)idx + i]; v[3 + i] = g_scales[3 * (size_t)idx + i]; v[11 + i] = drgb[3 * (size_t)idx + i]; }
+        v[6] = g_opac[idx];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[7 + i] = g_rot[4 * (size_t)idx + i];
+    }
+    bool live = false;
+#pragma unroll
+    for (int i = 0; i < 14; i++) live = live || (v[i] != 0.0f);      // (a NaN row is live: it must show up in the sum)
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(live);
+    if (mask == 0ull) return;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned int)__popcll(mask));
+    base = (unsigned int)__shfl((int)base, 0, 64);
+    const unsigned int at = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+    if (!live || at >= capacity) return;         // (over capacity: the count says so, the host packs again into a larger buffer)
+    float4* r = rows + (size_t)at * (FRG_ROW_FLOATS / 4);
+    r[0] = make_float4(__uint_as_float((uint32_t)idx), v[0], v[1], v[2]);
+    r[1] = make_float4(v[3], v[4], v[5], v[6]);
+    r[2] = make_float4(v[7], v[8], v[9], v[10]);
+    r[3] = make_float4(v[11], v[12], v[13], 0.0f);
+}
+
+__global__ void __launch_bounds__(256)
+scatter_grad_rows_kernel(unsigned int n, int P, const float4* __restrict__ rows, float* __restrict__ g_means3D,
+                         float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_opac,
+                         float* __restrict__ drgb_dense)
+{
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4* r = rows + (size_t)i * (FRG_ROW_FLOATS / 4);
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+    const uint32_t idx = __float_as_uint(a.x);
+    if (idx >= (uint32_t)P) return;              // (a corrupt row must not write out of range)
+    float* m = g_means3D + 3 * (size_t)idx;
+    m[0] += a.y; m[1] += a.z; m[2] += a.w;
+    float* sc = g_scales + 3 * (size_t)idx;
+    sc[0] += b.x; sc[1] += b.y; sc[2] += b.z;
+    g_opac[idx] += b.w;
+    float* q = g_rot + 4 * (size_t)idx;
+    q[0] += c.x; q[1] += c.y; q[2] += c.z; q[3] += c.w;
+    if (drgb_dense) { float* o = drgb_dense + 3 * (size_t)idx; o[0] = d.x; o[1] = d.y; o[2] = d.z; }
+}
+
+hipError_t launch_pack_grad_rows(int P, const float* g_means3D, const float* g_scales, const float* g_rot, const float* g_opac,
+                                 const float* drgb, float* rows, unsigned int capacity, unsigned int* count, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pack_grad_rows_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g_means3D, g_scales, g_rot, g_opac, drgb,
+                       reinterpret_cast<float4*>(rows), capacity, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_grad_rows(unsigned int n, int P, const float* rows, float* g_means3D, float* g_scales, float* g_rot,
+                                    float* g_opac, float* drgb_dense, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_grad_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, P, reinterpret_cast<const float4*>(rows),
+                       g_means3D, g_scales, g_rot, g_opac, drgb_dense);
+    return hipGetLastError();
+}
+
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s)
 {
     hipLaunchKernelGGL(sh_color_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rgb_clamped, radii, dL_dcolor, out);

@@ -54,6 +54,34 @@ def _hip_sh_reducer(ex: "GradientExchange"):
         raise RuntimeError(f"frg_sh_grad_from_views failed ({rc}): {_lib.last_error()}")
 
 
+ROW_FLOATS = 16    # a row of the sparse exchange: index bits, dL_dmeans3D[3], dL_dscales[3], dL_dopacity, dL_drotations[4], dRGB[3], pad
+
+
+def _hip_row_packer(ex: "GradientExchange"):
+    """rows_own <- the non-zero rows of this view's dense gradients + dRGB, count_dev <- their number (frg_pack_grad_rows)."""
+    if ex.flat.device.type != "cuda":
+        raise RuntimeError("the sparse exchange packs its rows with a HIP kernel: gradients must live on the GPU "
+                           "(no CPU path; tests inject their own packer)")
+    v = ex.views
+    stream = C.c_void_p(torch.cuda.current_stream(ex.flat.device).cuda_stream)
+    rc = _lib.lib().frg_pack_grad_rows(ex.P, _p(v["means3D"]), _p(v["scales"]), _p(v["rotations"]), _p(v["opacities"]),
+                                       _p(ex.own_drgb), _p(ex.rows_own), ex.rows_own.shape[0], _p(ex.count_dev), stream)
+    if rc < 0:
+        raise RuntimeError(f"frg_pack_grad_rows failed ({rc}): {_lib.last_error()}")
+
+
+def _hip_row_scatterer(ex: "GradientExchange", rows: torch.Tensor, n: int, drgb_dense):
+    """dense gradient arrays += rows[:n]; drgb_dense[index] <- the rows' dRGB (frg_scatter_grad_rows)."""
+    if ex.flat.device.type != "cuda":
+        raise RuntimeError("the sparse exchange scatters its rows with a HIP kernel (no CPU path; tests inject their own)")
+    v = ex.views
+    stream = C.c_void_p(torch.cuda.current_stream(ex.flat.device).cuda_stream)
+    rc = _lib.lib().frg_scatter_grad_rows(int(n), ex.P, _p(rows), _p(v["means3D"]), _p(v["scales"]), _p(v["rotations"]),
+                                          _p(v["opacities"]), _p(drgb_dense), stream)
+    if rc < 0:
+        raise RuntimeError(f"frg_scatter_grad_rows failed ({rc}): {_lib.last_error()}")
+
+
 # ---- the 8-GPU budget (DESIGN.md section 5) -----------------------------------------------------------------------------
 XGMI_LINKS = 7                 # one node: every MI355X talks to each of the other seven over its own link
 XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task statement and SURVEY 8(e) give)
@@ -61,32 +89,56 @@ XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task sta
 
 def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "factored", reduce: str = "allreduce",
                      schedule: str = "in-step", link_efficiency: float = 0.8, rebuild_ms_per_view: float = 0.019,
-                     split_overhead_ms: float = 0.08, per_gaussian_bwd_ms: float = 0.29):
+                     split_overhead_ms: float = 0.08, per_gaussian_bwd_ms: float = 0.29, bus_GBps: float = None,
+                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0):
     """Predicted step time and scaling of the view-parallel step on ONE node of `world` MI355X: arithmetic, not a
     measurement (no 8-GPU run is available to this repository; bench.py prints it as `predicted`).
 
     Bytes per rank: the dense part is 11 floats per Gaussian (44 P bytes) in the factored plan, (11 + 3 K) floats in the
-    plain one; the factored plan adds an all-gather of 3 floats per Gaussian and view.  Wire time of a collective over the
-    fully connected xGMI node:
+    plain one; the factored plan adds an all-gather of 3 floats per Gaussian and view; the sparse plan moves ROWS of 64
+    bytes for the rows_fraction x P Gaussians with a gradient (0.124 = the 371 447 of 3 M measured at C3).  Wire time of a
+    collective over the fully connected xGMI node, when bus_GBps is None -- from the links:
       * direct (reduce-scatter + all-gather of 1/N shards, every link busy): 2 (N-1)/N bytes / (links in use x rate),
         links in use = min(N - 1, 7);
       * RCCL all-reduce is taken as a ring bound by ONE link: 2 (N-1)/N bytes / rate -- the pessimistic reading of
         SURVEY 8(e); RCCL may do better on this topology, which is for the driver's curve to say;
-      * all-gather of the payloads: (N-1) x 12 P bytes arrive over N-1 links in parallel: 12 P bytes / rate.
+      * all-gather of the payloads / the rows: every peer's block arrives over its own link: block bytes / rate.
+    With bus_GBps (the aggregate rate at which ONE GPU receives / sends during a collective -- RCCL's "bus bandwidth";
+    7 x 153 = 1071 nominal): every collective moves its incoming bytes, (N-1)/N x the total, at that rate (the all-reduce
+    twice: reduce-scatter + all-gather), whatever its algorithm.
     Exposed time (what the step grows by): schedule "in-step" with the two-call backward hides the payload all-gather
     under phase 2 of the backward (per_gaussian_bwd_ms) at the price of split_overhead_ms; the SH rebuild
-    (rebuild_ms_per_view x N, measured 0.15 ms at 8 views) runs beside the dense sum; "sync" hides nothing.
+    (rebuild_ms_per_view x N, measured 0.15 ms at 8 views) runs beside the dense sum; "sync" hides nothing.  Sparse plan
+    (one-call backward, nothing hidden but the zero fills, which run under the wire): pack (one read of the 56 P bytes) +
+    the host's wait for the counts (0.03 ms) + the row all-gather + one scatter launch per view + the SH rebuild.
     link_efficiency: achieved / nominal link rate.  Returns a dict."""
     rate = XGMI_LINK_GBPS * 1e9 * link_efficiency
     links = max(1, min(world - 1, XGMI_LINKS))
-    factored = plan == "factored"
+    factored = plan in ("factored", "sparse")
+    sparse = plan == "sparse"
+    bus = bus_GBps * 1e9 if bus_GBps else None
     dense_bytes = 4 * P * (11 if factored else 11 + 3 * K)
     frac = 2.0 * (world - 1) / world if world > 1 else 0.0
-    dense_ms = 1e3 * frac * dense_bytes / (rate * (links if reduce == "direct" else 1))
-    gather_ms = 1e3 * (12.0 * P / rate) if (factored and world > 1) else 0.0
+    if bus:
+        dense_ms = 1e3 * frac * dense_bytes / bus
+        gather_ms = 1e3 * (12.0 * P * (world - 1) / bus) if (factored and world > 1) else 0.0
+    else:
+        dense_ms = 1e3 * frac * dense_bytes / (rate * (links if reduce == "direct" else 1))
+        gather_ms = 1e3 * (12.0 * P / rate) if (factored and world > 1) else 0.0
     rebuild_ms = rebuild_ms_per_view * world if factored else 0.0
+    rows = rows_fraction * P
+    rows_ms = pack_ms = scatter_ms = zero_ms = counts_ms = 0.0
+    if sparse and world > 1:
+        row_bytes = 4.0 * ROW_FLOATS * rows
+        rows_ms = 1e3 * (row_bytes * (world - 1) / bus if bus else row_bytes / rate)
+        pack_ms = 1e3 * (56.0 * P + row_bytes) / (hbm_GBps * 1e9)
+        counts_ms = 0.03
+        zero_ms = 1e3 * (44.0 * P + 12.0 * P * world) / (hbm_GBps * 1e9)      # the dense part and the dense dRGB of every view
+        scatter_ms = world * (0.004 + 1e3 * (row_bytes + 2 * 44.0 * rows + 12.0 * rows) / (hbm_GBps * 1e9 * 0.5))   # launch + scattered read-modify-write at half rate
     if world == 1:
         exposed = 0.0
+    elif sparse:
+        exposed = pack_ms + counts_ms + max(rows_ms, zero_ms) + scatter_ms + rebuild_ms
     elif not factored:
         exposed = dense_ms
     elif schedule == "in-step":
@@ -94,11 +146,16 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
     else:
         exposed = gather_ms + dense_ms + rebuild_ms
     step = render_ms + exposed
-    return {"world": world, "plan": plan, "reduce": reduce, "schedule": schedule, "dense_MB": dense_bytes / 1e6,
-            "gather_MB_in": 12.0 * P * max(world - 1, 0) / 1e6 if factored else 0.0, "dense_wire_ms": dense_ms,
-            "gather_wire_ms": gather_ms, "sh_rebuild_ms": rebuild_ms, "exposed_ms": exposed, "ms_per_step": step,
-            "scaling_vs_1gpu": world * render_ms / step, "link_GBps": XGMI_LINK_GBPS, "link_efficiency": link_efficiency,
-            "note": "arithmetic from bytes and the nominal xGMI link rate, not a measurement"}
+    out = {"world": world, "plan": plan, "reduce": reduce, "schedule": schedule, "dense_MB": (0.0 if sparse else dense_bytes / 1e6),
+           "gather_MB_in": 12.0 * P * max(world - 1, 0) / 1e6 if (factored and not sparse) else 0.0, "dense_wire_ms": 0.0 if sparse else dense_ms,
+           "gather_wire_ms": 0.0 if sparse else gather_ms, "sh_rebuild_ms": rebuild_ms, "exposed_ms": exposed, "ms_per_step": step,
+           "scaling_vs_1gpu": world * render_ms / step, "link_GBps": XGMI_LINK_GBPS, "link_efficiency": link_efficiency,
+           "bus_GBps": bus_GBps,
+           "note": "arithmetic from bytes and the nominal xGMI link rate (or the given bus bandwidth), not a measurement"}
+    if sparse:
+        out.update(rows_per_rank=rows, rows_MB_in=4.0 * ROW_FLOATS * rows * max(world - 1, 0) / 1e6, rows_wire_ms=rows_ms,
+                   pack_ms=pack_ms, counts_wait_ms=counts_ms, zero_fill_ms=zero_ms, scatter_ms=scatter_ms)
+    return out
 
 
 class GradientExchange:
@@ -114,7 +171,8 @@ class GradientExchange:
         independent of the collective's reduction order for the SH part."""
 
     def __init__(self, shapes: dict, device, process_group=None, average: bool = False,
-                 factor_sh: bool = False, sh_reducer=None, reduce: str = "allreduce"):
+                 factor_sh: bool = False, sh_reducer=None, reduce: str = "allreduce", sparse: bool = False,
+                 row_packer=None, row_scatterer=None):
         """reduce: how the summed part travels.  "allreduce": one collective, the backend picks the
         algorithm (RCCL: rings / trees over xGMI).  "direct": reduce-scatter written as ONE all-to-all of
         1/N shards -- every GPU sends shard j straight to GPU j over its own xGMI link, all seven links of
@@ -123,6 +181,14 @@ class GradientExchange:
         seven)."""
         self.shapes = {k: tuple(shapes[k]) for k in PARAM_ORDER if k in shapes}
         self.device = torch.device(device)
+        # sparse: the third plan (round 5).  Per view only the Gaussians some pixel reached carry a gradient (one visible
+        # Gaussian in seven at C3), so ranks all-gather ROWS -- (index, the 11 dense floats, dRGB): 64 bytes per Gaussian
+        # with a gradient -- instead of summing 44 bytes and gathering 12 per Gaussian: counts first (one small all-gather
+        # the host waits for: it sizes the padded row all-gather), the rows, then every rank adds the views' rows into a
+        # zeroed dense part in VIEW ORDER (one scatter launch per view) and rebuilds the SH sum as the factored plan does.
+        # Bit-identical to the single-process accumulation, whatever the collective's internals.
+        self.sparse = bool(sparse) and "shs" in self.shapes
+        factor_sh = factor_sh or self.sparse
         self.group = process_group
         self.average = average
         _, self.layout, self.numel = flat_layout(self.shapes)
@@ -145,6 +211,17 @@ class GradientExchange:
             self.gathered = None                            # [world, payload_numel], sized at first start()
             self.sh_reducer = sh_reducer or _hip_sh_reducer
             self.means3D, self.sh_degree = None, 0
+        if self.sparse:
+            self.P = P
+            self.row_packer = row_packer or _hip_row_packer
+            self.row_scatterer = row_scatterer or _hip_row_scatterer
+            self.rows_own = torch.zeros((max(1024, P // 4), ROW_FLOATS), dtype=torch.float32, device=self.device)   # grows when a view needs more
+            self.count_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.header_own = torch.zeros(4, dtype=torch.float32, device=self.device)     # row count (int32 bit pattern), camera centre
+            self.headers = None                        # [world, 4]
+            self.rows_all = None                       # [world, capacity, ROW_FLOATS], sized from the gathered counts
+            self.counts = []                           # rows per view of the exchange in flight
+            self.sparse_stats = {"rows_own": 0, "rows_max": 0, "repacks": 0}
 
     def set_sh_context(self, means3D: torch.Tensor, sh_degree: int):
         """Replicated inputs the SH rebuild needs (factored plan)."""
@@ -157,6 +234,8 @@ class GradientExchange:
     @property
     def wire_floats_per_rank(self) -> int:
         """Floats each rank contributes to the collectives of one exchange."""
+        if self.sparse:       # what the last exchange moved: the padded rows + the header
+            return max(self.sparse_stats["rows_max"], 1) * ROW_FLOATS + 4
         return (self.dense.numel() + self.payload_numel) if self.factor_sh else self.numel
 
     def _active(self):
@@ -179,6 +258,8 @@ class GradientExchange:
             self._works = []
         if not self._active():
             return None
+        if self.sparse:
+            return self._start_sparse()
         if self.factor_sh:
             if part != "dense":
                 world = dist.get_world_size(self.group)
@@ -195,6 +276,55 @@ class GradientExchange:
         else:
             self._works.append(dist.all_reduce(summed, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return self._works
+
+    def _start_sparse(self):
+        """Pack this view's non-zero rows, all-gather the row counts (+ camera centres) -- the one host wait of the plan:
+        the counts size the padded all-gather of the rows -- and enqueue that all-gather."""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        while True:
+            self.row_packer(self)
+            n_own = int(self.count_dev.item())                   # host wait: the backward is complete, the rows are packed
+            if n_own <= self.rows_own.shape[0]:
+                break
+            self.rows_own = torch.zeros((int(n_own * 1.25) + 1024, ROW_FLOATS), dtype=torch.float32, device=self.device)
+            self.sparse_stats["repacks"] += 1
+        self.header_own[0:1].view(torch.int32).fill_(n_own)
+        self.header_own[1:4].copy_(self.own_campos)
+        if self.headers is None or self.headers.shape[0] != world:
+            self.headers = torch.zeros((world, 4), dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(self.headers.view(-1), self.header_own, group=self.group)
+        self.counts = [int(c) for c in self.headers[:, 0].contiguous().view(torch.int32).tolist()]
+        cap = (max(self.counts + [1]) + 255) // 256 * 256      # the same on every rank: it comes from the gathered counts
+        if self.rows_own.shape[0] < cap:
+            grown = torch.zeros((cap, ROW_FLOATS), dtype=torch.float32, device=self.device)
+            grown[: self.rows_own.shape[0]].copy_(self.rows_own)
+            self.rows_own = grown
+        if self.rows_all is None or self.rows_all.shape[0] != world or self.rows_all.shape[1] < cap:
+            self.rows_all = torch.zeros((world, int(cap * 1.25) // 256 * 256 + 256, ROW_FLOATS), dtype=torch.float32, device=self.device)
+        self._rows_cap = cap
+        self._rows_recv = self.rows_all.view(-1)[: world * cap * ROW_FLOATS]
+        self.sparse_stats.update(rows_own=n_own, rows_max=max(self.counts))
+        self._works.append(dist.all_gather_into_tensor(self._rows_recv, self.rows_own[:cap].reshape(-1), group=self.group, async_op=True))
+        return self._works
+
+    def _finish_sparse(self):
+        """The dense part <- the views' rows added in view order into zeros; the dRGB of every view laid out densely for
+        the SH rebuild; the rebuild."""
+        world, cap = len(self.counts), self._rows_cap
+        if self.gathered is None or self.gathered.shape[0] != world:
+            self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
+        self.dense.zero_()
+        self.gathered.zero_()
+        P = self.P
+        recv = self._rows_recv.view(world, cap, ROW_FLOATS)
+        for v in range(world):                                # view order: the order of the single-process accumulation
+            self.gathered[v, 3 * P: 3 * P + 3].copy_(self.headers[v, 1:4])
+            if self.counts[v]:
+                self.row_scatterer(self, recv[v], self.counts[v], self.gathered[v, : 3 * P])
+        if self.means3D is None:
+            raise RuntimeError("sparse exchange: call set_sh_context(means3D, sh_degree) first")
+        self.sh_reducer(self)
 
     def _start_direct(self, summed):
         """Phase 1 of the direct plan.  RCCL: ONE reduce_scatter_tensor -- rank j receives the sum of everyone's shard
@@ -247,9 +377,11 @@ class GradientExchange:
         for w in self._works:
             w.wait()
         self._works = []
-        if self.reduce == "direct":
+        if self.sparse:
+            self._finish_sparse()
+        elif self.reduce == "direct":
             self._finish_direct()
-        if self.factor_sh:
+        if self.factor_sh and not self.sparse:
             if self.means3D is None:
                 raise RuntimeError("factored exchange: call set_sh_context(means3D, sh_degree) first")
             self.sh_reducer(self)
@@ -264,7 +396,7 @@ class GradientExchange:
         current stream then waits for both."""
         if not self._works:
             return self.flat
-        overlap = self.factor_sh and not self.average and self.flat.device.type == "cuda"
+        overlap = self.factor_sh and not self.sparse and not self.average and self.flat.device.type == "cuda"
         if not overlap:
             self._finish_on_current_stream()
             return self.flat
@@ -294,7 +426,7 @@ class GradientExchange:
         this buffer is started again and before the SH rows are read."""
         if not self._works:
             return
-        if not self.factor_sh or self.average or self.flat.device.type != "cuda":
+        if not self.factor_sh or self.sparse or self.average or self.flat.device.type != "cuda":
             self._finish_on_current_stream()
             return
         if self.means3D is None:
@@ -423,7 +555,7 @@ class ViewParallelRasterizer:
 
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
                  deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce",
-                 write_all_outputs: bool = True, raw_params: bool = False):
+                 write_all_outputs: bool = True, raw_params: bool = False, sparse: bool = False):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
@@ -439,10 +571,12 @@ class ViewParallelRasterizer:
         self.scene = scene
         P, K = scene.means3D.shape[0], scene.shs.shape[1]
         self.P, self.K = P, K
+        self._group, self._average = process_group, average
         shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
         # two gradient buffers: the exchange of step k may still be in flight on the
         # collective stream while step k+1 renders and writes the other buffer
-        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average, factor_sh=factor_sh, reduce=reduce)
+        # sparse: the exchange moves rows of the Gaussians with a gradient (GradientExchange, third plan)
+        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average, factor_sh=factor_sh, reduce=reduce, sparse=sparse)
                           for _ in range(2)]
         for ex in self.exchanges:
             if ex.factor_sh:
@@ -461,6 +595,21 @@ class ViewParallelRasterizer:
         self.out_color = None
         self.num_rendered = 0
         self._view = None
+
+    def set_exchange_plan(self, plan: str, reduce: str = None):
+        """Replace the gradient exchange: 'allreduce' | 'factored' | 'sparse' (GradientExchange).  Pending collectives of the
+        old plan must have been waited for; the gradient buffers are new (zeroed)."""
+        old = self.exchanges[0]
+        shapes = old.shapes
+        reduce = reduce or old.reduce
+        self.exchanges = None
+        del old
+        self.exchanges = [GradientExchange(shapes, self.dev, self._group, self._average, factor_sh=(plan != "allreduce"), reduce=reduce,
+                                           sparse=(plan == "sparse")) for _ in range(2)]
+        for ex in self.exchanges:
+            if ex.factor_sh:
+                ex.set_sh_context(self.scene.means3D, self.scene.sh_degree)
+        self.exchange = self.exchanges[0]
 
     def forward(self, cam, bg, deferred=None, keep_mask=None):
         """Render one view.  With deferred counters the returned image is valid only if the
@@ -600,7 +749,7 @@ class ViewParallelRasterizer:
         exchanges[slot].finish_in_step() (or exchange_in_step(slot, started=True)).  Without a live factored exchange:
         a plain backward + start_exchange."""
         ex = self.exchanges[slot]
-        if not (ex.factor_sh and ex._active()):
+        if not (ex.factor_sh and ex._active()) or ex.sparse:      # (sparse: one call -- its rows are packed from the finished gradients)
             g = self.backward(dL_dimage, slot)
             ex.start()
             return g

@@ -245,8 +245,10 @@ int frg_backward_ex(const frg_backward_args* args);
  * "tight_binning": 1 = a (Gaussian, tile) instance is only put on the tile's list if the Gaussian can
  * reach alpha >= 1/255 somewhere in the tile (the closed-form bound the blend kernels use per 8x8
  * quadrant, taken over the 16x16 tile); the reference lists every tile of the 3-sigma square
- * (forward.cu:236-255), about twice as many.  num_rendered, radii, the image and all gradients are
- * bit-identical either way; the tile lists become order-preserving sub-lists of the reference's.
+ * (forward.cu:236-255), about twice as many.  num_rendered, radii and the image are bit-identical either way; the
+ * tile lists become order-preserving sub-lists of the reference's.  The gradients are bit-identical while no tile's
+ * walk crosses a segment boundary of the backward blend ("bwd_seg_log"), and agree to float32 rounding beyond (a
+ * boundary is a list position: the sub-list restarts the walk from another rounding of the same state).
  * Default 0: lists identical to the reference's, entry for entry.
  * "bwd_waves" (default 0 = one single-wave workgroup per work item, at most 16384): workgroups of the backward blend.
  * A work item is a SEGMENT of a tile's processed list prefix (the forward leaves every pixel's state at the segment
@@ -349,6 +351,21 @@ int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const fl
 int frg_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D,
                            const float* campos, long long campos_stride,
                            const float* drgb, long long view_stride, float* dL_dsh, void* hip_stream);
+
+/* Sparse form of the exchange (round 5).  Of one view's per-Gaussian gradients only the rows of Gaussians some pixel reached
+ * are non-zero (one visible Gaussian in seven at 3 M Gaussians), so what travels between ranks are ROWS of 16 floats
+ *   { index (uint32 bit pattern), dL_dmeans3D[3], dL_dscales[3], dL_dopacity, dL_drotations[4], dRGB[3], 0 }
+ * of the Gaussians with a non-zero row: 64 bytes per Gaussian with a gradient instead of 56 per Gaussian.
+ * frg_pack_grad_rows: rows <- the non-zero rows of the five arrays, compacted (in no particular order; indices are unique);
+ *   *count (device, 4 bytes) <- their number, which may exceed capacity_rows -- then only capacity_rows of them were
+ *   written and the caller packs again into a larger buffer.  `rows` 16-byte aligned.
+ * frg_scatter_grad_rows: adds n_rows rows INTO the four dense arrays (+=) and, when drgb_dense != NULL, stores their dRGB
+ *   at drgb_dense[3 * index ..] (the layout frg_sh_grad_from_views reads).  One call per view, in view order, on one
+ *   stream: every element then receives its terms in view order -- the single-process accumulation, bit for bit. */
+int frg_pack_grad_rows(int P, const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations, const float* dL_dopacity,
+                       const float* drgb, float* rows, long long capacity_rows, unsigned int* count, void* hip_stream);
+int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_dmeans3D, float* dL_dscales, float* dL_drotations,
+                          float* dL_dopacity, float* drgb_dense, void* hip_stream);
 
 /* ---- fused Adam over the flat per-Gaussian parameter layout ---------------------------
  * SURVEY.md 8(f) rank 1, the step right after the backward / the gradient exchange.  Replaces

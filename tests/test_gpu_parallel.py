@@ -89,8 +89,8 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
     try:
         scene, cam, bg = scenes.config_scene("mini", 2, P=6000)
         ref = None
-        for factored in (False, True):
-            vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored)
+        for factored in (False, True, "sparse"):
+            vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=bool(factored), sparse=factored == "sparse")
             img, _ = vpr.forward(cam.to(dev), bg.to(dev))
             gpix, _ = scenes.l1_target_grad(img.cpu(), 77)
             gpix = gpix.to(dev)
@@ -120,6 +120,9 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
             assert torch.equal(flat, ref)
             if factored:
                 assert torch.equal(vpr.exchanges[0].own, own_before)       # the payload phase 1 wrote = the one-call payload
+            if factored == "sparse":     # rows of the Gaussians with a gradient only: fewer than are visible, packed without a re-pack at this size
+                st = vpr.exchanges[0].sparse_stats
+                assert 0 < st["rows_own"] <= int((vpr.radii > 0).sum()) and st["rows_max"] == st["rows_own"]
     finally:
         dist.destroy_process_group()
 
@@ -209,7 +212,7 @@ def test_deferred_counters_forward_matches_blocking_forward(gpu_device):
     assert torch.equal(img, img0) and torch.equal(vpr.exchange.flat, flat0)
 
 
-def _rank_worker(rank, world, port, factored, P, q):
+def _rank_worker(rank, world, port, factored, P, q, sparse=False):
     """One rank of a 2-rank job on GPU 0 (gloo carries the collectives: RCCL refuses two ranks per device)."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -219,7 +222,7 @@ def _rank_worker(rank, world, port, factored, P, q):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         scene, cam, bg = scenes.config_scene("mini", rank + 1, P=P)       # rank k renders view k + 1
-        vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored)
+        vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored, sparse=sparse)
         img, _ = vpr.forward(cam.to(dev), bg.to(dev))
         gpix, _ = scenes.l1_target_grad(img.cpu(), 555 + rank + 1)
         gpix = gpix.to(dev)
@@ -243,14 +246,16 @@ def _rank_worker(rank, world, port, factored, P, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("factored", [False, True])
+@pytest.mark.parametrize("factored", [False, True, "sparse"])
 def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
     import torch.multiprocessing as mp
     world, P = 2, 5000
+    sparse = factored == "sparse"
+    factored = bool(factored)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, factored, P, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, factored, P, q, sparse)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -272,7 +277,7 @@ def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
     assert (res[0] == res[1]).all()
 
 
-@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+@pytest.mark.parametrize("exchange", ["factored", "allreduce", "sparse"])
 def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
     """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under
     torch.distributed.run, both ranks share GPU 0 (FRG_BENCH_ONE_GPU) and exchange over gloo; rank 0 prints

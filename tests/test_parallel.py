@@ -95,6 +95,29 @@ def torch_sh_reducer(ex):
     ex.views["shs"].copy_(out)
 
 
+def torch_row_packer(ex):
+    """Test-side stand-ins for csrc/view_exchange.hip's pack / scatter kernels (the product ones are HIP-only)."""
+    v = ex.views
+    dense = torch.cat([v["means3D"], v["scales"], v["opacities"], v["rotations"], ex.own_drgb], 1)     # the row layout, [P, 14]
+    idx = ((dense != 0) | dense.isnan()).any(1).nonzero().flatten()
+    ex.count_dev.fill_(idx.numel())
+    m = min(idx.numel(), ex.rows_own.shape[0])
+    ex.rows_own[:m, 0] = idx[:m].to(torch.int32).view(torch.float32)
+    ex.rows_own[:m, 1:15] = dense[idx[:m]]
+    ex.rows_own[:m, 15] = 0.0
+
+
+def torch_row_scatterer(ex, rows, n, drgb_dense):
+    r = rows[:n]
+    idx = r[:, 0].contiguous().view(torch.int32).long()
+    v = ex.views
+    v["means3D"].index_add_(0, idx, r[:, 1:4])
+    v["scales"].index_add_(0, idx, r[:, 4:7])
+    v["opacities"].index_add_(0, idx, r[:, 7:8])
+    v["rotations"].index_add_(0, idx, r[:, 8:12])
+    drgb_dense.view(-1, 3)[idx] = r[:, 12:15]
+
+
 def _view_inputs(rank, P, K, deg):
     """Per-view gradient of rank `rank`: random dense part, rank-one SH part."""
     from frosting_amd.sh import sh_basis
@@ -174,15 +197,21 @@ def test_factored_exchange_needs_gpu_reducer():
 # (exchange -> Adam -> next forward) on N ranks must equal the single-process accumulation of the same N views, bit
 # for bit: the in-step schedule leaves nothing of step k in flight when step k+1 reads the parameters.
 
-def _view_gradient(params, view, deg, K):
+def _view_gradient(params, view, deg, K, unreached=False):
     """A deterministic stand-in for one view's backward: depends on the CURRENT parameters (so a stale exchange would
-    show), dense part arbitrary, SH part rank one per Gaussian as the rasterizer's is (basis(view dir) x dRGB)."""
+    show), dense part arbitrary, SH part rank one per Gaussian as the rasterizer's is (basis(view dir) x dRGB).
+    unreached: two Gaussians in three get no gradient at all in this view (no pixel reached them), as on a saturating frame."""
     from frosting_amd.sh import sh_basis
     P = params["means3D"].shape[0]
     campos = 4.0 * torch.nn.functional.normalize(torch.tensor([1.0 + view, 0.5 - view, 2.0]), dim=0)
     dense = {k: torch.sin(params[k] * (1.5 + view)) * (0.1 + 0.01 * view) for k in ("means3D", "scales", "rotations", "opacities")}
     drgb = torch.cos(params["shs"][:, 0, :] * (2.0 + view)) * 0.05
     drgb[(torch.arange(P) + view) % 4 == 0] = 0.0                      # culled / clamped rows of this view
+    if unreached:
+        dead = (torch.arange(P) * 7 + 3 * view) % 3 != 0
+        for t in dense.values():
+            t[dead] = 0.0
+        drgb[dead] = 0.0
     d = params["means3D"] - campos
     basis = sh_basis(deg, d / d.norm(dim=1, keepdim=True))
     shs = torch.zeros(P, K, 3)
@@ -196,7 +225,7 @@ def _initial_params(P, K):
     return shapes, {k: torch.randn(s, generator=g) for k, s in shapes.items()}
 
 
-def _train_worker(rank, world, port, P, K, deg, steps, factored, reduce, q):
+def _train_worker(rank, world, port, P, K, deg, steps, factored, reduce, q, sparse=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -204,10 +233,13 @@ def _train_worker(rank, world, port, P, K, deg, steps, factored, reduce, q):
     shapes, init = _initial_params(P, K)
     params = {k: v.clone().requires_grad_(True) for k, v in init.items()}
     opt = torch.optim.Adam([params[k] for k in PARAM_ORDER], lr=0.01, eps=1e-15)
-    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=factored, sh_reducer=torch_sh_reducer, reduce=reduce)
+    ex = GradientExchange(shapes, "cpu", dist.group.WORLD, factor_sh=factored, sh_reducer=torch_sh_reducer, reduce=reduce,
+                          sparse=sparse, row_packer=torch_row_packer, row_scatterer=torch_row_scatterer)
+    if sparse:
+        ex.rows_own = ex.rows_own[:8].clone()        # start far too small: the first view must re-pack into a grown buffer
     for it in range(steps):
         with torch.no_grad():
-            campos, drgb, dense, shs = _view_gradient({k: v.detach() for k, v in params.items()}, rank, deg, K)
+            campos, drgb, dense, shs = _view_gradient({k: v.detach() for k, v in params.items()}, rank, deg, K, unreached=sparse)
             for k, v in dense.items():
                 ex.views[k].copy_(v)
             ex.views["shs"].copy_(shs)
@@ -218,6 +250,9 @@ def _train_worker(rank, world, port, P, K, deg, steps, factored, reduce, q):
         ex.start()
         ex.finish_in_step()                  # complete here: nothing is waited for in a later step
         assert not ex._works
+        if sparse:                           # a third of the rows travelled (64 B each) instead of all of them (56 B each)
+            assert 0 < max(ex.counts) <= P // 3 + 1 and ex.sparse_stats["repacks"] == 1
+            assert ex.wire_floats_per_rank < (11 + 3) * P // 2
         for k in PARAM_ORDER:
             params[k].grad = ex.views[k].clone()
         opt.step()
@@ -227,13 +262,17 @@ def _train_worker(rank, world, port, P, K, deg, steps, factored, reduce, q):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("factored,reduce", [(False, "allreduce"), (True, "allreduce"), (True, "direct")])
+@pytest.mark.parametrize("factored,reduce", [(False, "allreduce"), (True, "allreduce"), (True, "direct"), (True, "sparse")])
 def test_exchange_then_adam_then_next_forward_equals_single_process_accumulation_gloo(factored, reduce):
+    """... and the sparse plan (rows of the Gaussians with a gradient: counts, padded all-gather, scatter-add in view
+    order, SH rebuild), on views in which two Gaussians in three have no gradient."""
     world, P, K, deg, steps = 2, 131, 16, 3, 3
+    sparse = reduce == "sparse"
+    reduce = "allreduce" if sparse else reduce
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, world, port, P, K, deg, steps, factored, reduce, q)) for r in range(world)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, P, K, deg, steps, factored, reduce, q, sparse)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=150) for _ in range(world))
@@ -248,7 +287,7 @@ def test_exchange_then_adam_then_next_forward_equals_single_process_accumulation
         acc = None
         with torch.no_grad():
             for v in range(world):
-                _, _, dense, shs = _view_gradient({k: t.detach() for k, t in params.items()}, v, deg, K)
+                _, _, dense, shs = _view_gradient({k: t.detach() for k, t in params.items()}, v, deg, K, unreached=sparse)
                 cur = dict(dense, shs=shs)
                 acc = cur if acc is None else {k: acc[k] + cur[k] for k in cur}
         for k in PARAM_ORDER:

@@ -1,0 +1,89 @@
+#!/usr/bin/env bash
+# One gpurun call of round 5.  WHAT selects the parts (default: tests sparse smoke bench prof).
+#   tests     pytest -m gpu                                   sparse   tools/sparse_grad_check.py (gradients vs reference AND float64)
+#   smoke     __graft_entry__.smoke()                         bench    the driver's bench line
+#   prof      rocprofv3 --kernel-trace --stats of bench.py    ab       tools/ab.py with $AB_ARGS (one line per setting)
+#   train     tools/train_step.py                             exchange single-rank exchange schedules
+#   pmc       PMC passes LAST (FETCH/WRITE/SQ), collected into profiles/r05_pmc_*.json with the build fingerprint
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+TAG="${TAG:-r05}"
+mkdir -p gpurun_out/$TAG
+WHAT="${WHAT:-tests sparse smoke bench prof}"
+export TMPDIR=/tmp
+ROOTD="$PWD"; O="$ROOTD/gpurun_out/$TAG"
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 1800 python -m pytest tests -m gpu -q -rA --durations=15 ${PYTEST_ARGS:-} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  grep -E "passed|failed|^FAILED|^ERROR|rc=" $O/pytest_gpu.log | tail -15 ;;
+sparse)
+  FROSTING_EXPERIMENTS=1 timeout 1500 python tools/sparse_grad_check.py ${SPARSE_ARGS:-} > $O/sparse_grad_check.log 2>&1; echo "sparse rc=$?" >> $O/sparse_grad_check.log
+  grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/sparse_grad_check.log | tail -120 ;;
+smoke)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log ;;
+bench)
+  timeout 1200 python bench.py --steps 20 --warmup 5 ${BENCH_ARGS:-} > $O/bench_c3.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 2500 $O/bench_c3.json; tail -3 $O/bench.err ;;
+prof)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -- python "$ROOTD/bench.py" --steps 16 --warmup 3 --spinup-steps 24 --no-cpu-baseline --no-extras > "$O/prof_bench_c3.json" 2> "$O/prof.err")
+  f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_c3_kernel_stats.csv && head -18 $O/bench_c3_kernel_stats.csv | cut -c1-70,150-230
+  rm -rf $O/prof ;;
+ab)
+  FROSTING_EXPERIMENTS=1 timeout 900 python tools/ab.py ${AB_ARGS:-} > $O/ab.log 2>&1; echo "ab rc=$?" >> $O/ab.log; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/ab.log | tail -40 ;;
+trace)
+  # kernel timeline of one step of ${TRACE_CFG:-c2} (gaps between launches): rocprofv3 kernel trace, no counters
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace" -- python "$ROOTD/bench.py" --config ${TRACE_CFG:-c2} --steps 30 --warmup 5 --spinup-steps 50 --views 1 --no-cpu-baseline --no-extras --no-stage-timers ${TRACE_ARGS:-} > "$O/trace_bench.json" 2> "$O/trace.err")
+  f=$(find $O/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py "$f" > $O/trace_${TRACE_CFG:-c2}.log 2>&1; cat $O/trace_${TRACE_CFG:-c2}.log | tail -40
+  rm -rf $O/trace ;;
+train)
+  timeout 600 python tools/train_step.py > $O/train_step.log 2>&1; tail -6 $O/train_step.log ;;
+exchange)
+  : > $O/exchange_1rank.log
+  for mode in "--exchange factored" "--exchange factored --sync-exchange" "--exchange factored --reduce direct" "--exchange allreduce" "--exchange sparse"; do
+    echo "== bench.py --force-exchange $mode" >> $O/exchange_1rank.log
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --force-exchange $mode 2>&1 | grep -v "^Librccl\|^RCCL\|^HIP\|^ROCm\|^Hostname\|amdgpu.ids" | tail -2 >> $O/exchange_1rank.log
+  done
+  grep -c metric $O/exchange_1rank.log ;;
+pmc)
+  mkdir -p gpurun_out/pmc
+  run() { local name="$1"; shift
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOTD/gpurun_out/pmc/$name" -- python "$ROOTD/bench.py" --steps 8 --warmup 1 --spinup-steps 0 --no-cpu-baseline --no-extras --no-stage-timers > "$ROOTD/gpurun_out/pmc/$name.json" 2> "$ROOTD/gpurun_out/pmc/$name.err"); }
+  run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+  run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES
+  run fetch FETCH_SIZE
+  run write WRITE_SIZE
+  run tcc TCC_HIT_sum TCC_MISS_sum
+  python tools/collect_traffic.py gpurun_out/pmc $TAG > $O/pmc_traffic_stdout.json 2> $O/collect.err
+  python tools/collect_sq.py gpurun_out/pmc $TAG > $O/pmc_sq_stdout.json 2>> $O/collect.err
+  cp profiles/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_sq.json $O/ 2>/dev/null
+  rm -rf gpurun_out/pmc
+  tail -3 $O/collect.err; ls $O ;;
+gradab)
+  # the default arithmetic's distance to float64, one A/B build (tools/build_variants.sh) at a time: $GRADAB_LIBS = names under frosting_amd/lib_ab/
+  : > $O/grad_ab.log
+  for v in - ${GRADAB_LIBS:-}; do
+    if [ "$v" = "-" ]; then unset FROSTING_LIB; else export FROSTING_LIB="$ROOTD/frosting_amd/lib_ab/$v/libfrosting_rasterizer.so"; fi
+    timeout 600 python tools/grad_ab.py ${GRADAB_ARGS:-} 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" >> $O/grad_ab.log
+  done
+  unset FROSTING_LIB
+  cat $O/grad_ab.log ;;
+ab4|ab4b)
+  # alternating bench.py passes: SETTINGS="name|lib or -|bench args (commas for spaces)" CONFIGS="c3 c4 c2" (ab4b: SETTINGS2 / CONFIGS2)
+  if [ $w = ab4b ]; then SET="${SETTINGS2}"; CFG="${CONFIGS2:-c3}"; else SET="${SETTINGS}"; CFG="${CONFIGS:-c3}"; fi
+  : > $O/$w.log
+  for rep in 1 2; do
+   for setting in ${SET}; do
+    name="${setting%%|*}"; rest="${setting#*|}"; lib="${rest%%|*}"; extra="${rest#*|}"; extra="${extra//,/ }"
+    if [ "$lib" != "-" ]; then export FROSTING_LIB="$ROOTD/$lib"; else unset FROSTING_LIB; fi
+    for cfg in ${CFG}; do
+      timeout 600 python bench.py --config $cfg --steps ${STEPS:-40} --warmup 10 --no-cpu-baseline --no-extras $extra 2>> $O/$w.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%-10s %-3s %.4f ms/step | ' % ('$name', '$cfg', d['ms_per_step']) + ' '.join('%s %.3f' % (k, v) for k, v in d.get('stage_ms', {}).items()))" >> $O/$w.log
+    done
+   done
+  done
+  unset FROSTING_LIB
+  cat $O/$w.log ;;
+esac
+done
