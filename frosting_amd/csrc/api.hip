@@ -873,7 +873,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  char* workspace, size_t workspace_bytes, int debug, void* hip_stream,
-                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0, int phase = 0)
+                 const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0, int phase = 0,
+                 unsigned char* row_live = nullptr)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     // the arithmetic of this backward's blend pass: what the caller says (frg_backward_args::exact_blend), else what
@@ -926,6 +927,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     frg::BwdOutputs out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot};
     out.dL_dshell_logits = dL_dshell_logits;
     out.dL_dshell_verts = dL_dshell_verts;
+    out.row_live = row_live;
     const int pbw_flags = phase == 1 ? FRG_PBW_SUMS_ONLY : phase == 2 ? FRG_PBW_FROM_SUMS : 0;
     if (phase == 2) {     // the sums are in the workspace: one launch, no slot reduction, hence no 16-wave form either
         if (!phase1_matches(workspace, geom_buffer, image_buffer, P, R))
@@ -995,15 +997,17 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
 
 int frg_backward_ex(const frg_backward_args* a)
 {
-    const size_t b1 = offsetof(frg_backward_args, exact_blend), b2 = offsetof(frg_backward_args, phase);
-    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1 && a->struct_size != b2))
-        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu, %zu)", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_backward_args), b2, b1);
+    // four generations of the struct: up to shell_*, + exact_blend / shell_bary_mode, + phase, + row_live
+    const size_t b1 = offsetof(frg_backward_args, exact_blend), b2 = offsetof(frg_backward_args, phase), b3 = offsetof(frg_backward_args, row_live);
+    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1 && a->struct_size != b2 && a->struct_size != b3))
+        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu, %zu, %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_backward_args), b3, b2, b1);
     frg::RawInputs rw;
     rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
     rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
     int exact_mode = 0;
-    const int phase = a->struct_size == sizeof(frg_backward_args) ? a->phase : 0;
+    const int phase = a->struct_size >= b3 ? a->phase : 0;
+    unsigned char* row_live = a->struct_size == sizeof(frg_backward_args) ? a->row_live : nullptr;
     if (a->struct_size >= b2) {
         if (a->exact_blend < 0 || a->exact_blend > 2 || a->shell_bary_mode < 0 || a->shell_bary_mode > 1)
             return fail(FRG_EINVAL, "frg_backward_args: mode out of range (exact_blend %d, shell_bary_mode %d)", a->exact_blend, a->shell_bary_mode);
@@ -1015,7 +1019,7 @@ int frg_backward_ex(const frg_backward_args* a)
                          a->tan_fovx, a->tan_fovy, a->radii, a->geom_buffer, a->binning_buffer, a->image_buffer, a->dL_dpix,
                          a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh,
                          a->dL_dscale, a->dL_drot, a->workspace, a->workspace_bytes, a->debug, a->hip_stream, rw,
-                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode, phase);
+                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode, phase, row_live);
 }
 
 int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,
@@ -1067,6 +1071,8 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
     return FRG_OK;
 }
 
+static thread_local frg::AdamRows g_adam_rows;     // set by frg_adam_step_rows around its call of frg_adam_step
+
 int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                   const long long* segment_ends, const float* segment_lrs, const int* segment_period,
                   const int* segment_head, const float* segment_head_lrs, int n_segments,
@@ -1103,8 +1109,31 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
     const float omb2 = (float)(1.0 - beta2);    // as the Python floats of torch/optim/adam.py are
     const float inv_bc2_sqrt = 1.0f / (float)std::sqrt(bc2);   // ATen divides by a scalar as a multiplication by its float reciprocal
     FRG_HIP(frg::launch_adam_step(n, params, grads, exp_avg, exp_avg_sq, seg, w1, (float)beta2, omb2, inv_bc2_sqrt, (float)eps, grad_scale,
-                                  (hipStream_t)hip_stream));
+                                  (hipStream_t)hip_stream, g_adam_rows.live ? &g_adam_rows : nullptr));
     return FRG_OK;
+}
+
+int frg_adam_step_rows(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       const long long* segment_ends, const float* segment_lrs, const int* segment_period,
+                       const int* segment_head, const float* segment_head_lrs, int n_segments,
+                       double beta1, double beta2, double eps, int step, float grad_scale,
+                       const unsigned char* row_live, int P, const int* segment_width, void* hip_stream)
+{
+    if (!row_live) return frg_adam_step(n, params, grads, exp_avg, exp_avg_sq, segment_ends, segment_lrs, segment_period, segment_head,
+                                        segment_head_lrs, n_segments, beta1, beta2, eps, step, grad_scale, hip_stream);
+    if (P < 0 || !segment_width) return fail(FRG_EINVAL, "row_live needs P >= 0 and segment_width");
+    if (n_segments < 1 || n_segments > FRG_ADAM_MAX_SEGMENTS) return fail(FRG_EINVAL, "1..%d segments expected, got %d", FRG_ADAM_MAX_SEGMENTS, n_segments);
+    for (int k = 0; k < n_segments; k++) {
+        const long long begin = k ? segment_ends[k - 1] : 0;
+        if (segment_width[k] < 0 || (long long)segment_width[k] * P > segment_ends[k] - begin)
+            return fail(FRG_EINVAL, "segment %d: %d elements per Gaussian x %d Gaussians exceed its %lld elements", k, segment_width[k], P, segment_ends[k] - begin);
+    }
+    g_adam_rows.live = row_live; g_adam_rows.P = P;
+    for (int k = 0; k < FRG_ADAM_MAX_SEGMENTS; k++) g_adam_rows.width[k] = k < n_segments ? segment_width[k] : 0;
+    const int rc = frg_adam_step(n, params, grads, exp_avg, exp_avg_sq, segment_ends, segment_lrs, segment_period, segment_head,
+                                 segment_head_lrs, n_segments, beta1, beta2, eps, step, grad_scale, hip_stream);
+    g_adam_rows.live = nullptr;
+    return rc;
 }
 
 size_t frg_photometric_workspace_bytes(int channels, int width, int height)

@@ -60,6 +60,8 @@ struct BwdOutputs {
     // parameters; with shell-bound centres dL_dshell_logits [P,6] is written and, when non-NULL, dL_dshell_verts
     // [F,6,3] is ACCUMULATED into (caller zeroes it): the learnable shell of learn_shell = True
     float *dL_dshell_logits = nullptr, *dL_dshell_verts = nullptr;
+    // optional ([P] bytes): 1 = the Gaussian has a gradient in this view; the rows of the others are then NOT written
+    unsigned char* row_live = nullptr;
 };
 // heavy_only: false = every wave of 64 Gaussians that is not on GeomState::heavy_waves (the plain kernel), true = the
 // listed waves (the 16-wave form; any stream ordered after the blend backward).  flags:
@@ -96,9 +98,16 @@ struct AdamSegments {
     float head_step_size[FRG_ADAM_MAX_SEGMENTS];
     int count;
 };
+// row_live (optional, with width[k] = elements per Gaussian of segment k, 0 = not per-Gaussian, P Gaussians): the gradient
+// of an element whose Gaussian is unmarked is zero and is not read
+struct AdamRows {
+    const unsigned char* live = nullptr;
+    int P = 0;
+    int width[FRG_ADAM_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
 hipError_t launch_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,
-                            float grad_scale, hipStream_t s);
+                            float grad_scale, hipStream_t s, const AdamRows* rows = nullptr);
 
 // Frosting shell parameterisation of the centres (shell.hip)
 hipError_t launch_shell_points(int P, const float* logits, const float* cell_verts, const long long* cell, float* points,

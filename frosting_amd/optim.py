@@ -116,7 +116,10 @@ class FlatAdam:
             raise KeyError(name)
         self.lrs[name] = float(lr)
 
-    def step(self, flat_grads: torch.Tensor, grad_scale: float = 1.0):
+    def step(self, flat_grads: torch.Tensor, grad_scale: float = 1.0, row_live: torch.Tensor = None):
+        """row_live (optional, uint8 [P], as frg_backward_args::row_live leaves it): the gradient rows of unmarked Gaussians
+        were never written -- they count as zero and are not read (the moments decay, the parameter moves by its momentum:
+        what a stored zero gives, bit for bit).  Every group must then be per-Gaussian."""
         g = flat_grads
         if g.device.type != "cuda" or self.flat.device.type != "cuda":
             raise RuntimeError("FlatAdam runs on the GPU only (no CPU path)")
@@ -126,11 +129,22 @@ class FlatAdam:
         head_lrs = (C.c_float * len(self.names))(*[(self.sh_dc_lr if (k == "shs" and self.sh_dc_lr is not None) else 0.0)
                                                     for k in self.names])
         stream = C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
-        rc = _lib.lib().frg_adam_step(self.numel, C.c_void_p(self.flat.data_ptr()), C.c_void_p(g.data_ptr()),
-                                      C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
-                                      self._ends, lrs, self._period, self._head, head_lrs, len(self.names),
-                                      self.betas[0], self.betas[1], self.eps,
-                                      self.steps + 1, float(grad_scale), stream)
+        if row_live is not None:
+            P = self._per_gaussian()
+            if row_live.dtype != torch.uint8 or row_live.numel() != P or row_live.device != self.flat.device or not row_live.is_contiguous():
+                raise RuntimeError(f"row_live: expected a contiguous uint8 tensor of {P} entries on {self.flat.device}")
+            widths = (C.c_int * len(self.names))(*[int(torch.Size(self.shapes[k][1:]).numel()) for k in self.names])
+            rc = _lib.lib().frg_adam_step_rows(self.numel, C.c_void_p(self.flat.data_ptr()), C.c_void_p(g.data_ptr()),
+                                               C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                               self._ends, lrs, self._period, self._head, head_lrs, len(self.names),
+                                               self.betas[0], self.betas[1], self.eps, self.steps + 1, float(grad_scale),
+                                               C.c_void_p(row_live.data_ptr()), P, widths, stream)
+        else:
+            rc = _lib.lib().frg_adam_step(self.numel, C.c_void_p(self.flat.data_ptr()), C.c_void_p(g.data_ptr()),
+                                          C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                          self._ends, lrs, self._period, self._head, head_lrs, len(self.names),
+                                          self.betas[0], self.betas[1], self.eps,
+                                          self.steps + 1, float(grad_scale), stream)
         if rc < 0:
             raise RuntimeError(f"frg_adam_step failed ({rc}): {_lib.last_error()}")
         self.steps += 1                       # only a step that ran advances the bias correction

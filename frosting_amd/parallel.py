@@ -215,13 +215,16 @@ class GradientExchange:
             self.P = P
             self.row_packer = row_packer or _hip_row_packer
             self.row_scatterer = row_scatterer or _hip_row_scatterer
-            self.rows_own = torch.zeros((max(1024, P // 4), ROW_FLOATS), dtype=torch.float32, device=self.device)   # grows when a view needs more
-            self.count_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            # room for every Gaussian's row (64 B each: 192 MB at 3 M -- 288 GB of HBM per GPU): a view can never overflow it,
+            # and only the padded prefix the gathered counts call for travels
+            self.rows_own = torch.zeros((P + 256, ROW_FLOATS), dtype=torch.float32, device=self.device)
             self.header_own = torch.zeros(4, dtype=torch.float32, device=self.device)     # row count (int32 bit pattern), camera centre
+            self.count_dev = self.header_own[0:1].view(torch.int32)                       # (the pack kernel writes the count here)
+            self.own_campos = self.header_own[1:4]                                        # (the backward's payload step writes the centre here)
             self.headers = None                        # [world, 4]
             self.rows_all = None                       # [world, capacity, ROW_FLOATS], sized from the gathered counts
             self.counts = []                           # rows per view of the exchange in flight
-            self.sparse_stats = {"rows_own": 0, "rows_max": 0, "repacks": 0}
+            self.sparse_stats = {"rows_own": 0, "rows_max": 0}
 
     def set_sh_context(self, means3D: torch.Tensor, sh_degree: int):
         """Replicated inputs the SH rebuild needs (factored plan)."""
@@ -278,33 +281,29 @@ class GradientExchange:
         return self._works
 
     def _start_sparse(self):
-        """Pack this view's non-zero rows, all-gather the row counts (+ camera centres) -- the one host wait of the plan:
-        the counts size the padded all-gather of the rows -- and enqueue that all-gather."""
+        """Pack this view's non-zero rows (the kernel leaves their number in the header), all-gather the headers -- row
+        count + camera centre of every view -- and read them: the ONE host wait of the plan (the counts size the padded
+        all-gather of the rows; the zero fills the scatter needs are enqueued before it and run while the host waits).
+        Then the all-gather of the rows is enqueued."""
         import torch.distributed as dist
         world = dist.get_world_size(self.group)
-        while True:
-            self.row_packer(self)
-            n_own = int(self.count_dev.item())                   # host wait: the backward is complete, the rows are packed
-            if n_own <= self.rows_own.shape[0]:
-                break
-            self.rows_own = torch.zeros((int(n_own * 1.25) + 1024, ROW_FLOATS), dtype=torch.float32, device=self.device)
-            self.sparse_stats["repacks"] += 1
-        self.header_own[0:1].view(torch.int32).fill_(n_own)
-        self.header_own[1:4].copy_(self.own_campos)
+        rank = dist.get_rank(self.group)
         if self.headers is None or self.headers.shape[0] != world:
             self.headers = torch.zeros((world, 4), dtype=torch.float32, device=self.device)
+        if self.gathered is None or self.gathered.shape[0] != world:
+            self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
+        self.row_packer(self)                                    # rows_own, header_own[0] <- the count
         dist.all_gather_into_tensor(self.headers.view(-1), self.header_own, group=self.group)
-        self.counts = [int(c) for c in self.headers[:, 0].contiguous().view(torch.int32).tolist()]
+        self.dense.zero_()                                       # behind the pack (it reads the dense part), under the host's wait
+        self.gathered.zero_()
+        hdr = self.headers.cpu()                                 # host wait: backward, pack and the header gather are through
+        self.counts = [int(c) for c in hdr[:, 0].contiguous().view(torch.int32).tolist()]
         cap = (max(self.counts + [1]) + 255) // 256 * 256      # the same on every rank: it comes from the gathered counts
-        if self.rows_own.shape[0] < cap:
-            grown = torch.zeros((cap, ROW_FLOATS), dtype=torch.float32, device=self.device)
-            grown[: self.rows_own.shape[0]].copy_(self.rows_own)
-            self.rows_own = grown
         if self.rows_all is None or self.rows_all.shape[0] != world or self.rows_all.shape[1] < cap:
             self.rows_all = torch.zeros((world, int(cap * 1.25) // 256 * 256 + 256, ROW_FLOATS), dtype=torch.float32, device=self.device)
         self._rows_cap = cap
         self._rows_recv = self.rows_all.view(-1)[: world * cap * ROW_FLOATS]
-        self.sparse_stats.update(rows_own=n_own, rows_max=max(self.counts))
+        self.sparse_stats.update(rows_own=self.counts[rank], rows_max=max(self.counts))
         self._works.append(dist.all_gather_into_tensor(self._rows_recv, self.rows_own[:cap].reshape(-1), group=self.group, async_op=True))
         return self._works
 
@@ -312,14 +311,10 @@ class GradientExchange:
         """The dense part <- the views' rows added in view order into zeros; the dRGB of every view laid out densely for
         the SH rebuild; the rebuild."""
         world, cap = len(self.counts), self._rows_cap
-        if self.gathered is None or self.gathered.shape[0] != world:
-            self.gathered = torch.zeros((world, self.payload_numel), dtype=torch.float32, device=self.device)
-        self.dense.zero_()
-        self.gathered.zero_()
         P = self.P
         recv = self._rows_recv.view(world, cap, ROW_FLOATS)
+        self.gathered[:, 3 * P: 3 * P + 3].copy_(self.headers[:, 1:4])
         for v in range(world):                                # view order: the order of the single-process accumulation
-            self.gathered[v, 3 * P: 3 * P + 3].copy_(self.headers[v, 1:4])
             if self.counts[v]:
                 self.row_scatterer(self, recv[v], self.counts[v], self.gathered[v, : 3 * P])
         if self.means3D is None:
@@ -555,7 +550,7 @@ class ViewParallelRasterizer:
 
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
                  deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce",
-                 write_all_outputs: bool = True, raw_params: bool = False, sparse: bool = False):
+                 write_all_outputs: bool = True, raw_params: bool = False, sparse: bool = False, live_rows: bool = False):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
@@ -564,6 +559,10 @@ class ViewParallelRasterizer:
         # quaternion); the activations run inside the per-Gaussian kernels (frg_forward_ex / frg_backward_ex) and the
         # gradients written to the flat buffer are those of the raw parameters -- straight into the optimizer
         self.raw_params = raw_params
+        # live_rows: the backward marks the Gaussians with a gradient in self.row_live (uint8 [P]) and does NOT write the
+        # rows of the others (frg_backward_args::row_live) -- for a consumer that takes an unmarked row as zero without
+        # reading it (FlatAdam.step(row_live=...)).  Single-GPU training steps; not with an exchange (it sums whole buffers).
+        self.live_rows = live_rows
         self.deferred_counters = deferred_counters
         self.capacity_slack = capacity_slack
         self.capacity = 0            # instances the binning arena is sized for (deferred forwards)
@@ -592,6 +591,9 @@ class ViewParallelRasterizer:
         self.dL_dcov3D = f(P, 6) if write_all_outputs else None
         self.geom, self.binning, self.img, self.work = (_Arena(self.dev) for _ in range(4))
         self.radii = torch.empty(P, dtype=torch.int32, device=self.dev)
+        self.row_live = torch.zeros(P, dtype=torch.uint8, device=self.dev) if live_rows else None
+        if live_rows and process_group is not None:
+            raise ValueError("live_rows leaves the rows of Gaussians without a gradient unwritten: not with a gradient exchange")
         self.out_color = None
         self.num_rendered = 0
         self._view = None
@@ -696,7 +698,7 @@ class ViewParallelRasterizer:
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        if self.raw_params or phase:
+        if self.raw_params or phase or self.live_rows:
             v = lambda t: None if t is None else t.data_ptr()
             raw = self.raw_params
             a = _lib.BackwardArgs(
@@ -710,7 +712,7 @@ class ViewParallelRasterizer:
                 dL_dmean3D=v(g["means3D"]), dL_dcov3D=v(self.dL_dcov3D), dL_dsh=None if defer_sh else v(g["shs"]),
                 dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), workspace=v(work), workspace_bytes=work.numel(), debug=0,
                 hip_stream=stream.value, raw_opacities=v(s.opacities) if raw else None, raw_scales=v(s.scales) if raw else None,
-                raw_rotations=v(s.rotations) if raw else None, phase=int(phase))
+                raw_rotations=v(s.rotations) if raw else None, phase=int(phase), row_live=v(self.row_live))
             rc = L.frg_backward_ex(C.byref(a))
         else:
             rc = self._backward_plain(L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream)

@@ -231,6 +231,12 @@ typedef struct frg_backward_args {
      *   phase 2  everything else (the covariance / projection / SH chain and every other output), from those sums.
      * Same arguments and the same workspace in both calls; the two together write exactly what one call writes, bit for bit. */
     int phase;
+    /* fourth generation: row_live (optional, [P] bytes).  NULL: every row of every gradient output is written, zero or
+     * value (the reference's callers get that from their zero-fill, rasterize_points.cu:151-159).  Non-NULL: row_live[i] <- 1
+     * for the Gaussians with a gradient in this view, 0 for the others -- visible or not -- and the rows of those others are
+     * NOT written (at 3 M Gaussians six rows in seven are zeros: 0.74 of the 0.85 GB the backward writes).  A consumer that
+     * treats an unmarked row as zero without reading it (frg_adam_step_rows) gets exactly what the dense form gives. */
+    unsigned char* row_live;
 } frg_backward_args;
 int frg_backward_ex(const frg_backward_args* args);
 
@@ -416,6 +422,17 @@ int frg_activate(int P, const float* raw_opacity, const float* raw_scale, const 
                  float* opacity, float* scale, float* rot, void* hip_stream);
 int frg_activate_backward(int P, const float* opacity, const float* scale, const float* raw_rot,
                           float* g_opacity, float* g_scale, float* g_rot, void* hip_stream);
+
+/* frg_adam_step with a row mask: row_live[P] as frg_backward_args::row_live leaves it, segment_width[k] = elements per
+ * Gaussian of segment k (0: the segment is not per-Gaussian -- its gradients are always read).  The gradient of an
+ * element whose Gaussian is unmarked is taken as zero WITHOUT being read (the moments still decay and the parameter still
+ * moves by its momentum: the reference's dense semantics); everything else as frg_adam_step.  Bit-identical to
+ * frg_adam_step on the dense gradient. */
+int frg_adam_step_rows(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       const long long* segment_ends, const float* segment_lrs, const int* segment_period,
+                       const int* segment_head, const float* segment_head_lrs, int n_segments,
+                       double beta1, double beta2, double eps, int step, float grad_scale,
+                       const unsigned char* row_live, int P, const int* segment_width, void* hip_stream);
 
 /* ---- fused photometric loss (forward + backward) ----------------------------------------
  * SURVEY.md 8(f) rank 2, the step right before the rasterizer's backward.  Replaces

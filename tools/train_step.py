@@ -9,7 +9,9 @@ in FlatAdam's flat buffer.  Prints the time of each part and of the whole step, 
   launch  one HIP launch for the three activations, one for their backward (frosting_amd/activations.py);
   fused   the activations evaluated inside the per-Gaussian kernels (ViewParallelRasterizer(raw_params=True) ->
           frg_forward_ex / frg_backward_ex on the raw parameters, gradients w.r.t. the raw parameters straight into the
-          optimizer's buffer, no activated tensor in memory)."""
+          optimizer's buffer, no activated tensor in memory);
+  rows    fused + the backward leaves the rows of Gaussians WITHOUT a gradient unwritten and marks the others
+          (frg_backward_args::row_live: six rows in seven at C3), Adam takes an unmarked row as zero without reading it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -51,6 +53,7 @@ target = (img + 0.05 * torch.randn_like(img)).clamp(0, 1)
 raw_scene = scenes.Scene(opt.params["means3D"], opt.params["scales"], opt.params["rotations"], opt.params["opacities"],
                          opt.params["shs"], scene.sh_degree)
 vpr_raw = ViewParallelRasterizer(raw_scene, dev, raw_params=True)
+vpr_rows = ViewParallelRasterizer(raw_scene, dev, raw_params=True, live_rows=True)
 
 
 # eager: torch leaves aliasing the optimizer's buffers, activated copies kept by autograd
@@ -81,6 +84,12 @@ def step(raw):
         activations_backward_eager(g)
         opt.step(vpr.exchange.flat)
         return loss
+    if raw == "rows":
+        image, _ = vpr_rows.forward(cam_d, bg_d)
+        loss, dimg = photometric_loss_and_grad(image, target)
+        vpr_rows.backward(dimg, 0)
+        opt.step(vpr_rows.exchange.flat, row_live=vpr_rows.row_live)
+        return loss
     if raw:
         image, _ = vpr_raw.forward(cam_d, bg_d)
         loss, dimg = photometric_loss_and_grad(image, target)
@@ -99,7 +108,8 @@ def step(raw):
 # every variant starts from the SAME model and optimizer state: 48 Adam steps towards the noisy target change the scene
 # (round 3 timed the variants one after the other on the drifting model: its "fused is 0.17 ms slower" was partly that)
 snapshot = (opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.steps)
-for raw in ("eager", False, True):
+final = {}
+for raw in ("eager", False, True, "rows"):
     opt.flat.copy_(snapshot[0]); opt.exp_avg.copy_(snapshot[1]); opt.exp_avg_sq.copy_(snapshot[2]); opt.steps = snapshot[3]
     for _ in range(8):
         step(raw)
@@ -115,6 +125,11 @@ for raw in ("eager", False, True):
             ev[3].record(); g = vpr.backward(dimg, 0)
             ev[4].record(); activations_backward_eager(g)
             ev[5].record(); opt.step(vpr.exchange.flat)
+        elif raw == "rows":
+            ev[0].record(); ev[1].record(); image, _ = vpr_rows.forward(cam_d, bg_d)
+            ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
+            ev[3].record(); vpr_rows.backward(dimg, 0)
+            ev[4].record(); ev[5].record(); opt.step(vpr_rows.exchange.flat, row_live=vpr_rows.row_live)
         elif raw:
             ev[0].record(); ev[1].record(); image, _ = vpr_raw.forward(cam_d, bg_d)
             ev[2].record(); loss, dimg = photometric_loss_and_grad(image, target)
@@ -136,8 +151,12 @@ for raw in ("eager", False, True):
         step(raw)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / n
+    final[raw] = opt.flat.clone()
     what = ("EAGER torch activations + autograd around the rasterizer (the reference's chain)" if raw == "eager" else
+            "raw parameters, rows of Gaussians without a gradient neither written nor read (row_live)" if raw == "rows" else
             "raw parameters into the rasterizer (activations inside the per-Gaussian kernels)" if raw else "activation launches around the rasterizer")
     print(f"C3 native training step, P={scene.P}, {what}: activations {acc[0]/n:.3f} ms, forward {acc[1]/n:.3f} ms, loss fwd+bwd "
           f"{acc[2]/n:.3f} ms, backward {acc[3]/n:.3f} ms, activations backward {acc[4]/n:.3f} ms, Adam {acc[5]/n:.3f} ms")
     print(f"    whole step {1e3*t:.3f} ms = {1/t:.0f} steps/s (loss {losses[0]:.5f} -> {losses[-1]:.5f} over {n} steps of the same view)")
+print(f"parameters after the 48 steps, rows of Gaussians without gradient unwritten vs the dense fused path: "
+      f"{'bit-identical' if torch.equal(final[True], final['rows']) else 'DIFFERENT'}")
