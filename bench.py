@@ -138,7 +138,7 @@ def pmc_traffic(stage: str, cfg_name: str, P: int):
     if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"]:
         return None
     mine = _lib.build_fingerprint()["kernel_sources_sha256"]
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         try:
             doc = json.load(open(path))
@@ -150,6 +150,46 @@ def pmc_traffic(stage: str, cfg_name: str, P: int):
         if stage == "*":      # the whole op: every stage of one view
             return {"bytes": sum(v["hbm_bytes_corrected"] for v in per.values()), "source": f"profiles/{rnd}_pmc_traffic.json"}
         return per[stage]["hbm_bytes_corrected"]
+    return None
+
+
+# what one wave-instruction costs a SIMD: tools/micro/pk_rate.hip on this GPU (2048 workgroups x 256 threads of independent
+# chains): a plain f32 VALU op 2.8 cycles at the 2.4 GHz the tool assumes (v_exp / v_rcp ~10, v_add_f32_dpp ~7 -- a kernel's
+# mix costs more than this floor)
+VALU_CYCLES_PER_WAVE_INSTR = 2.8
+SIMDS = 256 * 4
+CLOCK_HZ = 2.4e9
+STAGE_KERNELS = {"preprocess": ("preprocess_fwd_kernel",), "scan": ("colsum_kernel", "reorder_kernel"), "scatter": ("scatter_rows_kernel",),
+                 "sort": ("sort_tiles_lds_kernel",), "blend_fwd": ("blend_fwd_kernel",), "blend_bwd": ("blend_bwd_kernel",),
+                 "preprocess_bwd": ("preprocess_bwd_kernel",)}
+
+
+def pmc_valu(stage: str, cfg_name: str, P: int, launch_ms: float):
+    """The compute side of the dominant kernel's roofline: vector wave-instructions per launch from the committed SQ counter
+    passes (profiles/r0N_pmc_sq.json, same staleness rule as pmc_traffic) -> the time the chip's 1024 SIMDs need to ISSUE them
+    at the measured cost of a plain f32 VALU op, and which share of the kernel's launch that is.  A kernel near 1 is bound by
+    instruction issue, whatever its HBM fraction says."""
+    from frosting_amd import _lib, scenes
+    if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"] or stage not in STAGE_KERNELS:
+        return None
+    mine = _lib.build_fingerprint()["kernel_sources_sha256"]
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_sq.json")
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        if doc.get("build", {}).get("kernel_sources_sha256") != mine:
+            return "stale"
+        ks = [v for k, v in doc["kernels"].items() if any(n in k for n in STAGE_KERNELS[stage])]
+        if not ks:
+            return None
+        insts = sum(v.get("SQ_INSTS_VALU", 0) for v in ks)
+        floor_ms = 1e3 * insts * VALU_CYCLES_PER_WAVE_INSTR / SIMDS / CLOCK_HZ
+        return {"wave_instr": insts, "cycles_per_instr": VALU_CYCLES_PER_WAVE_INSTR, "simds": SIMDS, "clock_GHz": CLOCK_HZ / 1e9,
+                "issue_floor_ms": floor_ms, "issue_frac": floor_ms / launch_ms if launch_ms else None,
+                "lds_bank_conflict_cycles": sum(v.get("SQ_LDS_BANK_CONFLICT", 0) for v in ks),
+                "source": f"profiles/{rnd}_pmc_sq.json (SQ_INSTS_VALU per launch) x tools/micro/pk_rate.hip (cycles per plain f32 wave-instruction)"}
     return None
 
 
@@ -210,39 +250,46 @@ def cpu_baseline(cfg_name: str, P: int, backward: bool = True, torch_budget_s: f
         return port
 
 
-def reference_on_this_gpu(scene_d, cam_d, bg_d, gpix, backward: bool, iters: int = 5):
+def reference_on_this_gpu(scene_d, cam_d, bg_d, gpix, backward: bool, iters: int = 20, warm: int = 5, keep=None):
     """The reference's own rasterizer (oracle/_ref fast build = hipcc defaults, compiled from /root/reference by
-    oracle/build_ref.sh) on the same tensors: 'the reference on MI355X' beside ours.  Baseline leg only."""
+    oracle/build_ref.sh) on the same tensors: 'the reference on MI355X' beside ours.  Baseline leg only.
+    SURVEY 8(d)'s protocol: `warm` untimed + `iters` timed iterations, torch.cuda.Event around the forward and around the
+    backward (the reference launches on the legacy default stream, which is torch's current stream here), median.
+    keep (bool [P], C4): the reference has no skip flag -- Frosting compacts its five parameter tensors with the occlusion
+    mask in front of every render (frosting_model.py:1564-1586); that compaction is timed with the forward."""
     import torch
     from oracle import ref_rasterizer as REF
     if not REF.available("fast"):
         return None
-    kw = dict(means3D=scene_d.means3D, opacities=scene_d.opacities, viewmatrix=cam_d.viewmatrix, projmatrix=cam_d.projmatrix,
-              campos=cam_d.campos, bg=bg_d, width=cam_d.image_width, height=cam_d.image_height, tanfovx=cam_d.tanfovx,
-              tanfovy=cam_d.tanfovy, shs=scene_d.shs, scales=scene_d.scales, rotations=scene_d.rotations,
-              sh_degree=scene_d.sh_degree, variant="fast")
+    cam = dict(viewmatrix=cam_d.viewmatrix, projmatrix=cam_d.projmatrix, campos=cam_d.campos, bg=bg_d, width=cam_d.image_width,
+               height=cam_d.image_height, tanfovx=cam_d.tanfovx, tanfovy=cam_d.tanfovy, sh_degree=scene_d.sh_degree, variant="fast")
+
+    def inputs():
+        t = dict(means3D=scene_d.means3D, opacities=scene_d.opacities, shs=scene_d.shs, scales=scene_d.scales, rotations=scene_d.rotations)
+        return t if keep is None else {k: v[keep] for k, v in t.items()}
+
     fw, bw = [], []
-    for it in range(iters + 1):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        R, _, _, st = REF.forward(**kw)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for it in range(warm + iters):
+        ev[0].record()
+        R, _, _, st = REF.forward(**inputs(), **cam)
+        ev[1].record()
         if backward:
             REF.backward(st, gpix)
-            torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        if it:   # first iteration: module load
-            fw.append(1e3 * (t1 - t0))
-            bw.append(1e3 * (t2 - t1))
+        ev[2].record()
+        torch.cuda.synchronize()
+        if it >= warm:
+            fw.append(ev[0].elapsed_time(ev[1]))
+            bw.append(ev[1].elapsed_time(ev[2]))
     return {"forward_ms": statistics.median(fw), "backward_ms": statistics.median(bw) if backward else None,
-            "ms_per_step": statistics.median(fw) + (statistics.median(bw) if backward else 0.0),
-            "note": "the reference's own CUDA sources built for gfx950 with hipcc (oracle/_ref, fast variant), host wall "
-                    "clock per call incl. its allocations and the zero-fill of its gradient outputs, median of "
-                    f"{iters}"}
+            "ms_per_step": statistics.median(fw) + (statistics.median(bw) if backward else 0.0), "num_rendered": int(R),
+            "note": "the reference's own CUDA sources built for gfx950 with hipcc (oracle/_ref, fast variant): "
+                    f"{warm} warm-up + {iters} timed iterations, torch.cuda.Event around forward and backward, median "
+                    "(incl. its allocations and the zero-fill of its gradient outputs" +
+                    ("; forward incl. the five boolean compactions by the occlusion mask" if keep is not None else "") + ")"}
 
 
-def side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, steps: int = 20):
+def side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, steps: int = 20, with_reference: bool = False):
     """One of the other BASELINE configs on this GPU: ms per step over `steps` steps (wall clock between two
     synchronisations) and the fraction of the 8 TB/s roofline of ITS algorithmic bytes (C4 adds the
     triangle raster's 12 bytes per vertex of every face and 16 bytes per pixel, and the 9 bytes per Gaussian of the
@@ -308,6 +355,15 @@ def side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, steps
         out["mesh_raster_note"] = "triangle raster + visible-face mask + per-Gaussian keep flag (the cull_mask() part of the step), timed on its own"
     out["algorithmic_bytes_per_view"] = B
     out["frac"] = B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if with_reference:      # ours beside the reference's own code on this GPU, for every config
+        try:
+            keep = mask()
+            ref = reference_on_this_gpu(scene.to(dev), cam_d, bg_d, g, backward, keep=None if keep is None else keep.bool())
+            if ref:
+                out["reference_on_mi355x"] = ref
+                out["speedup_vs_reference"] = ref["ms_per_step"] / ms
+        except Exception as ex:     # informative: never lose our number over it
+            out["reference_on_mi355x"] = {"error": repr(ex)}
     return out
 
 
@@ -665,7 +721,7 @@ def main():
     if single and extras and args.config == "c3" and not args.points:
         for name in ("c2", "c4"):
             try:
-                side[name] = side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib)
+                side[name] = side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, with_reference=True)
             except Exception as ex:
                 side[name] = {"error": repr(ex)}
 
@@ -769,7 +825,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.config, P),
                                "algorithmic_bytes_per_launch": B[dom], "avg_launch_ms": dom_ms,
-                               "timed": "hipEvents around this kernel in every timed step"}
+                               "timed": "hipEvents around this kernel in every timed step",
+                               "valu": pmc_valu(dom, args.config, P, dom_ms)}
             out["roofline"]["build"] = _lib.build_fingerprint()
             out["stage_ms"] = stage_avg
             out["stage_ms_note"] = "all stages, 5 extra steps after the timed region"

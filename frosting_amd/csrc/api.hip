@@ -1127,9 +1127,14 @@ int frg_adam_step_rows(long long n, float* params, const float* grads, float* ex
         const long long begin = k ? segment_ends[k - 1] : 0;
         if (segment_width[k] < 0 || (long long)segment_width[k] * P > segment_ends[k] - begin)
             return fail(FRG_EINVAL, "segment %d: %d elements per Gaussian x %d Gaussians exceed its %lld elements", k, segment_width[k], P, segment_ends[k] - begin);
+        if (segment_width[k] > 0 && segment_ends[k] - begin > 0xffffffffLL)
+            return fail(FRG_EINVAL, "segment %d: a per-Gaussian segment of a masked step holds at most 2^32 elements", k);
     }
     g_adam_rows.live = row_live; g_adam_rows.P = P;
-    for (int k = 0; k < FRG_ADAM_MAX_SEGMENTS; k++) g_adam_rows.width[k] = k < n_segments ? segment_width[k] : 0;
+    for (int k = 0; k < FRG_ADAM_MAX_SEGMENTS; k++) {
+        g_adam_rows.width[k] = k < n_segments ? segment_width[k] : 0;
+        g_adam_rows.magic[k] = g_adam_rows.width[k] > 1 ? (unsigned int)(0x100000000ull / (unsigned long long)g_adam_rows.width[k]) : 0u;
+    }
     const int rc = frg_adam_step(n, params, grads, exp_avg, exp_avg_sq, segment_ends, segment_lrs, segment_period, segment_head,
                                  segment_head_lrs, n_segments, beta1, beta2, eps, step, grad_scale, hip_stream);
     g_adam_rows.live = nullptr;

@@ -104,6 +104,7 @@ struct AdamRows {
     const unsigned char* live = nullptr;
     int P = 0;
     int width[FRG_ADAM_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int magic[FRG_ADAM_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // floor(2^32 / width): offset / width without a division
 };
 hipError_t launch_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                             const AdamSegments& seg, float w1, float beta2, float omb2, float inv_bc2_sqrt, float eps,

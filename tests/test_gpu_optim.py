@@ -158,13 +158,13 @@ def test_live_rows_training_steps_equal_the_dense_path(gpu_device):
     """frg_backward_args::row_live + frg_adam_step_rows (VERDICT r04, next 7): the backward marks the Gaussians with a gradient
     and leaves the rows of the others UNWRITTEN (the gradient buffer is poisoned with NaN before every step to prove it); Adam
     takes an unmarked row as zero without reading it.  Twenty native training steps (raw parameters into the rasterizer,
-    fused loss, fused Adam) on a saturating frame -- more than a third of the visible Gaussians without gradient -- leave
+    fused loss, fused Adam) on a saturating frame (1 M Gaussians on the C3 image: about half of the visible ones without gradient) leave
     parameters and both moments bit-identical to the dense path's."""
     from frosting_amd import scenes
     from frosting_amd.loss import photometric_loss_and_grad
     from frosting_amd.parallel import ViewParallelRasterizer
     dev = gpu_device
-    scene, cam, bg = scenes.config_scene("c2", 1, P=400_000)
+    scene, cam, bg = scenes.config_scene("c3", 1, P=1_000_000)
     shapes = {k: tuple(getattr(scene, k).shape) for k in PARAM_ORDER}
     lrs = dict(means3D=1.6e-5, scales=5e-3, rotations=1e-3, opacities=5e-2, shs=2.5e-3)
     cam_d, bg_d = cam.to(dev), bg.to(dev)
@@ -195,7 +195,7 @@ def test_live_rows_training_steps_equal_the_dense_path(gpu_device):
             opt.step(vpr.exchange.flat, row_live=vpr.row_live)
         torch.cuda.synchronize(dev)
         if live_rows:
-            assert 0.05 < min(fractions) and max(fractions) < 0.67, fractions       # a saturating frame: many visible Gaussians are never reached
+            assert 0.2 < min(fractions) and max(fractions) < 0.8, fractions         # a saturating frame: many visible Gaussians are never reached
         results.append((opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
     for a, b in zip(*results):
         assert bool(torch.isfinite(b).all())
