@@ -1041,6 +1041,48 @@ def test_reached_marks_prune_work_not_results(gpu_device):
     assert int(((stv().flag_words >> 8) & 0xFF).ne(0).sum()) == 0
 
 
+def test_two_backwards_of_one_forward_on_two_streams(gpu_device):
+    """frg_backward WRITES one byte of the geometry buffer per reached Gaussian (the marks; the reference's callers never
+    had to know).  Two backwards of the SAME forward state -- what retain_graph + a second .backward() does -- issued from
+    two host threads on two streams at once, the marks starting cleared: both store the same byte values into words the
+    other one is reading with 16-byte loads, and a load sees the mark or does not -- which only decides whether the byte is
+    stored again.  Every backward sets all of its marks in its own blend pass, before its own per-Gaussian pass reads them
+    (stream order), and its slots live in its own workspace: each call reproduces the lone backward bit for bit."""
+    import threading
+    from frosting_amd.introspect import State
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("c3", 1, P=1_000_000)
+    out, args = Hh.run_ours_native(scene, cam, bg, dev)
+    st = State(scene.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
+    grads = [scenes.l1_target_grad(out[1].cpu(), 60 + k)[0].to(dev) for k in range(2)]
+    lone = [[g.clone() for g in _C.rasterize_gaussians_backward(*_bwd_args(args, out, gp))] for gp in grads]
+    torch.cuda.synchronize(dev)
+    for trial in range(3):
+        st.flag_words.bitwise_and_(0xFF)                    # marks cleared: both backwards set them while the other reads
+        torch.cuda.synchronize(dev)
+        streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        got, errs = [None, None], []
+        go = threading.Barrier(2)
+
+        def run(k):
+            try:
+                with torch.cuda.stream(streams[k]):
+                    go.wait()
+                    got[k] = [g.clone() for g in _C.rasterize_gaussians_backward(*_bwd_args(args, out, grads[k]))]
+                streams[k].synchronize()
+            except Exception as ex:       # noqa: BLE001
+                errs.append(ex)
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for k in range(2):
+            assert all(torch.equal(x, y) for x, y in zip(lone[k], got[k])), (trial, k)
+
+
 _HEAVY_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})

@@ -31,10 +31,12 @@ prof)
 ab)
   FROSTING_EXPERIMENTS=1 timeout 900 python tools/ab.py ${AB_ARGS:-} > $O/ab.log 2>&1; echo "ab rc=$?" >> $O/ab.log; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/ab.log | tail -40 ;;
 trace)
-  # kernel timeline of one step of ${TRACE_CFG:-c2} (gaps between launches): rocprofv3 kernel trace, no counters
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace" -- python "$ROOTD/bench.py" --config ${TRACE_CFG:-c2} --steps 30 --warmup 5 --spinup-steps 50 --views 1 --no-cpu-baseline --no-extras --no-stage-timers ${TRACE_ARGS:-} > "$O/trace_bench.json" 2> "$O/trace.err")
-  f=$(find $O/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py "$f" > $O/trace_${TRACE_CFG:-c2}.log 2>&1; cat $O/trace_${TRACE_CFG:-c2}.log | tail -40
-  rm -rf $O/trace ;;
+  # kernel timeline of one step of each of ${TRACE_CFGS:-c2} (gaps between launches): rocprofv3 kernel trace, no counters
+  for tc in ${TRACE_CFGS:-${TRACE_CFG:-c2}}; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace" -- python "$ROOTD/bench.py" --config $tc --steps 30 --warmup 5 --spinup-steps 50 --views 1 --no-cpu-baseline --no-extras --no-stage-timers ${TRACE_ARGS:-} > "$O/trace_bench.json" 2> "$O/trace.err")
+    f=$(find $O/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py "$f" > $O/trace_$tc.log 2>&1; cat $O/trace_$tc.log | tail -40
+    rm -rf $O/trace
+  done ;;
 train)
   timeout 600 python tools/train_step.py > $O/train_step.log 2>&1; tail -6 $O/train_step.log ;;
 exchange)
