@@ -1002,9 +1002,14 @@ scatter_rows_kernel(int T, int gx, int gy, const uint4* __restrict__ row_records
     // Every workgroup takes one contiguous share of the records, a multiple of 1024 (a few cells: some dozens of
     // tiles), and reserves ONE run per touched tile.  Workgroup b runs on XCD b % 8: XCD x takes the shares
     // [x * per_xcd, (x + 1) * per_xcd), so that a tile's pairs are written through one L2.
+    // (The grid is sized on the host, which does not know the number of records: the shares are cut HERE, and dealt to the
+    // XCDs evenly whatever the grid -- with gridDim / 8 shares per XCD a grid a quarter too large left two XCDs idle:
+    // 0.093 instead of 0.083 ms at C3.)
     const uint32_t nvis = counters->num_visible;
-    const uint32_t per_xcd = gridDim.x / FRG_NUM_XCD;
     const uint32_t share = ((nvis + gridDim.x - 1) / gridDim.x + FRG_BIN_THREADS - 1) / FRG_BIN_THREADS * FRG_BIN_THREADS;
+    const uint32_t nshares = share ? (nvis + share - 1) / share : 0u;
+    const uint32_t per_xcd = (nshares + FRG_NUM_XCD - 1) / FRG_NUM_XCD;
+    if (blockIdx.x / FRG_NUM_XCD >= per_xcd) return;        // workgroup-uniform: the grid has more workgroups than there are shares
     const uint32_t first = ((blockIdx.x % FRG_NUM_XCD) * per_xcd + blockIdx.x / FRG_NUM_XCD) * share;
     if (first >= nvis) return;                       // workgroup-uniform
     const uint32_t last = min(nvis, first + share);
@@ -1213,7 +1218,9 @@ hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const G
         // ... and fewer for small models: a share's fixed costs (its LDS difference array over the tiles, one reserved run
         // per touched tile) do not shrink with it -- C2 (100 k Gaussians, 70 k records), same box: 512 workgroups 19 us,
         // 256 16, 128 15, 64 18
-        const int by_size = std::min(512, std::max(64, P / 768));
+        // ... and more than two per CU for the large ones (r05, shares dealt evenly to the XCDs whatever the grid; same box, scatter
+        // stage at C3 / C4): 512 workgroups 0.088 / 0.098 ms, 640 0.081 / 0.098, 768 0.080 / 0.089, 1024 0.081 / 0.089, 1536 0.078 / 0.089
+        const int by_size = std::min(1024, std::max(64, P / 768));
         const int grid = ((std::max(need, g_rows_grid > 0 ? g_rows_grid : by_size) + FRG_NUM_XCD - 1) / FRG_NUM_XCD) * FRG_NUM_XCD;
         hipError_t e = allow_big_lds(scatter_rows_kernel, lds);
         if (e != hipSuccess) return e;
