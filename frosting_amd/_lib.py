@@ -190,6 +190,10 @@ def lib():
     L.frg_sh_color_grad.argtypes = [i, vp, vp, vp, vp, vp]
     L.frg_sh_grad_from_views.restype = i
     L.frg_sh_grad_from_views.argtypes = [i, i, i, i, vp, vp, C.c_longlong, vp, C.c_longlong, vp, vp]
+    L.frg_adam_step_shard.restype = i
+    L.frg_adam_step_shard.argtypes = [C.c_longlong, C.c_longlong, vp, vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), i,
+                                      C.c_double, C.c_double, C.c_double, i, f, vp]
     L.frg_adam_step_rows.restype = i
     L.frg_adam_step_rows.argtypes = [C.c_longlong, vp, vp, vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_float),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), i,
@@ -245,7 +249,7 @@ EXPORTED_SYMBOLS = [
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_geometry_layout_n", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_mesh_visible_faces", "frg_sh_color_grad", "frg_sh_grad_from_views",
-    "frg_pack_grad_rows", "frg_scatter_grad_rows", "frg_adam_step_rows",
+    "frg_pack_grad_rows", "frg_scatter_grad_rows", "frg_adam_step_rows", "frg_adam_step_shard",
     "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_backward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",
     "frg_knn_workspace_bytes", "frg_knn_mean_dist2", "frg_shell_points", "frg_shell_points_backward",

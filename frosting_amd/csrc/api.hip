@@ -1072,6 +1072,7 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
 }
 
 static thread_local frg::AdamRows g_adam_rows;     // set by frg_adam_step_rows around its call of frg_adam_step
+static thread_local bool g_adam_shard = false;     // frg_adam_step_shard: segment ends before the first element (negative) are expected
 
 int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                   const long long* segment_ends, const float* segment_lrs, const int* segment_period,
@@ -1083,7 +1084,7 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
         return fail(FRG_EINVAL, "1..%d segments expected, got %d", FRG_ADAM_MAX_SEGMENTS, n_segments);
     for (int k = 1; k < n_segments; k++)
         if (segment_ends[k] < segment_ends[k - 1]) return fail(FRG_EINVAL, "segment ends must not decrease");
-    if (segment_ends[0] < 0 || segment_ends[n_segments - 1] != n) return fail(FRG_EINVAL, "the last segment must end at n");
+    if ((segment_ends[0] < 0 && !g_adam_shard) || segment_ends[n_segments - 1] != n) return fail(FRG_EINVAL, "the last segment must end at n");
     if (n == 0) return FRG_OK;
     if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(FRG_EINVAL, "null pointer");
     if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
@@ -1111,6 +1112,39 @@ int frg_adam_step(long long n, float* params, const float* grads, float* exp_avg
     FRG_HIP(frg::launch_adam_step(n, params, grads, exp_avg, exp_avg_sq, seg, w1, (float)beta2, omb2, inv_bc2_sqrt, (float)eps, grad_scale,
                                   (hipStream_t)hip_stream, g_adam_rows.live ? &g_adam_rows : nullptr));
     return FRG_OK;
+}
+
+int frg_adam_step_shard(long long n, long long first, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                        const long long* segment_ends, const float* segment_lrs, const int* segment_period,
+                        const int* segment_head, const float* segment_head_lrs, int n_segments,
+                        double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream)
+{
+    // elements [first, first + n) of the flat layout, the four arrays pointing at element `first`: the segment table is
+    // shifted by `first` behind a zero-length segment that ends at -first -- the kernel takes an element's segment as the last
+    // one whose predecessor ends at or before it and its offset from that end, so negative ends give every element of the
+    // shard its true segment and its true phase inside it (the DC / rest split of the SH rows)
+    if (n < 0 || first < 0 || first % 4 != 0) return fail(FRG_EINVAL, "bad shard: n=%lld first=%lld (a multiple of 4 elements)", n, first);
+    if (n_segments < 1 || n_segments + 1 > FRG_ADAM_MAX_SEGMENTS || !segment_ends || !segment_lrs)
+        return fail(FRG_EINVAL, "a sharded step takes 1..%d segments, got %d", FRG_ADAM_MAX_SEGMENTS - 1, n_segments);
+    if (first + n > segment_ends[n_segments - 1]) return fail(FRG_EINVAL, "the shard ends behind the last segment");
+    long long ends[FRG_ADAM_MAX_SEGMENTS];
+    float lrs[FRG_ADAM_MAX_SEGMENTS], hlrs[FRG_ADAM_MAX_SEGMENTS];
+    int per[FRG_ADAM_MAX_SEGMENTS], head[FRG_ADAM_MAX_SEGMENTS];
+    ends[0] = -first; lrs[0] = 0.0f; hlrs[0] = 0.0f; per[0] = 0; head[0] = 0;
+    for (int k = 0; k < n_segments; k++) {
+        ends[k + 1] = segment_ends[k] - first;
+        lrs[k + 1] = segment_lrs[k];
+        per[k + 1] = segment_period ? segment_period[k] : 0;
+        head[k + 1] = segment_head ? segment_head[k] : 0;
+        hlrs[k + 1] = segment_head_lrs ? segment_head_lrs[k] : 0.0f;
+    }
+    ends[n_segments] = n;       // the shard ends inside (or at the end of) the last segment it reaches; later ones are cut off
+    for (int k = 1; k <= n_segments; k++) if (ends[k] > n) ends[k] = n;
+    g_adam_shard = true;
+    const int rc = frg_adam_step(n, params, grads, exp_avg, exp_avg_sq, ends, lrs, per, head, hlrs, n_segments + 1, beta1, beta2, eps, step,
+                                 grad_scale, hip_stream);
+    g_adam_shard = false;
+    return rc;
 }
 
 int frg_adam_step_rows(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

@@ -149,3 +149,93 @@ class FlatAdam:
             raise RuntimeError(f"frg_adam_step failed ({rc}): {_lib.last_error()}")
         self.steps += 1                       # only a step that ran advances the bias correction
         return self.params
+
+
+class ShardedFlatAdam(FlatAdam):
+    """SURVEY.md 8(e), second option: instead of an all-reduce of the gradients and a replicated update, the gradients are
+    REDUCE-SCATTERED, every rank updates its 1/N shard of the flat parameter buffer (both moments exist only for the
+    shard), and the updated shards are ALL-GATHERED: the same wire bytes as the all-reduce's two halves, a 1/N Adam
+    (0.8 ms of a 2.4 ms training step at C3).  ``step(flat_grads)`` takes THIS rank's (per-view) gradient buffer; the
+    parameters it leaves in ``self.params`` are those of FlatAdam.step on the sum over ranks, bit for bit (the sum of a
+    shard is taken in rank order on backends without a reduce-scatter).
+
+    Whether it pays depends on the node: the parameter all-gather moves (N-1)/N x 708 MB at 3 M Gaussians -- 0.58 ms at the
+    nominal 7 x 153 GB/s, 1.4 ms at 450 GB/s -- against the 0.7 ms it takes off the replicated update
+    (frosting_amd.parallel.predict_exchange reports both)."""
+
+    def __init__(self, shapes: dict, lrs: dict, device, process_group, betas=(0.9, 0.999), eps: float = 1e-15, sh_dc_lr=None,
+                 shard_step=None):
+        import torch.distributed as dist
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self._shard_step = shard_step           # tests on CPU tensors inject the update of one shard (the product one is HIP-only)
+        super().__init__(shapes, lrs, device, betas=betas, eps=eps, sh_dc_lr=sh_dc_lr)
+
+    def _build(self, shapes: dict, old=None):
+        if old is not None:
+            raise RuntimeError("ShardedFlatAdam: prune / append re-shard the moments -- not implemented; rebuild the optimizer")
+        names = self.names
+        self.shapes = shapes
+        _, self.layout, self.numel = flat_layout(shapes, names)
+        # shards of equal length, a multiple of four elements (16-byte accesses); the flat buffers are padded to N shards
+        self.shard = ((self.numel + self.world - 1) // self.world + 3) // 4 * 4
+        padded = self.shard * self.world
+        self.flat_padded = torch.zeros(padded, dtype=torch.float32, device=self.device)
+        self.flat = self.flat_padded[: self.numel]
+        self.exp_avg = torch.zeros(self.shard, dtype=torch.float32, device=self.device)        # this rank's shard only
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.params = {k: self.flat[o:o + n].view(shapes[k]) for k, (o, n) in self.layout.items()}
+        ends = [self.layout[names[i + 1]][0] if i + 1 < len(names) else self.numel for i in range(len(names))]
+        ends[-1] = padded                                  # the pad behind the last segment rides with it (zeros: never moves)
+        self._ends = (C.c_longlong * len(names))(*ends)
+        n = len(names)
+        self._period, self._head = (C.c_int * n)(*([0] * n)), (C.c_int * n)(*([0] * n))
+        if self.sh_dc_lr is not None:
+            k = names.index("shs")
+            self._period[k], self._head[k] = int(shapes["shs"][1] * shapes["shs"][2]), int(shapes["shs"][2])
+        self._grad_padded = torch.zeros(padded, dtype=torch.float32, device=self.device)
+        self._grad_shard = torch.zeros(self.shard, dtype=torch.float32, device=self.device)
+        self._recv = None
+
+    def step(self, flat_grads: torch.Tensor, grad_scale: float = 1.0):
+        import torch.distributed as dist
+        g = flat_grads
+        if g.dtype != torch.float32 or g.numel() != self.numel or g.device != self.flat.device:
+            raise RuntimeError(f"expected a float32 gradient buffer of {self.numel} elements on {self.flat.device}")
+        self._grad_padded[: self.numel].copy_(g.reshape(-1))
+        lo = self.rank * self.shard
+        # 1. this rank's shard of the SUM of the gradients
+        if dist.get_backend(self.group) == "nccl":
+            dist.reduce_scatter_tensor(self._grad_shard, self._grad_padded, op=dist.ReduceOp.SUM, group=self.group)
+        else:       # gloo: all-to-all of the shards + a sum in rank order
+            if self._recv is None:
+                self._recv = torch.empty((self.world, self.shard), dtype=torch.float32, device=self.device)
+            dist.all_to_all_single(self._recv.view(-1), self._grad_padded, group=self.group)
+            torch.sum(self._recv, dim=0, out=self._grad_shard)
+        # 2. the update of the shard
+        mine = self.flat_padded[lo: lo + self.shard]
+        lrs = [self.lrs[k] for k in self.names]
+        head_lrs = [(self.sh_dc_lr if (k == "shs" and self.sh_dc_lr is not None) else 0.0) for k in self.names]
+        if self._shard_step is not None:
+            self._shard_step(self, lo, mine, self._grad_shard, lrs, head_lrs, float(grad_scale))
+        else:
+            if self.flat.device.type != "cuda":
+                raise RuntimeError("ShardedFlatAdam runs on the GPU only (no CPU path; tests inject their own shard update)")
+            n = len(self.names)
+            stream = C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
+            rc = _lib.lib().frg_adam_step_shard(self.shard, lo, C.c_void_p(mine.data_ptr()), C.c_void_p(self._grad_shard.data_ptr()),
+                                                C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                                self._ends, (C.c_float * n)(*lrs), self._period, self._head, (C.c_float * n)(*head_lrs), n,
+                                                self.betas[0], self.betas[1], self.eps, self.steps + 1, float(grad_scale), stream)
+            if rc < 0:
+                raise RuntimeError(f"frg_adam_step_shard failed ({rc}): {_lib.last_error()}")
+        # 3. every rank's updated shard to every rank
+        dist.all_gather_into_tensor(self.flat_padded, mine.clone(), group=self.group)
+        self.steps += 1
+        return self.params
+
+    def prune(self, keep_mask):
+        raise RuntimeError("ShardedFlatAdam: prune / append re-shard the moments -- not implemented; rebuild the optimizer")
+
+    append = prune

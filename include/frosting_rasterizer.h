@@ -423,6 +423,16 @@ int frg_activate(int P, const float* raw_opacity, const float* raw_scale, const 
 int frg_activate_backward(int P, const float* opacity, const float* scale, const float* raw_rot,
                           float* g_opacity, float* g_scale, float* g_rot, void* hip_stream);
 
+/* frg_adam_step on a SHARD of the flat layout (reduce-scatter of the gradients -> every rank updates its 1/N of
+ * the parameters -> all-gather of the parameters): elements [first, first + n), first a multiple of 4; the four arrays point at
+ * element `first` (the moments may be shard-sized allocations); segment_* describe the WHOLE layout as for frg_adam_step, at
+ * most 7 segments.  Every element gets the step size of its true segment and phase: the shards' updates together are
+ * frg_adam_step's on the whole buffer, bit for bit. */
+int frg_adam_step_shard(long long n, long long first, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                        const long long* segment_ends, const float* segment_lrs, const int* segment_period,
+                        const int* segment_head, const float* segment_head_lrs, int n_segments,
+                        double beta1, double beta2, double eps, int step, float grad_scale, void* hip_stream);
+
 /* frg_adam_step with a row mask: row_live[P] as frg_backward_args::row_live leaves it, segment_width[k] = elements per
  * Gaussian of segment k (0: the segment is not per-Gaussian -- its gradients are always read).  The gradient of an
  * element whose Gaussian is unmarked is taken as zero WITHOUT being read (the moments still decay and the parameter still

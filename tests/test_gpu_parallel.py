@@ -299,3 +299,67 @@ def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["scaling"] == "weak"
     assert out["config"]["exchange_bytes_per_rank"] > 0 and "exchange_timing" in out
     assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+
+
+def _sharded_adam_worker(rank, world, port, P, K, steps, q):
+    """One rank of a 2-rank job on GPU 0 over gloo: ShardedFlatAdam with the HIP shard update (frg_adam_step_shard)."""
+    import torch.distributed as dist
+    from frosting_amd.optim import ShardedFlatAdam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
+        lrs = dict(means3D=1.6e-4, scales=5e-3, rotations=1e-3, opacities=5e-2, shs=2.5e-3 / 20)
+        opt = ShardedFlatAdam(shapes, lrs, dev, dist.group.WORLD, sh_dc_lr=2.5e-3)
+        g0 = torch.Generator().manual_seed(5)
+        for k in PARAM_ORDER:
+            opt.params[k].copy_(torch.randn(shapes[k], generator=g0))
+        for it in range(steps):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            opt.step((torch.randn(opt.numel, generator=g) * 0.01).to(dev))
+        torch.cuda.synchronize(dev)
+        q.put((rank, opt.flat.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_adam_on_two_ranks_equals_flat_adam_on_the_summed_gradients(gpu_device):
+    """SURVEY 8(e), second option, with the HIP kernel: two ranks reduce-scatter their gradients, each updates its half of the
+    flat buffer (frg_adam_step_shard: the boundary falls inside the SH rows, off the 48-element DC / rest period, and inside
+    a 16-byte group of the unsharded layout's neighbour segment), the halves are all-gathered -- the parameters equal
+    FlatAdam.step on the summed gradients, bit for bit, after three steps."""
+    import torch.multiprocessing as mp
+    from frosting_amd.optim import FlatAdam
+    world, P, K, steps = 2, 1031, 16, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_adam_worker, args=(r, world, port, P, K, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dev = gpu_device
+    shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
+    lrs = dict(means3D=1.6e-4, scales=5e-3, rotations=1e-3, opacities=5e-2, shs=2.5e-3 / 20)
+    ref = FlatAdam(shapes, lrs, dev, sh_dc_lr=2.5e-3)
+    g0 = torch.Generator().manual_seed(5)
+    for k in PARAM_ORDER:
+        ref.params[k].copy_(torch.randn(shapes[k], generator=g0))
+    for it in range(steps):
+        total = None
+        for r in range(world):
+            g = torch.randn(ref.numel, generator=torch.Generator().manual_seed(1000 * it + r)) * 0.01
+            total = g if total is None else total + g
+        ref.step(total.to(dev))
+    want = ref.flat.cpu()
+    assert float(want.abs().max()) > 0
+    for r in range(world):
+        assert torch.equal(torch.from_numpy(res[r]), want), r

@@ -405,3 +405,91 @@ def test_probe_of_the_reduce_plans_gloo():
     assert t0 == t1 and b0 == b1 and b0 in ("allreduce", "direct") and set(t0) == {"allreduce", "direct"}
     assert r00 == r01 == r10 == r11 == b0
     assert v0 == v1 == 3.0                       # 1 + 2: the dense part summed over the two ranks
+
+
+# ---- sharded optimizer (second option): reduce-scatter -> update of the 1/N shard -> all-gather of the parameters
+
+def _torch_shard_step(opt, lo, params, grads, lrs, head_lrs, grad_scale):
+    """Test-side stand-in for frg_adam_step_shard: plain Adam on the elements [lo, lo + len) of the flat layout, the step size
+    of every element taken from its GLOBAL position (segment, and DC / rest phase inside the SH rows)."""
+    n = params.numel()
+    idx = torch.arange(lo, lo + n)
+    lr = torch.zeros(n)
+    begin = 0
+    for k, name in enumerate(opt.names):
+        end = int(opt._ends[k])
+        sel = (idx >= begin) & (idx < end)
+        lr[sel] = lrs[k]
+        if opt._period[k] > 0:
+            head = sel & (((idx - begin) % int(opt._period[k])) < int(opt._head[k]))
+            lr[head] = head_lrs[k]
+        begin = end
+    b1, b2 = opt.betas
+    t = opt.steps + 1
+    g = grads * grad_scale
+    opt.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+    opt.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = opt.exp_avg_sq.sqrt() / (1 - b2 ** t) ** 0.5 + opt.eps
+    params.sub_(lr / (1 - b1 ** t) * (opt.exp_avg / denom))
+
+
+def _sharded_worker(rank, world, port, P, K, steps, q):
+    import torch.distributed as dist
+    from frosting_amd.optim import ShardedFlatAdam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes, init = _initial_params(P, K)
+    lrs = dict(means3D=1.6e-4, scales=5e-3, rotations=1e-3, opacities=5e-2, shs=2.5e-3 / 20)
+    opt = ShardedFlatAdam(shapes, lrs, "cpu", dist.group.WORLD, sh_dc_lr=2.5e-3, shard_step=_torch_shard_step)
+    for k in PARAM_ORDER:
+        opt.params[k].copy_(init[k])
+    assert opt.exp_avg.numel() == opt.shard and opt.shard * world >= opt.numel      # the moments exist for the shard only
+    for it in range(steps):
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        opt.step(torch.randn(opt.numel, generator=g))
+    q.put((rank, opt.flat.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adam_equals_the_replicated_update_gloo(world):
+    """ShardedFlatAdam on N ranks (reduce-scatter of the per-view gradients, each rank's update of its shard, all-gather of
+    the parameters; the shard boundaries fall inside the SH rows, off the DC / rest period) == the same update of the
+    whole buffer on the summed gradients in one process, bit for bit, on every rank."""
+    P, K, steps = 131, 16, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, P, K, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    # one process: the whole buffer as one "shard"
+    import types
+    from frosting_amd.parallel import flat_layout
+    shapes, init = _initial_params(P, K)
+    names, layout, numel = flat_layout(shapes)
+    ref = types.SimpleNamespace(names=names, betas=(0.9, 0.999), eps=1e-15, steps=0, exp_avg=torch.zeros(numel), exp_avg_sq=torch.zeros(numel))
+    ref._ends = [layout[names[i + 1]][0] if i + 1 < len(names) else numel for i in range(len(names))]
+    ref._period = [0] * len(names); ref._head = [0] * len(names)
+    ref._period[names.index("shs")], ref._head[names.index("shs")] = K * 3, 3
+    flat = torch.zeros(numel)
+    for k in PARAM_ORDER:
+        o, n = layout[k]
+        flat[o:o + n] = init[k].reshape(-1)
+    lrs = dict(means3D=1.6e-4, scales=5e-3, rotations=1e-3, opacities=5e-2, shs=2.5e-3 / 20)
+    for it in range(steps):
+        total = None
+        for r in range(world):       # rank order, like the all-to-all + sum
+            g = torch.randn(numel, generator=torch.Generator().manual_seed(1000 * it + r))
+            total = g if total is None else total + g
+        _torch_shard_step(ref, 0, flat, total, [lrs[k] for k in names], [2.5e-3 if k == "shs" else 0.0 for k in names], 1.0)
+        ref.steps += 1
+    for r in range(world):
+        assert (torch.from_numpy(res[r]) == flat).all(), r
