@@ -82,6 +82,8 @@ def parse_args():
                          "'auto' (default) = both are timed on this run's buffers before the warm-up (RCCL backend, N>1) and the "
                          "faster one is used -- which of the two RCCL serves better on a fully connected xGMI node is not "
                          "something the arithmetic of DESIGN.md section 5 can settle; single rank / gloo: allreduce")
+    ap.add_argument("--probe-exchange", action="store_true",
+                    help="run the 'auto' probe of --exchange on any backend (it is skipped on gloo otherwise: functional tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only for functional tests of the multi-rank path on one GPU")
     ap.add_argument("--force-exchange", action="store_true",
@@ -537,18 +539,23 @@ def main():
     for _ in range(max(0, args.spinup_steps)):
         step()
     drain()
-    if auto_exchange and exchanging and world > 1 and args.backend == "nccl" and schedule[0] != "stale":
+    if auto_exchange and exchanging and world > 1 and (args.backend == "nccl" or args.probe_exchange) and schedule[0] != "stale":
         # both row-level plans timed on this run's scene, max over ranks; the faster one runs (the same on every rank: the
-        # choice is made from the reduced times)
-        exchange_probe = {}
-        for plan in ("factored", "sparse"):
-            vpr.set_exchange_plan(plan, reduce=args.reduce)
-            timed(3)
-            t_, _ = timed(6)
-            tt = torch.tensor([t_ / 6], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            exchange_probe[plan] = 1e3 * float(tt.item())
-        args.exchange = min(exchange_probe, key=exchange_probe.get)
+        # choice is made from the reduced times).  Anything going wrong in here must not cost the run: the factored plan,
+        # measured since round 2, is the fallback.
+        try:
+            exchange_probe = {}
+            for plan in ("factored", "sparse"):
+                vpr.set_exchange_plan(plan, reduce=args.reduce)
+                timed(3)
+                t_, _ = timed(6)
+                tt = torch.tensor([t_ / 6], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                exchange_probe[plan] = 1e3 * float(tt.item())
+            args.exchange = min(exchange_probe, key=exchange_probe.get)
+        except Exception as ex:      # noqa: BLE001
+            exchange_probe = {"error": repr(ex)}
+            args.exchange = "factored"
         vpr.set_exchange_plan(args.exchange, reduce=args.reduce)
     for w in range(args.warmup):
         if timers and w == args.warmup - 1:

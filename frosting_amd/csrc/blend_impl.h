@@ -189,6 +189,11 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
+#ifdef FRG_AB_PRIO
+    // A tile's four waves walk its list sequentially: the frame ends with its longest lists (C4: the limb of the shell, 5 000
+    // entries where the mean tile has 800).  Their waves are given issue priority over the short tiles' waves they share a SIMD with.
+    if (n > FRG_AB_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
 
     __shared__ float4 s_a_all[4][64];    // x, y, -, contributor (1-based list position)
     __shared__ float4 s_co_all[4][64];   // conic a, b, c, opacity

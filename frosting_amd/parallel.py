@@ -90,7 +90,7 @@ XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task sta
 def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "factored", reduce: str = "allreduce",
                      schedule: str = "in-step", link_efficiency: float = 0.8, rebuild_ms_per_view: float = 0.019,
                      split_overhead_ms: float = 0.08, per_gaussian_bwd_ms: float = 0.29, bus_GBps: float = None,
-                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0):
+                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0, adam_ms: float = 0.8):
     """Predicted step time and scaling of the view-parallel step on ONE node of `world` MI355X: arithmetic, not a
     measurement (no 8-GPU run is available to this repository; bench.py prints it as `predicted`).
 
@@ -110,7 +110,7 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
     under phase 2 of the backward (per_gaussian_bwd_ms) at the price of split_overhead_ms; the SH rebuild
     (rebuild_ms_per_view x N, measured 0.15 ms at 8 views) runs beside the dense sum; "sync" hides nothing.  Sparse plan
     (one-call backward, nothing hidden but the zero fills, which run under the wire): pack (one read of the 56 P bytes) +
-    the host's wait for the counts (0.03 ms) + the row all-gather + one scatter launch per view + the SH rebuild.
+    the host's wait for the counts and its serial section behind it (0.16 ms, measured on one rank) + the row all-gather + one scatter launch per view + the SH rebuild.
     link_efficiency: achieved / nominal link rate.  Returns a dict."""
     rate = XGMI_LINK_GBPS * 1e9 * link_efficiency
     links = max(1, min(world - 1, XGMI_LINKS))
@@ -132,9 +132,12 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
         row_bytes = 4.0 * ROW_FLOATS * rows
         rows_ms = 1e3 * (row_bytes * (world - 1) / bus if bus else row_bytes / rate)
         pack_ms = 1e3 * (56.0 * P + row_bytes) / (hbm_GBps * 1e9)
-        counts_ms = 0.03
+        # the host's wait for the counts and what it enqueues behind it with the GPU idle: a single rank's exposed time (0.35 ms,
+        # profiles/r05_exchange_1rank.log) less the kernels counted here
+        counts_ms = 0.16
         zero_ms = 1e3 * (44.0 * P + 12.0 * P * world) / (hbm_GBps * 1e9)      # the dense part and the dense dRGB of every view
-        scatter_ms = world * (0.004 + 1e3 * (row_bytes + 2 * 44.0 * rows + 12.0 * rows) / (hbm_GBps * 1e9 * 0.5))   # launch + scattered read-modify-write at half rate
+        # one scatter launch per view: 0.047 ms for the 372 000 rows of a C3 view (rocprofv3, profiles/r05_trace_c3_sparse_exchange.log)
+        scatter_ms = world * 0.047 * rows / 372000.0
     if world == 1:
         exposed = 0.0
     elif sparse:
@@ -155,6 +158,15 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
     if sparse:
         out.update(rows_per_rank=rows, rows_MB_in=4.0 * ROW_FLOATS * rows * max(world - 1, 0) / 1e6, rows_wire_ms=rows_ms,
                    pack_ms=pack_ms, counts_wait_ms=counts_ms, zero_fill_ms=zero_ms, scatter_ms=scatter_ms)
+    # SURVEY 8(e), second option (frosting_amd.optim.ShardedFlatAdam): the all-gather half of the sum moves PARAMETERS instead
+    # of gradients -- (N-1)/N of all 59 floats per Gaussian, whatever the exchange plan -- and takes (N-1)/N of the replicated
+    # Adam (adam_ms: 0.8 ms at C3) off every rank
+    if world > 1:
+        full = 4.0 * P * (11 + 3 * K) * (world - 1) / world
+        gather = 1e3 * full / (bus if bus else rate * links)
+        out["sharded_adam"] = {"param_gather_ms": gather, "adam_saved_ms": adam_ms * (world - 1) / world,
+                               "net_ms": gather - adam_ms * (world - 1) / world,
+                               "note": "net > 0: the sharded optimizer costs more than the replicated one on this node"}
     return out
 
 

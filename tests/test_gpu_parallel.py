@@ -277,7 +277,7 @@ def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
     assert (res[0] == res[1]).all()
 
 
-@pytest.mark.parametrize("exchange", ["factored", "allreduce", "sparse"])
+@pytest.mark.parametrize("exchange", ["factored", "allreduce", "sparse", "auto"])
 def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
     """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under
     torch.distributed.run, both ranks share GPU 0 (FRG_BENCH_ONE_GPU) and exchange over gloo; rank 0 prints
@@ -291,13 +291,16 @@ def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--exchange", exchange,
                         "--points", "30000", "--steps", "3", "--warmup", "2", "--spinup-steps", "2", "--no-cpu-baseline",
-                        "--no-extras"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+                        "--no-extras", "--probe-exchange"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["scaling"] == "weak"
     assert out["config"]["exchange_bytes_per_rank"] > 0 and "exchange_timing" in out
+    if exchange == "auto":      # both row-level plans were timed and one of them runs
+        probe = out["config"]["exchange_probe_ms_per_step"]
+        assert set(probe) == {"factored", "sparse"} and all(v > 0 for v in probe.values()), probe
     assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
 
 

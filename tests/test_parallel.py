@@ -360,6 +360,22 @@ def test_predicted_exchange_budget_arithmetic():
     assert ovl["scaling_vs_1gpu"] > 6.0 > plain["scaling_vs_1gpu"]
     one = predict_exchange(P, K, 1, 1.44)
     assert one["exposed_ms"] == 0.0 and one["scaling_vs_1gpu"] == 1.0
+    # every collective priced at one bus bandwidth per GPU (7 x 153 nominal, 450 = what RCCL usually reaches, 300):
+    # incoming bytes / bandwidth, the all-reduce twice
+    for bw in (1071.0, 450.0, 300.0):
+        f = predict_exchange(P, K, 8, 1.44, "factored", "direct", "in-step", bus_GBps=bw)
+        assert abs(f["dense_wire_ms"] - 2 * 7 / 8 * 132e6 / (bw * 1e9) * 1e3) < 1e-9 and abs(f["gather_wire_ms"] - 7 * 36e6 / (bw * 1e9) * 1e3) < 1e-9
+        sp = predict_exchange(P, K, 8, 1.44, "sparse", "direct", "sync", bus_GBps=bw)
+        assert abs(sp["rows_MB_in"] - 7 * 0.124 * P * 64 / 1e6) < 1e-6 and abs(sp["rows_wire_ms"] - sp["rows_MB_in"] * 1e6 / (bw * 1e9) * 1e3) < 1e-9
+        assert sp["dense_MB"] == 0.0 and sp["exposed_ms"] > sp["rows_wire_ms"]
+        sa = f["sharded_adam"]      # the sharded optimizer: (N-1)/N of ALL parameters gathered against (N-1)/N of the update saved
+        assert abs(sa["param_gather_ms"] - 7 / 8 * 708e6 / (bw * 1e9) * 1e3) < 1e-9 and abs(sa["net_ms"] - (sa["param_gather_ms"] - 0.7)) < 1e-9
+    # what the arithmetic says: at the nominal bus the factored in-step plan scales best (> 6 x); the sparse rows
+    # overtake it as the bandwidth drops -- and nothing reaches 6 x at 450 GB/s
+    at = lambda pl, sc, bw: predict_exchange(P, K, 8, 1.44, pl, "direct", sc, bus_GBps=bw)["scaling_vs_1gpu"]
+    assert at("factored", "in-step", 1071.0) > 6.0 > at("sparse", "sync", 1071.0)
+    assert at("sparse", "sync", 300.0) > at("factored", "in-step", 300.0)
+    assert max(at("factored", "in-step", 450.0), at("sparse", "sync", 450.0)) < 6.0
     for n in (2, 4, 8):           # more GPUs never cost less wire time per rank, and scaling stays below N
         r = predict_exchange(P, K, n, 1.44, "factored", "direct", "in-step")
         assert 0 < r["scaling_vs_1gpu"] < n
