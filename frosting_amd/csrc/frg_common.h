@@ -133,7 +133,7 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
     // the instance count the forward CARVED its binning chunk with (num_rendered; the capacity of a deferred-counters
     // forward), stamped by the chunk scan: BinningState::ckpt sits behind point_list and pairs, at an offset that depends
     // on it, and the backward blend takes the offset from HERE -- not from the R its caller passes, which may be either
-    // of the two (a wrong offset would silently read other tiles' checkpoints for every walk deeper than FRG_BWD_SEG)
+    // of the two (a wrong offset would silently read other tiles' checkpoints for every walk deeper than one segment)
     uint32_t carved_R;
     uint32_t bwd_seg_log;    // log2 of the segment length the forward blend left its checkpoints at (stamped by blend_fwd_kernel)
 };
@@ -293,10 +293,10 @@ struct BinningState {
     uint32_t* point_list;    // sorted Gaussian indices, tile-major
     uint2* pairs;            // (depth bits, index), tile-major, scatter order
     // Forward-blend checkpoints for the segmented backward blend: {T, C0, C1, C2} of every pixel of a tile at the list
-    // positions k * FRG_BWD_SEG (k >= 1) its walk passes -- the state BEFORE entry k * FRG_BWD_SEG is blended.  Record
-    // (first / FRG_BWD_SEG + k) belongs to the tile whose list starts at instance `first`: unique, because a list of n
+    // positions k * SEG (k >= 1; SEG = 1 << seg_log) its walk passes -- the state BEFORE entry k * SEG is blended.  Record
+    // (first / SEG + k) belongs to the tile whose list starts at instance `first`: unique, because a list of n
     // entries has floor((n - 1) / SEG) boundaries and the next list starts n instances later.  256 float4 per record,
-    // quadrant-major (the forward's wave q writes [q * 64, q * 64 + 64)).  4 bytes per instance; written only where crossed.
+    // quadrant-major (the forward's wave q writes [q * 64, q * 64 + 64)).  16 / 8 bytes of space per instance at 256 / 512; written only where crossed.
     float4* ckpt;
     __host__ __device__ static size_t ckpt_records(size_t R, int seg_log) { return (R >> seg_log) + 2; }
     // The backward blend's FULL-segment items (tile, segment), listed per XCD band by the forward blend as its tiles finish:
