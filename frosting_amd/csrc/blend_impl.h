@@ -216,14 +216,18 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
 
+    // The records of round r + 1 are requested while round r is processed -- and the list entries (Gaussian indices) of round
+    // r + 2 with them (r05): index -> record is a chain of two memory round trips, and a frame whose tail is a few long lists
+    // (C4's limb) pays one such chain per round of 64 entries; with the indices a round further ahead it is one trip.
     float4 a_n = make_float4(0.f, 0.f, 0.f, 0.f), co_n = a_n, col_n = a_n;
-    auto fetch = [&](int base) {       // unconditional loads at clamped positions (see blend_bwd_kernel)
-        const uint32_t id = point_list[rg.x + min(base + lane, n - 1)];
+    uint32_t id_n = 0;                 // this lane's list entry of the round after the one whose records are in flight
+    auto fetch_id = [&](int base) { id_n = point_list[rg.x + min(base + lane, n - 1)]; };   // unconditional loads at clamped positions (see blend_bwd_kernel)
+    auto fetch = [&](uint32_t id) {
         a_n = xydr[FRG_REC * id];
         co_n = conic_opacity[FRG_REC * id];
         col_n = rgb_clamped[FRG_REC * id];
     };
-    if (PREFETCH && n > 0) fetch(0);
+    if (PREFETCH && n > 0) { fetch_id(0); fetch(id_n); if (n > 64) fetch_id(64); }
     // The list is walked segment by segment (SEG entries: the work items of the backward blend).  At every
     // boundary the quadrant crosses, the state of its pixels BEFORE the segment's first entry is left for the backward's
     // item of the segment that ends there (a pixel that has stopped leaves stale values nobody reads: its last contributor
@@ -242,7 +246,10 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), co = a, col = a;
         if (PREFETCH) {
             a = a_n; co = co_n; col = col_n;
-            if (base + 64 < n) fetch(base + 64);          // wave-uniform
+            if (base + 64 < n) {                          // wave-uniform
+                fetch(id_n);
+                if (base + 128 < n) fetch_id(base + 128);
+            }
             hit = lane < cnt && quadrant_hit(a.x, a.y, co, qx0, qy0);
         } else if (lane < cnt) {
             const uint32_t id = point_list[rg.x + base + lane];
@@ -261,6 +268,45 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             s_rgb[d] = col;
         }
         wave_lds_sync();
+#ifndef FRG_FWD_UNROLL
+#define FRG_FWD_UNROLL 4       // same box, C4 forward blend: 1 -> 0.256 ms, 2 -> 0.249, 4 -> 0.245; C3 and C2 unchanged (profiles/r05_ab_fwd_unroll.log)
+#endif
+#if FRG_FWD_UNROLL > 1
+        // FRG_FWD_UNROLL entries per trip: the falloff of an entry (quadratic form, v_exp, min) does not depend on the pixel's
+        // state -- only T (1 - alpha), the stop test and the colour update do -- so the alphas of a group are computed side by
+        // side and the sequential part of a pixel's chain shrinks to three dependent operations per entry.  Same operations on
+        // the same values in the same order: every output bit-identical.  A frame of few, long lists (C4's limb: 4 500 entries
+        // walked by ONE wave per quadrant while the GPU has run dry) is bound by that chain's latency.
+        for (int j = 0; j < nkeep; j += FRG_FWD_UNROLL) {
+            float al[FRG_FWD_UNROLL], pw[FRG_FWD_UNROLL], cw[FRG_FWD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FRG_FWD_UNROLL; u++) {
+                const bool there = j + u < nkeep;            // wave-uniform; a slot beyond the round's entries is a no-op (alpha 0)
+                const float4 ga = s_a[min(j + u, 63)];
+                const float4 gco = s_co[min(j + u, 63)];
+                float dx, dy;
+                const float power = M::power(ga.x, ga.y, gco, pxf, pyf, dx, dy);
+                pw[u] = there ? power : 0.0f;
+                al[u] = there ? fminf(0.99f, gco.w * M::expo(power)) : 0.0f;
+                cw[u] = ga.w;
+            }
+#pragma unroll
+            for (int u = 0; u < FRG_FWD_UNROLL; u++) {
+                const float alpha = al[u];
+                const bool keep_px = !(pw[u] > 0.0f) & !(alpha * alive < 1.0f / 255.0f);
+                const float test_T = M::attenuate(Tr, alpha);
+                const bool stop = keep_px & (test_T < 0.0001f);
+                alive = stop ? 0.0f : alive;
+                if (keep_px & !stop) {
+                    const float4 gc = s_rgb[min(j + u, 63)];
+                    M::accumulate(gc, alpha, Tr, C0, C1, C2);
+                    Tr = test_T;
+                    last = __float_as_uint(cw[u]);
+                }
+            }
+            if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
+        }
+#else
         for (int j = 0; j < nkeep; j++) {
             const float4 ga = s_a[j];
             const float4 gco = s_co[j];
@@ -281,6 +327,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             }
             if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
         }
+#endif
     }
     }
 
