@@ -258,6 +258,54 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             col = rgb_clamped[FRG_REC * id];
             hit = quadrant_hit(a.x, a.y, co, qx0, qy0);
         }
+#ifdef FRG_AB_HALVES
+        // LANE-EFFICIENCY EXPERIMENT (an A/B build, not the product path): the quadrant's upper and lower
+        // 8x4 halves cull the staged entries SEPARATELY and walk their own compacted index lists side by side -- lanes 0..31
+        // take entry t of the upper list while lanes 32..63 take entry t of the lower one -- so a trip serves two different
+        // entries and the round takes max(|upper|, |lower|) trips instead of |union|.  Culling is conservative per half, so
+        // every pixel still blends exactly the entries that can reach it, in list order: outputs bit-identical.
+        const bool hit_u = hit && rect_hit_xy<7, 3>(a.x, a.y, co, qx0, qy0);
+        const bool hit_l = hit && rect_hit_xy<7, 3>(a.x, a.y, co, qx0, qy0 + 4);
+        const uint64_t keep_u = wave_ballot(hit_u), keep_l = wave_ballot(hit_l);
+        const int n_u = __popcll(keep_u), n_l = __popcll(keep_l);
+        __shared__ uint32_t s_idx_all[4][2][64];
+        uint32_t* s_iu = s_idx_all[q][0];
+        uint32_t* s_il = s_idx_all[q][1];
+        wave_lds_sync();                          // previous round's readers are done
+        if (hit_u | hit_l) {
+            s_a[lane] = make_float4(a.x, a.y, 0.f, __uint_as_float((uint32_t)(base + lane + 1)));
+            s_co[lane] = M::stage(co);
+            s_rgb[lane] = col;
+        }
+        if (hit_u) s_iu[lanes_before(keep_u, lane)] = (uint32_t)lane;
+        if (hit_l) s_il[lanes_before(keep_l, lane)] = (uint32_t)lane;
+        wave_lds_sync();
+        {
+            const uint32_t* mine = lane < 32 ? s_iu : s_il;
+            const int n_mine = lane < 32 ? n_u : n_l;
+            const int ntrip = max(n_u, n_l);
+            for (int t = 0; t < ntrip; t++) {
+                const bool there = t < n_mine;
+                const uint32_t j = mine[min(t, 63)] & 63u;
+                const float4 ga = s_a[j];
+                const float4 gco = s_co[j];
+                float dx, dy;
+                const float power = M::power(ga.x, ga.y, gco, pxf, pyf, dx, dy);
+                const float alpha = there ? fminf(0.99f, gco.w * M::expo(power)) : 0.0f;
+                const bool keep_px = there & !(power > 0.0f) & !(alpha * alive < 1.0f / 255.0f);
+                const float test_T = M::attenuate(Tr, alpha);
+                const bool stop = keep_px & (test_T < 0.0001f);
+                alive = stop ? 0.0f : alive;
+                if (keep_px & !stop) {
+                    const float4 gc = s_rgb[j];
+                    M::accumulate(gc, alpha, Tr, C0, C1, C2);
+                    Tr = test_T;
+                    last = __float_as_uint(ga.w);
+                }
+                if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
+            }
+        }
+#else
         const uint64_t keep = wave_ballot(hit);
         const int nkeep = __popcll(keep);
         wave_lds_sync();                          // previous round's readers are done
@@ -328,6 +376,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
         }
 #endif
+#endif   // FRG_AB_HALVES
     }
     }
 

@@ -446,8 +446,8 @@ __device__ __forceinline__ void tile_rect(float px, float py, int max_radius, in
 // d^2 <= 512), so the cull never removes a pixel the reference would have blended.
 // Evaluated WITHOUT contraction so that the blend kernels and the per-Gaussian backward
 // (which re-derives which quadrant slots exist) agree bit for bit.
-template <int EXTENT>
-__device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, int qy0)
+template <int EXTENT_X, int EXTENT_Y>
+__device__ __forceinline__ bool rect_hit_xy(float x, float y, float4 co, int qx0, int qy0)
 {
 #pragma clang fp contract(off)
     const float o = co.w;
@@ -457,7 +457,7 @@ __device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, i
     if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f) || !(a < 3.0e38f) || !(c < 3.0e38f)) return true;
     // 255 o lies in [1, 255]: the raw v_log_f32 (log2, 1 ulp) needs none of the denormal scaling __logf carries
     const float thr = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) + 0.02f;
-    const float xlo = (float)qx0 - x, ylo = (float)qy0 - y, xhi = xlo + (float)EXTENT, yhi = ylo + (float)EXTENT;
+    const float xlo = (float)qx0 - x, ylo = (float)qy0 - y, xhi = xlo + (float)EXTENT_X, yhi = ylo + (float)EXTENT_Y;
     if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return true;  // centre inside: Q = 0
     // v_rcp_f32 (1 ulp) instead of two IEEE divisions (~11 instructions each): an error of the clamped vertex
     // position enters Q at second order, far below the margins
@@ -471,6 +471,8 @@ __device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, i
     const float best = fminf(a * ex * ex + 2.f * b * ex * dy + c * dy * dy, a * dx * dx + 2.f * b * dx * ey + c * ey * ey);
     return !(0.5f * 0.999f * best > thr);
 }
+template <int EXTENT>
+__device__ __forceinline__ bool rect_hit(float x, float y, float4 co, int qx0, int qy0) { return rect_hit_xy<EXTENT, EXTENT>(x, y, co, qx0, qy0); }
 __device__ __forceinline__ bool quadrant_hit(float x, float y, float4 co, int qx0, int qy0) { return rect_hit<7>(x, y, co, qx0, qy0); }
 // the same bound over a whole 16x16 tile (a superset of its four quadrants)
 __device__ __forceinline__ bool tile_hit(float x, float y, float4 co, int tx, int ty) { return rect_hit<FRG_TILE - 1>(x, y, co, tx * FRG_TILE, ty * FRG_TILE); }
