@@ -457,6 +457,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_waves") == 0) { const int old = frg::g_bwd_waves; frg::g_bwd_waves = value < 0 ? 0 : value; return old; }
     if (name && strcmp(name, "fwd_order") == 0) { const int old = frg::g_fwd_order; frg::g_fwd_order = value ? 1 : 0; return old; }
+    if (name && strcmp(name, "sh_dir_in_backward") == 0) { const int old = frg::g_sh_no_dir; frg::g_sh_no_dir = value ? 1 : 0; return old; }
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
@@ -510,6 +511,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "bwd_seg_log") == 0) return g_bwd_seg_log.load();
     if (name && strcmp(name, "bwd_waves") == 0) return frg::g_bwd_waves;
     if (name && strcmp(name, "fwd_order") == 0) return frg::g_fwd_order;
+    if (name && strcmp(name, "sh_dir_in_backward") == 0) return frg::g_sh_no_dir;
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
     if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.load();
     if (name && strcmp(name, "fwd_prefetch") == 0) return frg::g_fwd_prefetch;

@@ -23,6 +23,7 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
                           const BinningState& b, hipStream_t s, int ablate = 0, Mailbox* mail = nullptr, uint32_t seq = 0);
 extern int g_rows_grid;   // workgroups of the row-ordered scatter (tuning)
+extern int g_sh_no_dir;   // 1: the forward's SH pass leaves d(colour)/d(direction) to the per-Gaussian backward
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
 
 // class_count: host copy of the per-class tile counts, or nullptr when they are only known on the

@@ -222,7 +222,9 @@ __device__ __forceinline__ int sh_dd_slot(int e) { const int q = e >> 2; return 
 // per-Gaussian forward 0.175 -> 0.142 ms).  dirs[r].w then names the lane behind slot r (the rank permutation is pushed
 // through the LDS crossbar, the invisible lanes behind the visible ones); DENSE: the visibility flag of lane r.
 // Two instances of one body: the dense one is the code the uniform scene has always run.
-template <bool DENSE>
+// WITH_DIR false (r05): the derivative rows are neither summed nor stored -- the per-Gaussian backward forms them from the
+// SH rows of the Gaussians that HAVE a gradient (GeomState::sh_layout bit 1 tells it), one visible Gaussian in seven at C3.
+template <bool DENSE, bool WITH_DIR>
 __device__ __forceinline__ float4 sh_pass(int deg, const float4* __restrict__ src, int nvalid, bool touched, uint64_t vis, int my_slot,
                                           float4* shbuf, const float4* dirs, int dir_stride, float* __restrict__ sh_dir_out)
 {
@@ -277,21 +279,23 @@ __device__ __forceinline__ float4 sh_pass(int deg, const float4* __restrict__ sr
                     if (i == 0) acc = w[0] * sv;
                     else if (i == 1 || i == 3) acc = acc - w[i] * sv;
                     else acc = acc + w[i] * sv;
-                    sd.feed(i, sv, ddx, ddy, ddz);
+                    if (WITH_DIR) sd.feed(i, sv, ddx, ddy, ddz);
                 }
             }
             reinterpret_cast<float*>(shbuf + g * PRE_ROW_F4 + 12)[ch] = acc;    // the row's pad float4: raw colour sums
             // The sub-batch's derivative rows ([16][9] floats, contiguous in sh_dir) are assembled in the LDS rows just
             // consumed -- in the float4 slots that are not a pad -- and leave as 36 float4: stored straight from here
             // they were 144 scattered 4-byte requests per sub-batch.
-            float* rowf = reinterpret_cast<float*>(shbuf);
-            const int e = g * 9 + ch;
-            rowf[sh_dd_slot(e)] = ddx; rowf[sh_dd_slot(e + 3)] = ddy; rowf[sh_dd_slot(e + 6)] = ddz;
+            if (WITH_DIR) {
+                float* rowf = reinterpret_cast<float*>(shbuf);
+                const int e = g * 9 + ch;
+                rowf[sh_dd_slot(e)] = ddx; rowf[sh_dd_slot(e + 3)] = ddy; rowf[sh_dd_slot(e + 6)] = ddz;
+            }
         }
         wave_sync_lds();
         // sh_dir holds the rows BY SLOT inside the wave's block of 64 (the per-Gaussian backward derives the slot from the
         // same visibility ballot); empty slots carry whatever the LDS held: never read
-        if (lane < PRE_SUB * 9 / 4) {     // (read again only by the per-Gaussian backward, a millisecond and gigabytes later)
+        if (WITH_DIR && lane < PRE_SUB * 9 / 4) {     // (read again only by the per-Gaussian backward, a millisecond and gigabytes later)
             typedef float nt_f4 __attribute__((ext_vector_type(4)));
             const float4 v = shbuf[lane + lane / 12];
             __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(sh_dir_out + (size_t)h * PRE_SUB * 9) + lane);
@@ -312,7 +316,7 @@ __device__ __forceinline__ float4 sh_pass(int deg, const float4* __restrict__ sr
 // the view is expected to see a part of the model; GeomState::sh_layout tells the backward).
 template <bool SPARSE>
 __device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restrict__ src, int nvalid, bool touched, float3 dir,
-                                                 float4* shbuf, float4* dirs, int dir_stride, float* __restrict__ sh_dir_out)
+                                                 float4* shbuf, float4* dirs, int dir_stride, float* __restrict__ sh_dir_out, bool with_dir)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t vis = __ballot(touched);
@@ -320,13 +324,15 @@ __device__ __forceinline__ float4 sh_stream_wave(int deg, const float4* __restri
     const int nvis = __popcll(vis);
     if (!SPARSE || sh_slot_dense(nvis)) {          // wave-uniform
         dirs[lane * dir_stride] = make_float4(dir.x, dir.y, dir.z, touched ? 1.0f : 0.0f);
-        return sh_pass<true>(deg, src, nvalid, touched, vis, lane, shbuf, dirs, dir_stride, sh_dir_out);
+        return with_dir ? sh_pass<true, true>(deg, src, nvalid, touched, vis, lane, shbuf, dirs, dir_stride, sh_dir_out)
+                        : sh_pass<true, false>(deg, src, nvalid, touched, vis, lane, shbuf, dirs, dir_stride, sh_dir_out);
     }
     const int rank = __popcll(vis & ((1ull << lane) - 1ull));
     const int behind = __builtin_amdgcn_ds_permute((touched ? rank : nvis + (lane - rank)) << 2, lane);
     dirs[lane * dir_stride] = make_float4(dir.x, dir.y, dir.z, __int_as_float(behind));
     wave_sync_lds();
-    return sh_pass<false>(deg, src, nvalid, touched, vis, rank, shbuf, dirs, dir_stride, sh_dir_out);
+    return with_dir ? sh_pass<false, true>(deg, src, nvalid, touched, vis, rank, shbuf, dirs, dir_stride, sh_dir_out)
+                    : sh_pass<false, false>(deg, src, nvalid, touched, vis, rank, shbuf, dirs, dir_stride, sh_dir_out);
 }
 
 // SHMODE: how the SH colour of a visible Gaussian is produced.
@@ -357,7 +363,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered,
                       uint32_t* __restrict__ row_matrix, int band_w, int nbands, float* __restrict__ sh_dir,
-                      uint32_t* __restrict__ heavy_waves, uint32_t* __restrict__ sh_layout)
+                      uint32_t* __restrict__ heavy_waves, uint32_t* __restrict__ sh_layout, int sh_no_dir)
 {
     constexpr bool SH16 = SHMODE == SH_STREAM || SHMODE == SH_STREAM_SPARSE;
     constexpr bool TIGHT = BINMODE == BIN_TIGHT, CELLS = BINMODE == BIN_CELLS;
@@ -384,7 +390,8 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         for (int t = threadIdx.x; t < nbins; t += FRG_BIN_THREADS) lds_bins[t] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         heavy_waves[0] = 0;   // (filled where point_offsets is finished)
-        if (SHMODE != SH_DEFER) *sh_layout = SHMODE == SH_STREAM_SPARSE ? 1u : 0u;    // (SH_DEFER: sh_color_kernel says)
+        // bit 0: sh_dir rows by rank in sparsely visible waves; bit 1: no sh_dir rows at all (only the float4-streamed pass has that form)
+        if (SHMODE != SH_DEFER) *sh_layout = (SHMODE == SH_STREAM_SPARSE ? 1u : 0u) | ((sh_no_dir && SHMODE != SH_INLINE) ? 2u : 0u);    // (SH_DEFER: sh_color_kernel says)
     }
     // the chunk totals of this workgroup's chunks are accumulated with atomics below
     for (int c = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; c < nchunks; c += FRG_BIN_THREADS * (int)gridDim.x) block_sums[c] = 0;
@@ -447,7 +454,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 // the direction of every Gaussian of the wave waits in the (still empty) colour slot of its record
                 const float4 col = sh_stream_wave<SHMODE == SH_STREAM_SPARSE>(vp.D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0),
                                                   touched != 0, dir, sh_lds + wave * (PRE_SUB * PRE_ROW_F4),
-                                                  rec_lds + (wave * 64) * FRG_REC + 2, FRG_REC, sh_dir + (size_t)idx0 * 9);
+                                                  rec_lds + (wave * 64) * FRG_REC + 2, FRG_REC, sh_dir + (size_t)idx0 * 9, !sh_no_dir);
                 (void)lane;
                 rec[2] = touched ? col : make_float4(0.f, 0.f, 0.f, 0.f);
             } else if (touched) {
@@ -502,9 +509,9 @@ template <bool SH16, bool SPARSE>
 __global__ void __launch_bounds__(SHC_THREADS)
 sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const float* __restrict__ means3D,
                 const int* __restrict__ radii, const float* __restrict__ shs, float4* __restrict__ rgb_clamped,
-                float* __restrict__ sh_dir, uint32_t* __restrict__ sh_layout)
+                float* __restrict__ sh_dir, uint32_t* __restrict__ sh_layout, int sh_no_dir)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sh_layout = (SH16 && SPARSE) ? 1u : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sh_layout = ((SH16 && SPARSE) ? 1u : 0u) | ((SH16 && sh_no_dir) ? 2u : 0u);
     __shared__ float4 sh_lds[SH16 ? (SHC_THREADS / 64) * PRE_SUB * PRE_ROW_F4 : 1];
     __shared__ float4 dir_lds[SH16 ? SHC_THREADS : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -522,7 +529,7 @@ sh_color_kernel(int P, int D, int M, const float* __restrict__ cam_pos, const fl
     }
     if (SH16) {
         const float4 col = sh_stream_wave<SPARSE>(D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0), touched, dir,
-                                          sh_lds + wave * (PRE_SUB * PRE_ROW_F4), dir_lds + wave * 64, 1, sh_dir + (size_t)idx0 * 9);
+                                          sh_lds + wave * (PRE_SUB * PRE_ROW_F4), dir_lds + wave * 64, 1, sh_dir + (size_t)idx0 * 9, !sh_no_dir);
         if (touched) rgb_clamped[FRG_REC * idx] = col;
     } else if (touched) {
         float w[16];
@@ -1101,6 +1108,7 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 // ---- host launchers -----------------------------------------------------------
 // workgroups of the cell-ordered scatter (tuning knob: frg_set_option("rows_grid")), 2 per CU by default
 int g_rows_grid = 0;     // 0: by the model's size (launch_scatter); > 0: timing experiments
+int g_sh_no_dir = 0;     // 1: the SH pass leaves d(colour)/d(direction) to the per-Gaussian backward (frg_set_option("sh_dir_in_backward"))
 
 // The scatter runs over cell-ordered records (reorder_kernel + scatter_rows_kernel) in the reference-identical
 // binning mode; tight binning keeps the scatter in the caller's order (it would evaluate the per-instance tile test in
@@ -1133,7 +1141,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
-                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves, g.sh_layout);
+                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves, g.sh_layout, g_sh_no_dir);
     return hipGetLastError();
 }
 
@@ -1164,11 +1172,11 @@ hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, con
     const dim3 grid((P + SHC_THREADS - 1) / SHC_THREADS), block(SHC_THREADS);
     if (sh_streamable(in, vp)) {
         if (vp.sparse_sh)
-            hipLaunchKernelGGL((sh_color_kernel<true, true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout);
+            hipLaunchKernelGGL((sh_color_kernel<true, true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, g_sh_no_dir);
         else
-            hipLaunchKernelGGL((sh_color_kernel<true, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout);
+            hipLaunchKernelGGL((sh_color_kernel<true, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, g_sh_no_dir);
     } else
-        hipLaunchKernelGGL((sh_color_kernel<false, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout);
+        hipLaunchKernelGGL((sh_color_kernel<false, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, g_sh_no_dir);
     return hipGetLastError();
 }
 

@@ -94,7 +94,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
         clamp_bits = __float_as_uint(rgb_clamped[FRG_REC * idx].w);
         tile_rect(g.x, g.y, radius, vp.gx, vp.gy, x0, y0, x1, y1);
     }
-    const int sh_row = idx0 + sh_slot_of(__ballot(visible), lane, *sh_layout != 0u);     // (frg_common.h: by lane or by rank among the wave's visible Gaussians)
+    const int sh_row = idx0 + sh_slot_of(__ballot(visible), lane, (*sh_layout & 1u) != 0u);     // (frg_common.h: by lane or by rank among the wave's visible Gaussians)
     // ---- 1. slot reduction ------------------------------------------------------
     const uint32_t incl = valid ? point_offsets[idx] : 0u;
     const uint32_t base = valid ? (idx == 0 ? 0u : point_offsets[idx - 1]) : 0u;
@@ -309,9 +309,33 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     const bool wr = valid && (!row_live || has_grad);
     if (row_live && valid) row_live[idx] = has_grad ? 1 : 0;
     // d(colour)/d(direction), left by the forward's SH pass (GeomState::sh_dir): the backward does not read the 192-byte SH rows
+    // -- or not left (sh_layout bit 1, r05): then they are formed in section 4 below, from the SH rows of the Gaussians that
+    // have a gradient only, in the forward's order of additions (the same bits either way)
+    const bool dir_here = SH16 && shs && (*sh_layout & 2u);          // wave-uniform
     float shd[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) shd[k] = (has_grad && shs) ? sh_dir[(size_t)sh_row * 9 + k] : 0.0f;
+    for (int k = 0; k < 9; k++) shd[k] = (has_grad && shs && !dir_here) ? sh_dir[(size_t)sh_row * 9 + k] : 0.0f;
+    if (dir_here && has_grad) {
+        // shd[3 a + ch] = sum_i dbasis_i/d(axis a) * sh[i][ch], coefficient after coefficient as the forward's SH pass adds them
+        // (ShDir::feed; preprocess.hip sh_pass): 192 bytes of this Gaussian's row, read by the Gaussians with a gradient only.
+        // Here, in front of the covariance chain, the twelve requests in flight cost no registers beyond the kernel's peak.
+        const float3 m = param_mean(means3D, raw, idx);
+        const float dox = m.x - vmx.campos[0], doy = m.y - vmx.campos[1], doz = m.z - vmx.campos[2];   // the expressions of section 4 (and of the forward)
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const ShDir sd(vp.D, dox / len, doy / len, doz / len);
+        const int ncoef = (vp.D + 1) * (vp.D + 1);
+        const float4* row = reinterpret_cast<const float4*>(shs) + (size_t)idx * 12;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const float4 v = row[j];
+            const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int e = 4 * j + t, i = e / 3, ch = e % 3;
+                if (i < ncoef) sd.feed(i, f[t], shd[ch], shd[3 + ch], shd[6 + ch]);
+            }
+        }
+    }
     // The blend backward stores pixel MOMENTS of v = G dL/dalpha per (tile, Gaussian): sum v dx, v dy, v dx^2,
     // v dx dy, v dy^2, v.  The map to the reference's terms (backward.cu:536-554: dL/dG = o dL/dalpha,
     // dG/d(delta) = -G (a dx + b dy, c dy + b dx), d(delta)/d(NDC) = (W/2, H/2)) is linear with per-GAUSSIAN

@@ -276,6 +276,12 @@ int frg_backward_ex(const frg_backward_args* args);
  * given, or the previous forward of the calling thread saw less than three quarters of a model of the same size -- the SH
  * pass streams the coefficient rows of the VISIBLE Gaussians only (0: always the rows of every 16-Gaussian block with a
  * visible one).  Same arithmetic per Gaussian: every output bit-identical.
+ * "sh_dir_in_backward" (default 0): 1 = the forward's SH pass does not form d(colour)/d(direction) (36 bytes stored per
+ * visible Gaussian, read back by the per-Gaussian backward); a backward that follows forms it from the 192-byte SH rows of
+ * the Gaussians that have a gradient, in the forward's order of additions -- every gradient bit the same.  For forward-only
+ * rendering of large models (C3: the per-Gaussian forward 0.221 -> 0.189 ms); with a backward behind it the step is SLOWER
+ * (+0.064 ms in the per-Gaussian backward at C3), which is why it is not the default.  M = 16 coefficients only; the backward
+ * follows what its forward stamped, not the option at the time it runs.
  * "fwd_order" (default 1): the forward blend takes the tiles longest list first (the size classes the scan builds for the
  * sort); 0 = in tile order, one band of tile rows per XCD.  Scheduling only, outputs bit-identical.
  * "fwd_prefetch" (default 1): the forward blend requests the next 64 list entries' records while it processes the

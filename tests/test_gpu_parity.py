@@ -47,6 +47,8 @@ def _reset_options():
     _lib.set_option("fwd_order", 1)
     _lib.set_option("counter_mailbox", 1)
     _lib.set_option("sparse_sh", 1)
+    _lib.set_option("sh_dir_in_backward", 0)
+    _lib.set_option("async_sh", 0)
     _lib.set_option("exact_blend", 0)
     _lib.set_option("profile", 0)
     _lib.set_option("tight_binning", 0)
@@ -875,6 +877,68 @@ def test_sh_pass_over_the_visible_gaussians_only(gpu_device, ops):
         assert all(torch.equal(a, b) for a, b in zip(got[3], full_want[3]))
 
 
+@pytest.mark.parametrize("frame", ["c3:300000:3", "c3-half-outside:300000:3", "c2:60000:2", "c2:60000:3:async_sh=2"])
+def test_sh_direction_derivative_formed_by_the_backward_gives_the_same_bits(gpu_device, ops, frame):
+    """VERDICT r04 item 6.  Option sh_dir_in_backward = 1: the forward's SH pass neither sums nor stores d(colour)/d(direction)
+    (36 bytes per VISIBLE Gaussian); the per-Gaussian backward forms it from the 192-byte SH rows of the Gaussians that HAVE a
+    gradient, coefficient after coefficient in the forward's order -- image, radii and every gradient bit as with the rows
+    stored, on the plain pass, on the pass over the visible Gaussians of a half-visible model (rows by rank), at a lower
+    active degree and with the colours on the side stream.  The backward follows what ITS forward stamped (GeomState::
+    sh_layout), not the option at the time it runs."""
+    dev = gpu_device
+    parts = frame.split(":")
+    name, P, deg = parts[0], int(parts[1]), int(parts[2])
+    scene, cam, bg = scenes.config_scene(name.split("-")[0], 0, P=P)
+    means = scene.means3D + (torch.tensor([2.4, 0.0, 0.0]) if "half-outside" in name else 0.0)
+    scene = scenes.Scene(means.contiguous(), scene.scales, scene.rotations, scene.opacities, scene.shs, deg)
+    for extra in parts[3:]:
+        k, v = extra.split("=")
+        _lib.set_option(k, int(v))
+
+    def run(flip_to=None):
+        out, args = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
+        gpix, _ = scenes.l1_target_grad(out[1].cpu(), 13)
+        if flip_to is not None:
+            _lib.set_option("sh_dir_in_backward", flip_to)          # AFTER the forward
+        grads = ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(dev)))
+        return out[0], out[1].clone(), out[2].clone(), [g.clone() for g in grads]
+    _lib.set_option("sh_dir_in_backward", 0)
+    run()                                    # (a half-visible model: the second forward takes the pass over the visible ones)
+    want = run()
+    assert float(want[3][GRAD_NAMES.index("dL_dmeans3D")].abs().max()) > 0
+    _lib.set_option("sh_dir_in_backward", 1)
+    for flip in (None, 0):
+        got = run(flip)
+        _lib.set_option("sh_dir_in_backward", 1)
+        assert got[0] == want[0] and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        for n, a, b in zip(GRAD_NAMES, got[3], want[3]):
+            assert torch.equal(a, b), (n, flip)
+    _lib.set_option("sh_dir_in_backward", 0)
+    got = run(1)                             # rows stored by the forward, option flipped before the backward
+    assert all(torch.equal(a, b) for a, b in zip(got[3], want[3]))
+
+
+def test_sh_direction_derivative_in_the_backward_with_raw_parameters_and_a_shell(gpu_device):
+    """The same through the view-parallel rasterizer on RAW parameters (activations inside the per-Gaussian kernels) and on
+    the C4 shell scene under its occlusion mask (sparsely visible waves): the flat gradient buffer bit for bit."""
+    from frosting_amd.parallel import ViewParallelRasterizer
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("c3", 1, P=200_000)
+    raw = scenes.Scene(scene.means3D, torch.log(scene.scales), scene.rotations * 1.3, torch.log(scene.opacities / (1 - scene.opacities)),
+                       scene.shs, scene.sh_degree)
+    flats = {}
+    for mode in (0, 1):
+        _lib.set_option("sh_dir_in_backward", mode)
+        vpr = ViewParallelRasterizer(raw.to(dev), dev, raw_params=True)
+        for _ in range(2):
+            img, _ = vpr.forward(cam.to(dev), bg.to(dev))
+            gpix, _ = scenes.l1_target_grad(img.cpu(), 7)
+            vpr.exchange.flat.zero_()
+            vpr.backward(gpix.to(dev), 0)
+        flats[mode] = vpr.exchange.flat.clone()
+    assert float(flats[0].abs().max()) > 0 and torch.equal(flats[0], flats[1])
+
+
 def test_radii_may_be_null_like_the_reference(gpu_device):
     """rasterizer.h:54 / rasterizer_impl.cu:228-231,375-377: radii == nullptr -> the op keeps them in its own
     geometry state, forward and backward."""
@@ -1158,3 +1222,4 @@ def test_forward_tile_order_changes_nothing(gpu_device):
             assert a[0] == 0 and torch.equal(a[1], bg.to(gpu_device)[:, None, None].expand_as(a[1]))
         if label == "corner":
             assert int((res[1][4] > 0).sum()) > 0
+

@@ -40,7 +40,7 @@ def test_state_size_queries_and_options():
     _lib.set_option("exact_blend", old)
     # every documented option answers get / set and returns the previous value (include/frosting_rasterizer.h)
     for name, default in (("tight_binning", 0), ("global_bins", 0), ("bwd_waves", 0), ("bwd_seg_log", 0), ("fwd_order", 1), ("counter_mailbox", 1),
-                          ("clear_image_state", 0), ("sort_heavy_on_caller", 1), ("bwd_heavy_first", 1), ("fwd_prefetch", 1), ("sparse_sh", 1), ("profile", 0), ("profile_stage", -1)):
+                          ("clear_image_state", 0), ("sort_heavy_on_caller", 1), ("bwd_heavy_first", 1), ("fwd_prefetch", 1), ("sparse_sh", 1), ("sh_dir_in_backward", 0), ("profile", 0), ("profile_stage", -1)):
         assert _lib.get_option(name) == default, name
         assert _lib.set_option(name, default) == default and _lib.get_option(name) == default, name
     assert _lib.set_option("no_such_option", 1) < 0 and "unknown option" in _lib.last_error()
