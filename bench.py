@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="frg_set_option(NAME, VALUE) before anything runs (tuning experiments; repeatable)")
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
+    ap.add_argument("--composed-mask", action="store_true",
+                    help="C4: the occlusion mask as the composition of torch.ones / cat / matmul, frg_mesh_visible_faces and a torch "
+                         "index (rounds 2-4) instead of the one-call frg_mesh_occlusion_mask (A/B)")
     ap.add_argument("--tight-binning", action="store_true",
                     help="time the whole run with frg_set_option('tight_binning', 1): instances that cannot reach alpha >= "
                          "1/255 anywhere in their tile are dropped when the tile lists are built (outputs bit-identical, "
@@ -313,8 +316,7 @@ def side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, steps
     def mask():
         if shell is None:
             return None
-        fm = M.visible_face_mask(verts_d, faces_d, cam_d.projmatrix, cam.image_height, cam.image_width, ctx)
-        return M.occlusion_mask_from_face_mask(cell_d, fm)
+        return M.occlusion_keep_mask(verts_d, faces_d, cam_d.projmatrix, cam.image_height, cam.image_width, cell_d, 0, ctx)
 
     img, radii = vp.forward(cam_d, bg_d, keep_mask=mask())
     g, _ = scenes.l1_target_grad(img.cpu(), 11)
@@ -451,8 +453,10 @@ def main():
         if shell is None:
             return None
         c_d = c_d or cam_d
-        fm = M.visible_face_mask(verts_d, faces_d, c_d.projmatrix, cam.image_height, cam.image_width, mesh_ctx)
-        return M.occlusion_mask_from_face_mask(cell_d, fm)
+        if args.composed_mask:
+            fm = M.visible_face_mask(verts_d, faces_d, c_d.projmatrix, cam.image_height, cam.image_width, mesh_ctx)
+            return M.occlusion_mask_from_face_mask(cell_d, fm)
+        return M.occlusion_keep_mask(verts_d, faces_d, c_d.projmatrix, cam.image_height, cam.image_width, cell_d, 0, mesh_ctx)
 
     # one pass over this rank's cameras: the fixed loss gradient dL/dimage of every view, and what each view holds
     gpixs, view_V, view_R = [], [], []

@@ -183,6 +183,10 @@ def lib():
     L.frg_mesh_raster_workspace_bytes.argtypes = [i, i, i]
     L.frg_mesh_rasterize.restype = i
     L.frg_mesh_rasterize.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
+    L.frg_mesh_occlusion_workspace_bytes.restype = sz
+    L.frg_mesh_occlusion_workspace_bytes.argtypes = [i, i, i, i]
+    L.frg_mesh_occlusion_mask.restype = i
+    L.frg_mesh_occlusion_mask.argtypes = [i, i, vp, vp, vp, i, i, i, vp, i, vp, vp, vp, sz, vp]
     if hasattr(L, "frg_mesh_visible_faces"):
         L.frg_mesh_visible_faces.restype = i
         L.frg_mesh_visible_faces.argtypes = [i, i, vp, vp, i, i, vp, vp, sz, vp]
@@ -248,7 +252,7 @@ EXPORTED_SYMBOLS = [
     "frg_version", "frg_last_error", "frg_mark_visible", "frg_forward", "frg_backward_workspace_bytes",
     "frg_backward", "frg_set_option", "frg_get_option", "frg_stage_times", "frg_geometry_bytes", "frg_image_bytes",
     "frg_binning_bytes", "frg_geometry_layout", "frg_geometry_layout_n", "frg_image_layout", "frg_binning_layout",
-    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_mesh_visible_faces", "frg_sh_color_grad", "frg_sh_grad_from_views",
+    "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_mesh_visible_faces", "frg_mesh_occlusion_workspace_bytes", "frg_mesh_occlusion_mask", "frg_sh_color_grad", "frg_sh_grad_from_views",
     "frg_pack_grad_rows", "frg_scatter_grad_rows", "frg_adam_step_rows", "frg_adam_step_shard",
     "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_backward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",

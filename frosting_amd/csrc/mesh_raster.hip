@@ -17,6 +17,7 @@
 // pass recomputes the attributes of each pixel's winner.
 #include "../../include/frosting_rasterizer.h"
 #include "frg_common.h"
+#include <algorithm>
 
 namespace frg {
 
@@ -73,6 +74,29 @@ __device__ __forceinline__ TriSetup tri_setup(const float4 v0, const float4 v1, 
 {
     TriSetup t;
     t.ok = false;
+    // bounding box: exact when every vertex is in front of the eye, whole screen otherwise
+    if (v0.w > 1e-6f && v1.w > 1e-6f && v2.w > 1e-6f) {
+        const float nx0 = v0.x / v0.w, nx1 = v1.x / v1.w, nx2 = v2.x / v2.w;
+        const float ny0 = v0.y / v0.w, ny1 = v1.y / v1.w, ny2 = v2.y / v2.w;
+        const float mnx = fminf(nx0, fminf(nx1, nx2)), mxx = fmaxf(nx0, fmaxf(nx1, nx2));
+        const float mny = fminf(ny0, fminf(ny1, ny2)), mxy = fmaxf(ny0, fmaxf(ny1, ny2));
+        if (mxx < -1.f || mnx > 1.f || mxy < -1.f || mny > 1.f) return t;
+        // pixel i centre at ((i + 0.5) / W) * 2 - 1  =>  i = (ndc + 1) * W / 2 - 0.5.  A covered centre lies inside the
+        // vertices' NDC extent: i in [imin, imax].  These float expressions are within ~1e-3 pixel of the true bounds (three
+        // roundings of values below 2^13), so 1/16 pixel of slack keeps the box a superset -- coverage itself is decided
+        // in double by tri_sample.  (Rounds 1-4: a whole pixel of slack on each side and two past the end -- a 2 x 2 pixel
+        // triangle of the C4 shell sampled 36 centres instead of 9.)
+        t.x0 = max(0, (int)floorf((mnx + 1.f) * 0.5f * W - 0.5f - 0.0625f));
+        t.x1 = min(W, (int)floorf((mxx + 1.f) * 0.5f * W - 0.5f + 0.0625f) + 1);
+        t.y0 = max(0, (int)floorf((mny + 1.f) * 0.5f * H - 0.5f - 0.0625f));
+        t.y1 = min(H, (int)floorf((mxy + 1.f) * 0.5f * H - 0.5f + 0.0625f) + 1);
+    } else if (v0.w <= 1e-6f && v1.w <= 1e-6f && v2.w <= 1e-6f) {
+        return t;  // entirely behind the eye
+    } else {
+        t.x0 = 0; t.y0 = 0; t.x1 = W; t.y1 = H;
+    }
+    // (a box without a pixel centre -- sub-pixel triangles between centres, at the poles and the limb -- needs no setup)
+    if (!(t.x1 > t.x0 && t.y1 > t.y0)) return t;
     // det of M = [[x0 x1 x2],[y0 y1 y2],[w0 w1 w2]] (double: it cancels badly for slivers); its sign is the facing
     const double x0 = v0.x, y0 = v0.y, w0 = v0.w, x1 = v1.x, y1 = v1.y, w1 = v1.w, x2 = v2.x, y2 = v2.y, w2 = v2.w;
     const double det = x0 * (y1 * w2 - y2 * w1) + y0 * (x2 * w1 - x1 * w2) + w0 * (x1 * y2 - x2 * y1);
@@ -83,24 +107,7 @@ __device__ __forceinline__ TriSetup tri_setup(const float4 v0, const float4 v1, 
     edge_coeffs(v0, v1, sgn, t.a[2], t.b[2], t.c[2]);
     t.z[0] = v0.z; t.z[1] = v1.z; t.z[2] = v2.z;
     t.w[0] = v0.w; t.w[1] = v1.w; t.w[2] = v2.w;
-    // bounding box: exact when every vertex is in front of the eye, whole screen otherwise
-    if (v0.w > 1e-6f && v1.w > 1e-6f && v2.w > 1e-6f) {
-        const float nx0 = v0.x / v0.w, nx1 = v1.x / v1.w, nx2 = v2.x / v2.w;
-        const float ny0 = v0.y / v0.w, ny1 = v1.y / v1.w, ny2 = v2.y / v2.w;
-        const float mnx = fminf(nx0, fminf(nx1, nx2)), mxx = fmaxf(nx0, fmaxf(nx1, nx2));
-        const float mny = fminf(ny0, fminf(ny1, ny2)), mxy = fmaxf(ny0, fmaxf(ny1, ny2));
-        if (mxx < -1.f || mnx > 1.f || mxy < -1.f || mny > 1.f) return t;
-        // pixel i centre at ((i + 0.5) / W) * 2 - 1  =>  i = (ndc + 1) * W / 2 - 0.5; one pixel of slack
-        t.x0 = max(0, (int)floorf((mnx + 1.f) * 0.5f * W - 0.5f) - 1);
-        t.x1 = min(W, (int)ceilf((mxx + 1.f) * 0.5f * W - 0.5f) + 2);
-        t.y0 = max(0, (int)floorf((mny + 1.f) * 0.5f * H - 0.5f) - 1);
-        t.y1 = min(H, (int)ceilf((mxy + 1.f) * 0.5f * H - 0.5f) + 2);
-    } else if (v0.w <= 1e-6f && v1.w <= 1e-6f && v2.w <= 1e-6f) {
-        return t;  // entirely behind the eye
-    } else {
-        t.x0 = 0; t.y0 = 0; t.x1 = W; t.y1 = H;
-    }
-    t.ok = t.x1 > t.x0 && t.y1 > t.y0;
+    t.ok = true;
     return t;
 }
 
@@ -216,19 +223,81 @@ mesh_mark_kernel(size_t n, const unsigned long long* __restrict__ depth, unsigne
     if (key != ~0ull) face_visible[(uint32_t)key] = 1;      // (several pixels store the same byte: benign)
 }
 
+// frg_mesh_occlusion_mask: everything the z-buffer pass needs, in one launch -- the clip-space vertices [v,1] @ M (the
+// caller's torch.ones + torch.cat + matmul: frosting_utils/nvdiffrast.py:44-50), the cleared depth plane, the cleared face
+// marks and the cleared list of big triangles.  A fused multiply-add per term in the order of the sum over k, as a GEMM's
+// inner loop accumulates them.
+__global__ void __launch_bounds__(256)
+mesh_prepare_kernel(size_t n, unsigned long long* __restrict__ depth, uint32_t* __restrict__ big_count, int V,
+                    const float* __restrict__ verts, const float* __restrict__ M, float4* __restrict__ pos, int F,
+                    unsigned char* __restrict__ face_visible)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) depth[i] = ~0ull;
+    if (i == 0) *big_count = 0;
+    if (i < (size_t)F) face_visible[i] = 0;
+    if (i < (size_t)V) {
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = fmaf(1.0f, M[12 + j], fmaf(z, M[8 + j], fmaf(y, M[4 + j], x * M[j])));
+        pos[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// keep[i] = face_visible[cell_of_point[i]] for the shell's Gaussians, 1 for the background ones behind them
+// (frosting_model.py:1564-1586: _index_mask[self._point_cell_indices] ++ ones)
+#define MESH_KEEP_PER_THREAD 8
+__global__ void __launch_bounds__(256)
+mesh_keep_kernel(int n_shell, const long long* __restrict__ cell_of_point, int F, const unsigned char* __restrict__ face_visible,
+                 int n_total, unsigned char* __restrict__ keep)
+{
+    // eight consecutive Gaussians per thread: the indices as four 16-byte loads, the marks from the (cache-resident) face
+    // table, the flags as one 8-byte store where the block is whole and both arrays are aligned for it
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * MESH_KEEP_PER_THREAD;
+    if (i0 >= n_total) return;
+    auto one = [&](long long i) -> unsigned char {
+        if (i >= n_shell) return 1;
+        long long c = cell_of_point[i];
+        if (c < 0) c += F;                                   // (torch indexing: negative indices count from the end)
+        return (c >= 0 && c < F) ? face_visible[c] : 0;
+    };
+    const bool whole = i0 + MESH_KEEP_PER_THREAD <= n_shell && (reinterpret_cast<uintptr_t>(cell_of_point) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(keep) & 7) == 0;
+    if (whole) {
+        long long c[MESH_KEEP_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < MESH_KEEP_PER_THREAD; k += 2) {
+            const longlong2 v = *reinterpret_cast<const longlong2*>(cell_of_point + i0 + k);
+            c[k] = v.x; c[k + 1] = v.y;
+        }
+        unsigned long long out = 0;
+#pragma unroll
+        for (int k = 0; k < MESH_KEEP_PER_THREAD; k++) {
+            long long ck = c[k] < 0 ? c[k] + F : c[k];
+            const unsigned char m = (ck >= 0 && ck < F) ? face_visible[ck] : 0;
+            out |= (unsigned long long)m << (8 * k);
+        }
+        *reinterpret_cast<unsigned long long*>(keep + i0) = out;
+        return;
+    }
+    for (long long i = i0; i < i0 + MESH_KEEP_PER_THREAD && i < n_total; i++) keep[i] = one(i);
+}
+
 // the z-buffer pass shared by both entry points
 static void launch_depth_pass(int V, int F, const float4* p4, const int* tri, int width, int height, char* workspace, hipStream_t s,
-                              unsigned long long*& depth)
+                              unsigned long long*& depth, bool prepared = false)
 {
     const size_t N = (size_t)width * height;
     depth = reinterpret_cast<unsigned long long*>(workspace);
     uint32_t* big_list = reinterpret_cast<uint32_t*>(workspace + align_up(N * 8, 256));
     uint32_t* big_count = reinterpret_cast<uint32_t*>(workspace + align_up(N * 8, 256) + align_up((size_t)(F > 0 ? F : 1) * 4, 256));
-    hipLaunchKernelGGL(mesh_clear_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, big_count);
+    if (!prepared) hipLaunchKernelGGL(mesh_clear_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, big_count);
     if (F > 0) {
         hipLaunchKernelGGL(mesh_raster_small_kernel, dim3((F + 255) / 256), dim3(256), 0, s, V, F, p4, tri, width, height,
                            depth, big_list, big_count);
-        hipLaunchKernelGGL(mesh_raster_big_kernel, dim3(2048), dim3(256), 0, s, V, p4, tri, width, height, depth,
+        // (usually there is no such triangle: a grid the GPU holds at once, the workgroups stride)
+        hipLaunchKernelGGL(mesh_raster_big_kernel, dim3(1024), dim3(256), 0, s, V, p4, tri, width, height, depth,
                            big_list, big_count);
     }
 }
@@ -250,6 +319,41 @@ int frg_mesh_visible_faces(int V, int F, const float* pos, const int* tri, int w
     frg::launch_depth_pass(V, F, reinterpret_cast<const float4*>(pos), tri, width, height, workspace, s, depth);
     const size_t N = (size_t)width * height;
     hipLaunchKernelGGL(frg::mesh_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, face_visible);
+    return hipGetLastError() == hipSuccess ? FRG_OK : FRG_EHIP;
+}
+
+size_t frg_mesh_occlusion_workspace_bytes(int V, int F, int width, int height)
+{
+    return frg_mesh_raster_workspace_bytes(F, width, height) + frg::align_up((size_t)(V > 0 ? V : 1) * 16, 256);
+}
+
+int frg_mesh_occlusion_mask(int V, int F, const float* verts, const float* full_proj_transform, const int* tri, int width, int height,
+                            int n_shell, const long long* cell_of_point, int n_background, unsigned char* keep,
+                            unsigned char* face_visible, char* workspace, size_t workspace_bytes, void* hip_stream)
+{
+    if (V < 0 || F < 0 || width <= 0 || height <= 0 || n_shell < 0 || n_background < 0) return FRG_EINVAL;
+    if ((long long)n_shell + n_background > 0x7fffffffLL) return FRG_EINVAL;
+    if ((F > 0 && (!verts || !full_proj_transform || !tri || !face_visible)) || (n_shell > 0 && !cell_of_point) ||
+        (n_shell + n_background > 0 && !keep))
+        return FRG_EINVAL;
+    if (!workspace || workspace_bytes < frg_mesh_occlusion_workspace_bytes(V, F, width, height)) return FRG_EALLOC;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t N = (size_t)width * height;
+    const size_t raster_bytes = frg_mesh_raster_workspace_bytes(F, width, height);
+    float4* p4 = reinterpret_cast<float4*>(workspace + raster_bytes);
+    if (F > 0) {
+        unsigned long long* depth = reinterpret_cast<unsigned long long*>(workspace);
+        uint32_t* big_count = reinterpret_cast<uint32_t*>(workspace + frg::align_up(N * 8, 256) + frg::align_up((size_t)F * 4, 256));
+        const size_t items = std::max(N, std::max((size_t)V, (size_t)F));
+        hipLaunchKernelGGL(frg::mesh_prepare_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, N, depth, big_count, V, verts,
+                           full_proj_transform, p4, F, face_visible);
+        frg::launch_depth_pass(V, F, p4, tri, width, height, workspace, s, depth, true);
+        hipLaunchKernelGGL(frg::mesh_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, depth, face_visible);
+    }
+    const int n_total = n_shell + n_background;
+    if (n_total > 0)
+        hipLaunchKernelGGL(frg::mesh_keep_kernel, dim3((unsigned)((n_total + 256 * MESH_KEEP_PER_THREAD - 1) / (256 * MESH_KEEP_PER_THREAD))), dim3(256), 0, s, n_shell, cell_of_point, F,
+                           face_visible, n_total, keep);
     return hipGetLastError() == hipSuccess ? FRG_OK : FRG_EHIP;
 }
 

@@ -121,6 +121,35 @@ def visible_face_mask(verts, faces, full_proj_transform, height, width, glctx=No
     return mask
 
 
+def occlusion_keep_mask(verts, faces, full_proj_transform, height, width, point_cell_indices, n_background=0, glctx=None,
+                        return_face_mask=False):
+    """The keep mask of one frame in ONE native call (frg_mesh_occlusion_mask): what
+    occlusion_mask_from_face_mask(point_cell_indices, visible_face_mask(verts, faces, full_proj_transform, ...), n_background)
+    composes from torch.ones / cat / matmul, the z-buffer pass and a torch index (frosting_model.py:1524-1539, 1564-1586) --
+    five back-to-back launches instead of nine with host work between them.  bool [len(point_cell_indices) + n_background]."""
+    v = verts.detach().to(torch.float32).contiguous()
+    if not v.is_cuda:
+        raise RuntimeError("frosting_amd.mesh.occlusion_keep_mask needs ROCm device tensors (no CPU path)")
+    dev = v.device
+    t = faces.detach().to(device=dev, dtype=torch.int32).contiguous()
+    m = full_proj_transform.detach().to(device=dev, dtype=torch.float32).contiguous()
+    cells = point_cell_indices.detach().to(device=dev, dtype=torch.int64).contiguous()
+    V, F, H, W, n_shell = v.shape[0], t.shape[0], int(height), int(width), cells.shape[0]
+    L = _lib.lib()
+    face_mask = torch.empty(F, dtype=torch.bool, device=dev)
+    keep = torch.empty(n_shell + int(n_background), dtype=torch.bool, device=dev)
+    ctx = glctx if isinstance(glctx, RasterizeGLContext) else RasterizeGLContext()
+    work = ctx.workspace(int(L.frg_mesh_occlusion_workspace_bytes(V, F, W, H)), dev)
+    ptr = lambda x: C.c_void_p(x.data_ptr()) if x.numel() else None
+    with torch.cuda.device(dev):
+        rc = L.frg_mesh_occlusion_mask(V, F, ptr(v), ptr(m), ptr(t), W, H, n_shell, ptr(cells), int(n_background), ptr(keep),
+                                       ptr(face_mask), C.c_void_p(work.data_ptr()), work.numel(),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(f"frg_mesh_occlusion_mask failed ({rc}): {_lib.last_error()}")
+    return (keep, face_mask) if return_face_mask else keep
+
+
 def occlusion_mask_from_face_mask(point_cell_indices, face_mask, n_background=0):
     """occlusion_mask() for a precomputed boolean face mask."""
     keep = face_mask[point_cell_indices]

@@ -346,6 +346,21 @@ int frg_mesh_rasterize(int V, int F, const float* pos, const int* tri, int width
 int frg_mesh_visible_faces(int V, int F, const float* pos, const int* tri, int width, int height,
                            unsigned char* face_visible, char* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* The per-frame occlusion culling of a Frosting refine step in one call (frosting_model.py:1524-1539 visible faces of the
+ * shell's base mesh, :1564-1586 the per-Gaussian mask; frosting_utils/nvdiffrast.py:44-53 the clip-space vertices): from
+ * the mesh's vertices verts [V,3], the camera's full_proj_transform (16 floats, row-major, applied as [v,1] @ M) and the
+ * cell of every shell Gaussian (cell_of_point [n_shell], int64 as torch indexes) to
+ *   face_visible [F]   as frg_mesh_visible_faces writes it,
+ *   keep [n_shell + n_background] = face_visible[cell_of_point[i]] for the shell's Gaussians, 1 for the background ones --
+ * the keep_mask of frg_forward_ex.  Five launches, no host work between them: vertex transform + the clears, the two
+ * z-buffer passes, the marks, the gather (the composition of torch.ones / cat / matmul, frg_mesh_visible_faces and the
+ * torch index it replaces is nine launches: 105 -> 45 us per C4 frame).  The clip-space positions are one fused
+ * multiply-add per term in the order of the sum; the workspace also holds them (frg_mesh_occlusion_workspace_bytes). */
+size_t frg_mesh_occlusion_workspace_bytes(int V, int F, int width, int height);
+int frg_mesh_occlusion_mask(int V, int F, const float* verts, const float* full_proj_transform, const int* tri, int width, int height,
+                            int n_shell, const long long* cell_of_point, int n_background, unsigned char* keep,
+                            unsigned char* face_visible, char* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* ---- view-parallel gradient exchange helpers ---------------------------------------
  * No counterpart in the (single-GPU) reference; SURVEY.md 8(e).  The per-view SH gradient
  * is rank one per Gaussian, dL_dsh_v[i][ch] = basis_i(normalize(mean - campos_v)) * dRGB_v[ch]

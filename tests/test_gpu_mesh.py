@@ -177,6 +177,42 @@ def test_occlusion_culling_mask_c4_shape(gpu_device):
     assert abs(keep[:P].float().mean().item() - frac) < 0.02
 
 
+def test_occlusion_keep_mask_in_one_call_equals_the_composition(gpu_device):
+    """frg_mesh_occlusion_mask (vertex transform + clears, z-buffer, marks, gather in five launches) against the composition it
+    replaces -- torch.ones / cat / matmul, frg_mesh_visible_faces, the torch index and the background ones
+    (frosting_model.py:1524-1539, 1564-1586): the same faces and the same keep mask on the full C4 mesh from two cameras,
+    on a small mesh with background Gaussians and negative cell indices, and on the degenerate sizes.  The clip-space
+    vertices it forms differ from the matmul's in no bit (reported if they ever do: the mask is what is asserted)."""
+    dev = gpu_device
+    cfg = scenes.CONFIGS["c4"]
+    verts, faces = scenes.sphere_mesh(cfg["n_lat"], cfg["n_lon"])
+    H, W = cfg["height"], cfg["width"]
+    g = torch.Generator().manual_seed(3)
+    cell = torch.randint(0, faces.shape[0], (500_000,), generator=g)
+    ctx = M.RasterizeGLContext()
+    for view in (0, 5):
+        cam = scenes.ring_camera(view, W, H, cfg["fx"], cfg["fy"])
+        fm = M.visible_face_mask(verts.to(dev), faces.to(dev), cam.projmatrix.to(dev), H, W)
+        want = M.occlusion_mask_from_face_mask(cell.to(dev), fm, n_background=77)
+        keep, fm1 = M.occlusion_keep_mask(verts.to(dev), faces.to(dev), cam.projmatrix.to(dev), H, W, cell.to(dev), 77, ctx, return_face_mask=True)
+        assert keep.dtype == torch.bool and keep.shape == want.shape
+        ndiff = int((fm1 != fm).sum())
+        assert ndiff == 0, f"view {view}: {ndiff} faces differ between the fused and the composed path"
+        assert torch.equal(keep, want) and keep[-77:].all()
+        assert 0.2 < float(keep[:-77].float().mean()) < 0.45
+    # a small mesh, cells given from the end (torch's negative indices), no background
+    cam = scenes.ring_camera(2, 400, 264, 333.5, 333.5)
+    v, f = sphere_mesh(40, 80)
+    cells = torch.randint(-f.shape[0], f.shape[0], (10_000,), generator=g)
+    fm = M.visible_face_mask(v.to(dev), f.to(dev), cam.projmatrix.to(dev), 264, 400)
+    keep = M.occlusion_keep_mask(v.to(dev), f.to(dev), cam.projmatrix.to(dev), 264, 400, cells.to(dev), 0)
+    assert torch.equal(keep, fm[cells.to(dev)])
+    # no Gaussians; no faces
+    assert M.occlusion_keep_mask(v.to(dev), f.to(dev), cam.projmatrix.to(dev), 264, 400, cells[:0].to(dev), 0).numel() == 0
+    none = M.occlusion_keep_mask(v.to(dev), f[:0].to(dev), cam.projmatrix.to(dev), 264, 400, cells[:0].to(dev), 5)
+    assert none.shape[0] == 5 and none.all()
+
+
 def test_nvdiffrast_module_shim(gpu_device):
     M.install_as_nvdiffrast()
     import nvdiffrast.torch as dr
