@@ -200,6 +200,16 @@ def test_occlusion_keep_mask_in_one_call_equals_the_composition(gpu_device):
         assert ndiff == 0, f"view {view}: {ndiff} faces differ between the fused and the composed path"
         assert torch.equal(keep, want) and keep[-77:].all()
         assert 0.2 < float(keep[:-77].float().mean()) < 0.45
+        # the clip-space vertices it formed (behind the raster's part of the workspace) against the matmul's
+        from frosting_amd import _lib
+        V, F = verts.shape[0], faces.shape[0]
+        off = int(_lib.lib().frg_mesh_raster_workspace_bytes(F, W, H))
+        p4 = ctx._work[off:off + V * 16].view(torch.float32).view(V, 4)
+        pos = M.clip_space_vertices(verts.to(dev), cam.projmatrix.to(dev))[0]
+        nbits = int((p4 != pos).sum())
+        print(f"view {view}: clip-space vertices, fused multiply-adds vs matmul: {nbits} of {4 * V} floats differ"
+              + (f", max |diff| {float((p4 - pos).abs().max()):.3g}" if nbits else ""))
+        assert torch.allclose(p4, pos, rtol=2e-6, atol=1e-6)
     # a small mesh, cells given from the end (torch's negative indices), no background
     cam = scenes.ring_camera(2, 400, 264, 333.5, 333.5)
     v, f = sphere_mesh(40, 80)
