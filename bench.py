@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="frg_set_option(NAME, VALUE) before anything runs (tuning experiments; repeatable)")
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents (no roofline object)")
+    ap.add_argument("--keep-for-backward", action="store_true",
+                    help="C2 (forward only): the plain forward, which leaves checkpoints and work items for a backward, instead of "
+                         "frg_forward_args::forward_only (A/B)")
     ap.add_argument("--composed-mask", action="store_true",
                     help="C4: the occlusion mask as the composition of torch.ones / cat / matmul, frg_mesh_visible_faces and a torch "
                          "index (rounds 2-4) instead of the one-call frg_mesh_occlusion_mask (A/B)")
@@ -323,7 +326,7 @@ def side_config(name, dev, torch, scenes, M, ViewParallelRasterizer, _lib, steps
     g = g.to(dev)
 
     def step():
-        vp.forward(cam_d, bg_d, keep_mask=mask())
+        vp.forward(cam_d, bg_d, keep_mask=mask(), forward_only=not backward)    # (C2 is a forward-only config: frg_forward_args::forward_only)
         if backward:
             vp.backward(g, 0)
 
@@ -490,7 +493,7 @@ def main():
         k = counter[0] % n_views if cycle[0] else 0      # this step's camera
         c_d, g_d = cams_d[k], gpixs[k]
         counter[0] += 1
-        vpr.forward(c_d, bg_d, keep_mask=cull_mask(c_d))
+        vpr.forward(c_d, bg_d, keep_mask=cull_mask(c_d), forward_only=not do_backward and not args.keep_for_backward)
         if not do_backward:
             vpr.finish()
             return

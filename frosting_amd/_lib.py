@@ -46,17 +46,24 @@ class ForwardArgs(C.Structure):
                 ("shell_logits", C.c_void_p), ("shell_cell_verts", C.c_void_p), ("shell_cells", C.c_void_p),
                 # per-call modes: 0 = the process-wide frg_set_option value, k + 1 = value k for this call
                 ("exact_blend", C.c_int), ("tight_binning", C.c_int), ("async_sh", C.c_int),
-                ("shell_bary_mode", C.c_int)]
+                ("shell_bary_mode", C.c_int),
+                # no backward will follow: nothing is kept for one
+                ("forward_only", C.c_int)]
 
 
 def mode_fields(modes) -> dict:
     """{'exact_blend': 0|1, 'tight_binning': 0|1, 'async_sh': 0..3} (any subset, or None) -> the per-call mode fields
     of frg_forward_args (0 = process default, k + 1 = value k)."""
     out = {"exact_blend": 0, "tight_binning": 0, "async_sh": 0}
+    forward_only = 0
     for k, v in (modes or {}).items():
+        if k == "forward_only":          # a plain 0 | 1 field, no process-wide form
+            forward_only = int(bool(v))
+            continue
         if k not in out:
             raise KeyError(f"unknown per-call mode '{k}'")
         out[k] = int(v) + 1
+    out["forward_only"] = forward_only
     return out
 
 

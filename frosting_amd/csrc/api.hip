@@ -208,6 +208,7 @@ struct HostMail {
 };
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
+std::atomic<int> g_sh_no_dir{0};           // option "sh_dir_in_backward"
 std::atomic<int> g_sparse_sh{1};            // option "sparse_sh": the SH pass over the visible Gaussians only, where a view sees a part of the model
 std::atomic<int> g_bwd_heavy_first{1};
 std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
@@ -218,17 +219,24 @@ std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every fo
 // forward, not whatever frg_set_option says by then.  A ring of kFwdNotes entries: with more forwards than that
 // outstanding the oldest are forgotten -- their backward then launches both forms of the per-Gaussian backward (as if
 // nothing had been posted) and takes the process-wide blend mode.  The pinned mailboxes are never freed.
-struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; int rendered = -1; };
+struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; int rendered = -1; bool fwd_only = false; };
 constexpr int kFwdNotes = 64;
 std::mutex g_heavy_mu;
 FwdNote g_fwd_notes[kFwdNotes];
 unsigned g_fwd_next = 0;
 // a forward starts on `geom`: whatever an earlier forward posted about this buffer is void now
-void note_forward(const void* geom, int exact)
+void note_forward(const void* geom, int exact, bool fwd_only)
 {
     std::lock_guard<std::mutex> lk(g_heavy_mu);
-    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = nullptr; n.seq = 0; n.exact = exact; n.rendered = -1; return; }
-    g_fwd_notes[g_fwd_next++ % kFwdNotes] = FwdNote{geom, nullptr, 0, exact, -1};
+    for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = nullptr; n.seq = 0; n.exact = exact; n.rendered = -1; n.fwd_only = fwd_only; return; }
+    g_fwd_notes[g_fwd_next++ % kFwdNotes] = FwdNote{geom, nullptr, 0, exact, -1, fwd_only};
+}
+// the forward that last filled `geom` was told that no backward would follow (frg_forward_args::forward_only)
+bool forward_was_forward_only(const void* geom)
+{
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    for (const auto& n : g_fwd_notes) if (n.geom == geom) return n.fwd_only;
+    return false;
 }
 // the blocking forward on `geom` rendered R instances (a deferred forward does not know)
 void note_rendered(const void* geom, int R)
@@ -408,6 +416,7 @@ thread_local BwdSide g_bwd_side;
 // Modes of one forward: each is the per-call value of frg_forward_args when given, else the process-wide option.
 struct FwdModes {
     int exact, tight, async_sh;
+    int fwd_only = 0;     // frg_forward_args::forward_only (per call only: there is no process-wide form)
     static int pick(int field, int max_value, int fallback) { return field >= 1 && field <= max_value + 1 ? field - 1 : fallback; }
 };
 int exact_blend();
@@ -426,10 +435,11 @@ frg::ViewParams make_view(int P, int D, int M, int width, int height, float tan_
     vp.D = D; vp.M = M;
     vp.tight = tight;
     vp.sparse_sh = 0;
+    vp.sh_no_dir = 0;
     return vp;
 }
 
-FwdModes default_modes() { return FwdModes{exact_blend(), g_tight_binning.load(), g_async_sh.load()}; }
+FwdModes default_modes() { return FwdModes{exact_blend(), g_tight_binning.load(), g_async_sh.load(), 0}; }
 
 }  // namespace
 
@@ -457,7 +467,7 @@ int frg_set_option(const char* name, int value)
     if (name && strcmp(name, "bwd_heavy_first") == 0) return g_bwd_heavy_first.exchange(value ? 1 : 0);
     if (name && strcmp(name, "bwd_waves") == 0) { const int old = frg::g_bwd_waves; frg::g_bwd_waves = value < 0 ? 0 : value; return old; }
     if (name && strcmp(name, "fwd_order") == 0) { const int old = frg::g_fwd_order; frg::g_fwd_order = value ? 1 : 0; return old; }
-    if (name && strcmp(name, "sh_dir_in_backward") == 0) { const int old = frg::g_sh_no_dir; frg::g_sh_no_dir = value ? 1 : 0; return old; }
+    if (name && strcmp(name, "sh_dir_in_backward") == 0) return g_sh_no_dir.exchange(value ? 1 : 0);
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.exchange(value ? 1 : 0);
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) { const int old = frg::g_sort_heavy_on_caller; frg::g_sort_heavy_on_caller = value ? 1 : 0; return old; }
     // timing-experiment knobs: "ablate" and "probe" make kernels skip work or ignore dependencies (WRONG results), so a
@@ -511,7 +521,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "bwd_seg_log") == 0) return g_bwd_seg_log.load();
     if (name && strcmp(name, "bwd_waves") == 0) return frg::g_bwd_waves;
     if (name && strcmp(name, "fwd_order") == 0) return frg::g_fwd_order;
-    if (name && strcmp(name, "sh_dir_in_backward") == 0) return frg::g_sh_no_dir;
+    if (name && strcmp(name, "sh_dir_in_backward") == 0) return g_sh_no_dir.load();
     if (name && strcmp(name, "counter_mailbox") == 0) return g_use_mailbox.load();
     if (name && strcmp(name, "sparse_sh") == 0) return g_sparse_sh.load();
     if (name && strcmp(name, "fwd_prefetch") == 0) return frg::g_fwd_prefetch;
@@ -615,12 +625,13 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     // Will this view see only a part of the model?  With an occlusion mask: yes.  Otherwise: what the previous forward of
     // this thread saw (posted by its scatter) -- the SH pass then streams the rows of the visible Gaussians only.
     vp.sparse_sh = g_sparse_sh.load(std::memory_order_relaxed) && (keep_mask != nullptr || g_mail.sparse_view(P));
+    vp.sh_no_dir = (g_sh_no_dir.load(std::memory_order_relaxed) || md.fwd_only) ? 1 : 0;
     const int T = vp.gx * vp.gy;
 
     char* geom_chunk = geometry_alloc(user, frg_geometry_bytes(P));
     char* img_chunk = image_alloc(user, frg_image_bytes(width, height));
     if (!geom_chunk || !img_chunk) return fail(FRG_EALLOC, "allocation callback returned null");
-    note_forward(geom_chunk, exact);
+    note_forward(geom_chunk, exact, md.fwd_only != 0);
     const frg::GeomState g = frg::GeomState::carve(geom_chunk, P);
     const frg::ImageState img = frg::ImageState::carve(img_chunk, width, height, g_global_bins.load() != 0);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:228-231
@@ -779,9 +790,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     {
         StageScope sc_(ST_BLEND_FWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream), "blend");
+            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream, md.fwd_only != 0), "blend");
         else
-            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream), "blend");
+            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream, md.fwd_only != 0), "blend");
     }
     return R;
 }
@@ -815,12 +826,13 @@ int frg_forward_deferred(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc
 
 int frg_forward_ex(const frg_forward_args* a)
 {
-    // three generations of the struct: up to keep_mask (version 1 callers), with the raw-parameter fields, with the
-    // per-call modes
-    const size_t v1 = offsetof(frg_forward_args, raw_opacities), v2 = offsetof(frg_forward_args, exact_blend);
-    if (!a || (a->struct_size != sizeof(frg_forward_args) && a->struct_size != v1 && a->struct_size != v2))
-        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu (or %zu, %zu)", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_forward_args), v2, v1);
+    // four generations of the struct: up to keep_mask (version 1 callers), with the raw-parameter fields, with the
+    // per-call modes, with forward_only
+    const size_t v1 = offsetof(frg_forward_args, raw_opacities), v2 = offsetof(frg_forward_args, exact_blend),
+                 v3 = offsetof(frg_forward_args, forward_only);
+    if (!a || (a->struct_size != sizeof(frg_forward_args) && a->struct_size != v1 && a->struct_size != v2 && a->struct_size != v3))
+        return fail(FRG_EINVAL, "frg_forward_args: struct_size %zu, this library expects %zu (or %zu, %zu, %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_forward_args), v3, v2, v1);
     if (a->instance_capacity < 0) return fail(FRG_EINVAL, "instance_capacity < 0");
     frg::RawInputs rw;
     if (a->struct_size >= v2) {
@@ -829,6 +841,12 @@ int frg_forward_ex(const frg_forward_args* a)
     }
     FwdModes md = default_modes();
     if (a->struct_size == sizeof(frg_forward_args)) {
+        if (a->forward_only < 0 || a->forward_only > 1) return fail(FRG_EINVAL, "frg_forward_args: forward_only must be 0 or 1");
+        if (a->forward_only && a->instance_capacity > 0)
+            return fail(FRG_EINVAL, "frg_forward_args: forward_only with deferred counters (instance_capacity > 0) is not offered");
+        md.fwd_only = a->forward_only;
+    }
+    if (a->struct_size >= v3) {
         if (a->exact_blend < 0 || a->exact_blend > 2 || a->tight_binning < 0 || a->tight_binning > 2 || a->async_sh < 0 ||
             a->async_sh > 4 || a->shell_bary_mode < 0 || a->shell_bary_mode > 1)
             return fail(FRG_EINVAL, "frg_forward_args: mode out of range (exact_blend %d, tight_binning %d, async_sh %d, shell_bary_mode %d)",
@@ -904,6 +922,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     // R sizes the slots and the backward blend's item list: fewer than the forward rendered would overrun them.  (More is
     // fine -- a deferred forward's capacity: where the forward's checkpoints lie in the binning chunk is taken from what the
     // forward stamped, Counters::carved_R, not from R.)
+    if (forward_was_forward_only(geom_buffer))
+        return fail(FRG_EINVAL, "the forward that filled this geometry buffer was called with forward_only = 1: it kept nothing for a backward");
     {
         const int rendered = forward_rendered(geom_buffer);
         if (rendered >= 0 && R < rendered)

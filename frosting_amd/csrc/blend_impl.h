@@ -236,7 +236,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     for (int sbase = 0; sbase < n && !saturated; sbase += SEG) {
     if (sbase != 0) {
         if (wave_ballot(alive != 0.0f) == 0ull) break;
-        ckpt[((size_t)(rg.x >> seg_log) + (size_t)(sbase >> seg_log)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
+        if (ckpt) ckpt[((size_t)(rg.x >> seg_log) + (size_t)(sbase >> seg_log)) * FRG_TILE_PIX + q * 64 + lane] = make_float4(Tr, C0, C1, C2);
     }
     const int send = min(n, sbase + SEG);
     for (int base = sbase; base < send; base += 64) {
@@ -389,6 +389,10 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
         out_color[plane + pid] = M::mad(Tr, bg[1], C1);
         out_color[2 * plane + pid] = M::mad(Tr, bg[2], C2);
     }
+    // forward_only (ckpt == nullptr, frg_forward_args::forward_only): the frame is complete here -- what follows is kept for a
+    // backward: checkpoints above, final colours, walked depths, cutoff keys, work items.  (The item counters were cleared by
+    // the binning: a backward called all the same finds no item and returns zero gradients.)
+    if (!ckpt) return;
     // how deep this quadrant walked the tile's list
     uint32_t deepest = inside ? last : 0u;
 #pragma unroll
@@ -827,13 +831,13 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 extern int g_fwd_order;       // tuning (frg_set_option("fwd_order")): 1 = forward blend walks the tiles longest list first
 template <bool EXACT>
 static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                     const float* bg, float* out_color, bool prefetch, hipStream_t s)
+                                     const float* bg, float* out_color, bool prefetch, hipStream_t s, bool forward_only = false)
 {
     const int T = vp.gx * vp.gy;
 #define FRG_FWD(PF)                                                                                                        \
     hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,   \
-                       out_color, img.tile_work, b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr,             \
+                       out_color, img.tile_work, forward_only ? nullptr : b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr,             \
                        img.counters->class_count, b.seg_log, img.bwd_cnt, img.bwd_last, img.bwd_cap_b, b.bwd_full,         \
                        (uint32_t)BinningState::full_cap(b.carved_R), img.cutoff, img.counters)
     if (prefetch) FRG_FWD(true); else FRG_FWD(false);

@@ -364,6 +364,7 @@ struct ViewParams {
     int D, M;   // active SH degree, coefficients per channel in memory
     int tight;  // 1: binning keeps only (Gaussian, tile) instances that can reach alpha >= 1/255 in the tile
     int sparse_sh;  // 1: the view is expected to see a part of the model only (occlusion mask, last view's count): SH pass over the visible Gaussians
+    int sh_no_dir;  // 1: the SH pass leaves d(colour)/d(direction) out (option sh_dir_in_backward; a forward_only call): GeomState::sh_layout bit 1
 };
 struct ViewMats {
     float view[16];

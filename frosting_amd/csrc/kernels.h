@@ -23,7 +23,6 @@ hipError_t launch_scan(int P, const ViewParams& vp, const GeomState& g, const Im
 hipError_t launch_scatter(int P, const ViewParams& vp, const int* radii, const GeomState& g, const ImageState& img,
                           const BinningState& b, hipStream_t s, int ablate = 0, Mailbox* mail = nullptr, uint32_t seq = 0);
 extern int g_rows_grid;   // workgroups of the row-ordered scatter (tuning)
-extern int g_sh_no_dir;   // 1: the forward's SH pass leaves d(colour)/d(direction) to the per-Gaussian backward
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t s);
 
 // class_count: host copy of the per-class tile counts, or nullptr when they are only known on the
@@ -44,10 +43,11 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
                             uint32_t* big_hist, uint32_t* big_plan, uint32_t R, int max_tile_count, int index_bits,
                             uint32_t* point_list, hipStream_t stream);
 
+// forward_only: no backward will follow (frg_forward_args::forward_only) -- no checkpoints, no final colours, no work items
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, float* out_color, hipStream_t s);
+                                  const float* bg, float* out_color, hipStream_t s, bool forward_only = false);
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, float* out_color, hipStream_t s);
+                                 const float* bg, float* out_color, hipStream_t s, bool forward_only = false);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 // R: the instance count the caller sized the slots for (bounds the number of work items: the grid)
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,

@@ -363,7 +363,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       uint32_t* __restrict__ bin_matrix, uint32_t* __restrict__ tile_count,
                       uint32_t* __restrict__ block_sums, Counters* __restrict__ counters, int prefiltered,
                       uint32_t* __restrict__ row_matrix, int band_w, int nbands, float* __restrict__ sh_dir,
-                      uint32_t* __restrict__ heavy_waves, uint32_t* __restrict__ sh_layout, int sh_no_dir)
+                      uint32_t* __restrict__ heavy_waves, uint32_t* __restrict__ sh_layout)
 {
     constexpr bool SH16 = SHMODE == SH_STREAM || SHMODE == SH_STREAM_SPARSE;
     constexpr bool TIGHT = BINMODE == BIN_TIGHT, CELLS = BINMODE == BIN_CELLS;
@@ -391,7 +391,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         heavy_waves[0] = 0;   // (filled where point_offsets is finished)
         // bit 0: sh_dir rows by rank in sparsely visible waves; bit 1: no sh_dir rows at all (only the float4-streamed pass has that form)
-        if (SHMODE != SH_DEFER) *sh_layout = (SHMODE == SH_STREAM_SPARSE ? 1u : 0u) | ((sh_no_dir && SHMODE != SH_INLINE) ? 2u : 0u);    // (SH_DEFER: sh_color_kernel says)
+        if (SHMODE != SH_DEFER) *sh_layout = (SHMODE == SH_STREAM_SPARSE ? 1u : 0u) | ((vp.sh_no_dir && SHMODE != SH_INLINE) ? 2u : 0u);    // (SH_DEFER: sh_color_kernel says)
     }
     // the chunk totals of this workgroup's chunks are accumulated with atomics below
     for (int c = blockIdx.x + (int)threadIdx.x * (int)gridDim.x; c < nchunks; c += FRG_BIN_THREADS * (int)gridDim.x) block_sums[c] = 0;
@@ -454,7 +454,7 @@ preprocess_fwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                 // the direction of every Gaussian of the wave waits in the (still empty) colour slot of its record
                 const float4 col = sh_stream_wave<SHMODE == SH_STREAM_SPARSE>(vp.D, reinterpret_cast<const float4*>(shs) + (size_t)idx0 * 12, min(64, P - idx0),
                                                   touched != 0, dir, sh_lds + wave * (PRE_SUB * PRE_ROW_F4),
-                                                  rec_lds + (wave * 64) * FRG_REC + 2, FRG_REC, sh_dir + (size_t)idx0 * 9, !sh_no_dir);
+                                                  rec_lds + (wave * 64) * FRG_REC + 2, FRG_REC, sh_dir + (size_t)idx0 * 9, !vp.sh_no_dir);
                 (void)lane;
                 rec[2] = touched ? col : make_float4(0.f, 0.f, 0.f, 0.f);
             } else if (touched) {
@@ -1108,7 +1108,6 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 // ---- host launchers -----------------------------------------------------------
 // workgroups of the cell-ordered scatter (tuning knob: frg_set_option("rows_grid")), 2 per CU by default
 int g_rows_grid = 0;     // 0: by the model's size (launch_scatter); > 0: timing experiments
-int g_sh_no_dir = 0;     // 1: the SH pass leaves d(colour)/d(direction) to the per-Gaussian backward (frg_set_option("sh_dir_in_backward"))
 
 // The scatter runs over cell-ordered records (reorder_kernel + scatter_rows_kernel) in the reference-identical
 // binning mode; tight binning keeps the scatter in the caller's order (it would evaluate the per-instance tile test in
@@ -1141,7 +1140,7 @@ static hipError_t launch_pre_variant(int P, const ViewParams& vp, const FwdInput
                        in.projmatrix, in.cam_pos, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.cov3D_precomp, in.colors_precomp, in.keep_mask, in.raw, radii, g.xydr, g.conic_opacity, g.rgb_clamped,
                        g.tiles_touched, g.depth_rect, img.bin_matrix, img.tile_count, g.block_sums, img.counters, prefiltered,
-                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves, g.sh_layout, g_sh_no_dir);
+                       BINMODE == BIN_CELLS ? img.row_matrix : nullptr, img.band_w, img.nbands, g.sh_dir, g.heavy_waves, g.sh_layout);
     return hipGetLastError();
 }
 
@@ -1172,11 +1171,11 @@ hipError_t launch_sh_color(int P, const ViewParams& vp, const FwdInputs& in, con
     const dim3 grid((P + SHC_THREADS - 1) / SHC_THREADS), block(SHC_THREADS);
     if (sh_streamable(in, vp)) {
         if (vp.sparse_sh)
-            hipLaunchKernelGGL((sh_color_kernel<true, true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, g_sh_no_dir);
+            hipLaunchKernelGGL((sh_color_kernel<true, true>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, vp.sh_no_dir);
         else
-            hipLaunchKernelGGL((sh_color_kernel<true, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, g_sh_no_dir);
+            hipLaunchKernelGGL((sh_color_kernel<true, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, vp.sh_no_dir);
     } else
-        hipLaunchKernelGGL((sh_color_kernel<false, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, g_sh_no_dir);
+        hipLaunchKernelGGL((sh_color_kernel<false, false>), grid, block, 0, s, P, vp.D, vp.M, in.cam_pos, in.means3D, radii, in.shs, g.rgb_clamped, g.sh_dir, g.sh_layout, vp.sh_no_dir);
     return hipGetLastError();
 }
 

@@ -77,7 +77,7 @@ forward_common(const torch::Tensor& background, const torch::Tensor& means3D, co
                const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
                const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
                const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-               const bool prefiltered, const bool debug, const torch::Tensor* keep_mask)
+               const bool prefiltered, const bool debug, const torch::Tensor* keep_mask, const bool forward_only = false)
 {
     TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");  // rasterize_points.cu:57-59
     TORCH_CHECK(means3D.is_cuda(), "frosting_amd rasterizer: means3D must live on a ROCm device (no CPU path)");
@@ -123,7 +123,8 @@ forward_common(const torch::Tensor& background, const torch::Tensor& means3D, co
     a.hip_stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
     a.instance_capacity = 0;
     a.keep_mask = nullptr;
-    if (keep_mask && keep_mask->defined() && P) {
+    a.forward_only = forward_only ? 1 : 0;
+    if (keep_mask && keep_mask->defined() && P && !(forward_only && keep_mask->numel() == 0)) {   // (the forward-only export takes an empty tensor for "no mask")
         TORCH_CHECK(keep_mask->dim() == 1 && keep_mask->size(0) == P && keep_mask->device() == dev &&
                         (keep_mask->scalar_type() == torch::kBool || keep_mask->scalar_type() == torch::kUInt8),
                     "keep_mask must be a bool / uint8 tensor of shape (num_points,) on the Gaussians' device");
@@ -163,6 +164,21 @@ RasterizeGaussiansMaskedHIP(const torch::Tensor& background, const torch::Tensor
     return forward_common(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
                           &keep_mask);
+}
+
+// the forward of a call no backward will follow (frg_forward_args::forward_only): the 19 arguments + keep_mask (may be empty)
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansForwardOnlyHIP(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                                 const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+                                 const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                                 const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                                 const int image_height, const int image_width, const torch::Tensor& sh, const int degree,
+                                 const torch::Tensor& campos, const bool prefiltered, const bool debug,
+                                 const torch::Tensor& keep_mask)
+{
+    return forward_common(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                          projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                          &keep_mask, true);
 }
 
 // DGR/rasterize_points.h:40-62; returns the reference's eight gradients in its order (rasterize_points.cu:195)
@@ -247,5 +263,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackwardHIP);
     m.def("mark_visible", &markVisibleHIP);
     m.def("rasterize_gaussians_masked", &RasterizeGaussiansMaskedHIP);
+    m.def("rasterize_gaussians_forward_only", &RasterizeGaussiansForwardOnlyHIP);
     m.def("library_version", []() { return frg_version(); });
 }

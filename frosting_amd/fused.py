@@ -57,6 +57,8 @@ class _RasterizeRaw(torch.autograd.Function):
         t = _RasterizeRaw._views(inputs)
         cam = dict(bg=_f32(s.bg), view=_f32(s.viewmatrix), proj=_f32(s.projmatrix), campos=_f32(s.campos))
         modes = _lib.mode_fields(opts.get("modes"))
+        if not any(ctx.needs_input_grad):      # no parameter needs a gradient (or torch.no_grad()): nothing is kept for a backward
+            modes["forward_only"] = 1
         bary_mode = 0 if opts.get("use_softmax_for_bary_coords", True) else 1
         with torch.cuda.device(dev):
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)

@@ -625,10 +625,11 @@ class ViewParallelRasterizer:
                 ex.set_sh_context(self.scene.means3D, self.scene.sh_degree)
         self.exchange = self.exchanges[0]
 
-    def forward(self, cam, bg, deferred=None, keep_mask=None):
+    def forward(self, cam, bg, deferred=None, keep_mask=None, forward_only=False):
         """Render one view.  With deferred counters the returned image is valid only if the
         following finish() returns True.  keep_mask (bool / uint8 [P], optional): Frosting's occlusion
-        culling as a skip flag (frg_forward_ex)."""
+        culling as a skip flag (frg_forward_ex).  forward_only: no backward() will follow this view
+        (frg_forward_args::forward_only; not with deferred counters)."""
         L = _lib.lib()
         s = self.scene
         H, W = cam.image_height, cam.image_width
@@ -636,7 +637,9 @@ class ViewParallelRasterizer:
             self.out_color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         use_deferred = (self.deferred_counters if deferred is None else deferred) and self.capacity > 0
-        if keep_mask is not None or self.raw_params:
+        if forward_only and use_deferred:
+            raise RuntimeError("forward_only is not offered with deferred counters")
+        if keep_mask is not None or self.raw_params or forward_only:
             v = lambda t: None if t is None else t.data_ptr()
             rawkw = {}
             if self.raw_params:
@@ -649,7 +652,8 @@ class ViewParallelRasterizer:
                 scale_modifier=1.0, rotations=None if self.raw_params else v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix),
                 projmatrix=v(cam.projmatrix), cam_pos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy),
                 prefiltered=0, out_color=v(self.out_color), radii=v(self.radii), debug=0, hip_stream=stream.value,
-                instance_capacity=self.capacity if use_deferred else 0, keep_mask=v(keep_mask), **rawkw)
+                instance_capacity=self.capacity if use_deferred else 0, keep_mask=v(keep_mask),
+                forward_only=1 if forward_only else 0, **rawkw)
             self._keep_alive = keep_mask
             rc = L.frg_forward_ex(C.byref(a))
         else:

@@ -76,7 +76,8 @@ class _NativeOps:
         view as if culled -- Frosting's occlusion culling without the boolean compaction of every
         per-Gaussian tensor (frosting_scene/frosting_model.py:1564-1586).
         modes (extension, optional dict): per-call forward modes {'exact_blend', 'tight_binning', 'async_sh'} that
-        override the process-wide frg_set_option values for THIS call (frg_forward_args)."""
+        override the process-wide frg_set_option values for THIS call (frg_forward_args); 'forward_only': 1 = no backward
+        will follow, the forward keeps nothing for one (frg_forward_args::forward_only)."""
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
         if not means3D.is_cuda:
@@ -129,6 +130,13 @@ class _NativeOps:
     def rasterize_gaussians_masked(*args):
         """(the 19 arguments of rasterize_gaussians, keep_mask) -- same name as the compiled module's export."""
         return _NativeOps.rasterize_gaussians(*args[:19], keep_mask=args[19])
+
+    @staticmethod
+    def rasterize_gaussians_forward_only(*args):
+        """(the 19 arguments of rasterize_gaussians, keep_mask or an empty tensor): the forward of a call no backward will
+        follow (frg_forward_args::forward_only) -- same name as the compiled module's export."""
+        mask = args[19] if len(args) > 19 and args[19] is not None and args[19].numel() else None
+        return _NativeOps.rasterize_gaussians(*args[:19], keep_mask=mask, modes={"forward_only": 1})
 
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
@@ -228,7 +236,12 @@ def _make_autograd_function(ops):
                            s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh,
                            s.sh_degree, s.campos, s.prefiltered, s.debug)
 
+            # no input needs a gradient (or torch.no_grad()): no backward can follow -- the native forward keeps nothing for one
+            forward_only = not any(ctx.needs_input_grad) and hasattr(ops, "rasterize_gaussians_forward_only")
+
             def run():
+                if forward_only:
+                    return ops.rasterize_gaussians_forward_only(*native_args, keep_mask if keep_mask is not None else torch.empty(0))
                 if keep_mask is None:
                     return ops.rasterize_gaussians(*native_args)
                 return ops.rasterize_gaussians_masked(*native_args, keep_mask)

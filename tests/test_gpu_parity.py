@@ -1223,3 +1223,58 @@ def test_forward_tile_order_changes_nothing(gpu_device):
         if label == "corner":
             assert int((res[1][4] > 0).sum()) > 0
 
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_forward_only_keeps_nothing_for_a_backward_and_changes_no_output_bit(gpu_device, ops, exact):
+    """frg_forward_args::forward_only (ADVICE r04: every forward paid for the backward's checkpoints): the image, radii and
+    instance count of a forward told that no backward follows are those of the plain forward, bit for bit -- on a frame
+    whose tiles cross segment boundaries (checkpoints would be written), through both bindings, under an occlusion mask;
+    a backward on its buffers is refused; the autograd function takes the form by itself when no input needs a gradient
+    (torch.no_grad(), detached parameters) and the plain one as soon as one does."""
+    dev = gpu_device
+    _lib.set_option("exact_blend", exact)
+    base, _, bg = scenes.config_scene("c2", 0, P=200_000)
+    scene = scenes.Scene(base.means3D, base.scales * 2.5, base.rotations, (0.01 + 0.05 * base.opacities).contiguous(), base.shs, 3)
+    cam = scenes.ring_camera(1, 320, 240, 444.0, 444.0)
+    out, args = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
+    st = State(scene.P, cam.image_width, cam.image_height, out[0], out[3], out[4], out[5])
+    assert int((st.ranges[:, 1] - st.ranges[:, 0]).max()) > 1100        # lists longer than two segments of 512
+    want = (out[0], out[1].clone(), out[2].clone(), st.final_T.clone(), st.n_contrib.clone())
+    del st
+    keep = (torch.arange(scene.P, device=dev) % 3 != 0)
+    for mask in (torch.empty(0), keep):
+        fo = ops.rasterize_gaussians_forward_only(*args, mask.to(dev) if mask.numel() else mask)
+        if mask.numel() == 0:
+            st = State(scene.P, cam.image_width, cam.image_height, fo[0], fo[3], fo[4], fo[5])
+            assert fo[0] == want[0] and torch.equal(fo[1], want[1]) and torch.equal(fo[2], want[2])
+            assert torch.equal(st.final_T, want[3]) and torch.equal(st.n_contrib, want[4])
+            del st
+        else:
+            plain = ops.rasterize_gaussians_masked(*args, keep)
+            assert fo[0] == plain[0] and torch.equal(fo[1], plain[1]) and torch.equal(fo[2], plain[2])
+        gpix, _ = scenes.l1_target_grad(fo[1].cpu(), 3)
+        with pytest.raises(RuntimeError, match="forward_only"):
+            ops.rasterize_gaussians_backward(*_bwd_args(args, fo, gpix.to(dev)))
+    # the buffers of a plain forward still serve their backward afterwards (the note belongs to the buffer, not the thread)
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 3)
+    grads = ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(dev)))
+    assert float(grads[GRAD_NAMES.index("dL_dmeans3D")].abs().max()) > 0
+    # the module: no_grad / no leaf -> forward-only by itself, same image; with a leaf the gradients are the plain ones
+    from frosting_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    sc = scene.to(dev)
+    settings = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, bg.to(dev), 1.0,
+                                             cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    kw = dict(means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+              rotations=sc.rotations)
+    r = GaussianRasterizer(settings)
+    with torch.no_grad():
+        img0, radii0 = r(**kw)
+    assert torch.equal(img0, want[1]) and torch.equal(radii0, want[2]) and not img0.requires_grad
+    img1, _ = r(**kw)                                     # no leaf requires a gradient
+    assert torch.equal(img1, want[1]) and not img1.requires_grad
+    leaf = sc.means3D.clone().requires_grad_(True)
+    img2, _ = r(**dict(kw, means3D=leaf))
+    assert torch.equal(img2, want[1])
+    (img2 * gpix.to(dev)).sum().backward()
+    assert torch.equal(leaf.grad, grads[GRAD_NAMES.index("dL_dmeans3D")])

@@ -123,6 +123,19 @@ def test_extended_entry_points_validate_arguments_without_a_gpu():
     a.struct_size = 8                                     # a caller built against another header
     assert L.frg_forward_ex(C.byref(a)) == -1 and "struct_size" in _lib.last_error()
     assert L.frg_forward_ex(None) == -1
+    # four generations of frg_forward_args pass the size check (then fail on their null pointers, not on the size);
+    # forward_only is 0 | 1 and is not offered with deferred counters
+    for field in ("raw_opacities", "exact_blend", "forward_only"):
+        a = _lib.ForwardArgs()
+        a.struct_size = getattr(_lib.ForwardArgs, field).offset
+        assert L.frg_forward_ex(C.byref(a)) < 0 and "struct_size" not in _lib.last_error(), field
+    a = _lib.ForwardArgs()
+    a.struct_size = C.sizeof(_lib.ForwardArgs)
+    a.forward_only = 2
+    assert L.frg_forward_ex(C.byref(a)) == -1 and "forward_only" in _lib.last_error()
+    a.forward_only, a.instance_capacity = 1, 1000
+    assert L.frg_forward_ex(C.byref(a)) == -1 and "deferred" in _lib.last_error()
+    assert _lib.mode_fields({"forward_only": 1, "exact_blend": 1}) == {"exact_blend": 2, "tight_binning": 0, "async_sh": 0, "forward_only": 1}
     # frg_backward_args: three generations, told apart by struct_size (up to shell_*, + exact_blend / shell_bary_mode,
     # + phase); the ctypes mirror is the newest.  P == 0 returns before any pointer is looked at.
     b = _lib.BackwardArgs(P=0, width=8, height=8)
