@@ -203,3 +203,31 @@ def test_bench_self_launches_n_ranks_from_a_bare_shell(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     bench.self_launch_if_needed(bench.parse_args())
     assert not seen
+
+
+def test_ctypes_structs_have_the_headers_layout(tmp_path):
+    """frosting_amd/_lib.py restates frg_forward_args / frg_backward_args field by field: every field of the ctypes
+    structures sits at the offset the C compiler gives it in include/frosting_rasterizer.h, and the sizes agree (a field
+    added to one side only would shift everything behind it silently)."""
+    import ctypes as C
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    lines = []
+    for cname, ct in (("frg_forward_args", _lib.ForwardArgs), ("frg_backward_args", _lib.BackwardArgs)):
+        lines.append(f'printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "frosting_rasterizer.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    want = {}
+    for ln in out:
+        if ln.strip():
+            cname, fname, val = ln.split()
+            want[(cname, fname)] = int(val)
+    for cname, ct in (("frg_forward_args", _lib.ForwardArgs), ("frg_backward_args", _lib.BackwardArgs)):
+        assert C.sizeof(ct) == want[(cname, "sizeof")], cname
+        for fname, _ in ct._fields_:
+            assert getattr(ct, fname).offset == want[(cname, fname)], (cname, fname)
