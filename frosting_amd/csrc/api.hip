@@ -218,9 +218,11 @@ std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every fo
 // backward called without an explicit mode (the reference's 21-argument signature has no place for one) follows ITS
 // forward, not whatever frg_set_option says by then.  A ring of kFwdNotes entries: with more forwards than that
 // outstanding the oldest are forgotten -- their backward then launches both forms of the per-Gaussian backward (as if
-// nothing had been posted) and takes the process-wide blend mode.  The pinned mailboxes are never freed.
+// nothing had been posted) and reads the forward's blend modes back from the image chunk, where the forward blend stamped
+// them (Counters::fwd_flags: one blocking 4-byte copy -- the same path serves buffers that were cloned or restored at another
+// address).  The notes are a convenience that saves that copy, never the only carrier of a mode.  The pinned mailboxes are never freed.
 struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; int rendered = -1; bool fwd_only = false; };
-constexpr int kFwdNotes = 64;
+constexpr int kFwdNotes = 1024;
 std::mutex g_heavy_mu;
 FwdNote g_fwd_notes[kFwdNotes];
 unsigned g_fwd_next = 0;
@@ -231,12 +233,13 @@ void note_forward(const void* geom, int exact, bool fwd_only)
     for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = nullptr; n.seq = 0; n.exact = exact; n.rendered = -1; n.fwd_only = fwd_only; return; }
     g_fwd_notes[g_fwd_next++ % kFwdNotes] = FwdNote{geom, nullptr, 0, exact, -1, fwd_only};
 }
-// the forward that last filled `geom` was told that no backward would follow (frg_forward_args::forward_only)
-bool forward_was_forward_only(const void* geom)
+// the forward that last filled `geom` was told that no backward would follow (frg_forward_args::forward_only): 1 | 0, or
+// -1 when that forward is not remembered
+int forward_was_forward_only(const void* geom)
 {
     std::lock_guard<std::mutex> lk(g_heavy_mu);
-    for (const auto& n : g_fwd_notes) if (n.geom == geom) return n.fwd_only;
-    return false;
+    for (const auto& n : g_fwd_notes) if (n.geom == geom) return n.fwd_only ? 1 : 0;
+    return -1;
 }
 // the blocking forward on `geom` rendered R instances (a deferred forward does not know)
 void note_rendered(const void* geom, int R)
@@ -897,11 +900,6 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  unsigned char* row_live = nullptr)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
-    // the arithmetic of this backward's blend pass: what the caller says (frg_backward_args::exact_blend), else what
-    // the forward that filled these buffers used (the backward recomputes that forward's alpha, T and contributor
-    // tests: the same arithmetic keeps them consistent), else the process-wide option
-    const int noted = (exact_mode == 0 && geom_buffer) ? forward_exact_mode(geom_buffer) : -1;
-    const int exact = FwdModes::pick(exact_mode, 1, noted >= 0 ? noted : exact_blend());
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
     if (P == 0) return FRG_OK;
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !viewmatrix || !projmatrix || !campos)
@@ -922,8 +920,26 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     // R sizes the slots and the backward blend's item list: fewer than the forward rendered would overrun them.  (More is
     // fine -- a deferred forward's capacity: where the forward's checkpoints lie in the binning chunk is taken from what the
     // forward stamped, Counters::carved_R, not from R.)
-    if (forward_was_forward_only(geom_buffer))
-        return fail(FRG_EINVAL, "the forward that filled this geometry buffer was called with forward_only = 1: it kept nothing for a backward");
+    // The arithmetic of this backward's blend pass (the backward recomputes its forward's alpha, T and contributor tests:
+    // the same arithmetic keeps them consistent) and whether that forward kept anything for a backward: what the host
+    // remembers of the forward that last filled geom_buffer -- or, for a buffer it does not know (cloned, offloaded and
+    // restored at another address, more than kFwdNotes forwards ago), what that forward's blend kernel stamped into the image
+    // chunk, read back here with one blocking 4-byte copy.  An explicit frg_backward_args::exact_blend only overrides the
+    // arithmetic.  Never the process-wide option of the moment: that only shapes forwards.
+    int noted_exact = forward_exact_mode(geom_buffer), noted_only = forward_was_forward_only(geom_buffer);
+    if (noted_only < 0 && phase != 2) {
+        uint32_t flags = 0;
+        const frg::ImageState img0 = frg::ImageState::carve(image_buffer, width, height, false);
+        FRG_HIP(hipMemcpyAsync(&flags, &img0.counters->fwd_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+        FRG_HIP(hipStreamSynchronize(stream));
+        if (!(flags & FRG_FWD_STAMPED))
+            return fail(FRG_EINVAL, "the image buffer carries no forward's stamp: these are not the buffers of a completed frg_forward");
+        noted_exact = (flags & FRG_FWD_EXACT) ? 1 : 0;
+        noted_only = (flags & FRG_FWD_ONLY) ? 1 : 0;
+    }
+    const int exact = FwdModes::pick(exact_mode, 1, noted_exact >= 0 ? noted_exact : exact_blend());
+    if (noted_only > 0)
+        return fail(FRG_EINVAL, "the forward that filled these buffers was called with forward_only = 1: it kept nothing for a backward");
     {
         const int rendered = forward_rendered(geom_buffer);
         if (rendered >= 0 && R < rendered)
@@ -1185,6 +1201,10 @@ int frg_adam_step_rows(long long n, float* params, const float* grads, float* ex
             return fail(FRG_EINVAL, "segment %d: %d elements per Gaussian x %d Gaussians exceed its %lld elements", k, segment_width[k], P, segment_ends[k] - begin);
         if (segment_width[k] > 0 && segment_ends[k] - begin > 0xffffffffLL)
             return fail(FRG_EINVAL, "segment %d: a per-Gaussian segment of a masked step holds at most 2^32 elements", k);
+        // the kernel takes four consecutive elements per thread and lets ONE mask look-up stand for all four when the rows of
+        // their segment are a multiple of four elements long: true only if the segment starts on a multiple of four elements
+        if (segment_width[k] > 0 && segment_width[k] % 4 == 0 && begin % 4 != 0)
+            return fail(FRG_EINVAL, "segment %d: rows of %d elements must begin on a multiple of 4 elements (begins at %lld)", k, segment_width[k], begin);
     }
     g_adam_rows.live = row_live; g_adam_rows.P = P;
     for (int k = 0; k < FRG_ADAM_MAX_SEGMENTS; k++) {

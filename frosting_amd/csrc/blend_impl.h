@@ -68,17 +68,7 @@ struct BlendMath<false> {
     // The staging lane folds the -1/2 of the exponent and the log2(e) of exp -> exp2 into the conic once per
     // Gaussian (stage()); per pixel: power' = dx (a' dx + b' dy) + c' dy^2 in log2 units, G = exp2(power').
     // Seven instructions and one v_exp instead of ten and one; `power > 0` keeps its sign.
-    // FRG_AB_* (tools/build_variants.sh, A/B builds only): one ingredient of the default arithmetic at a time replaced by
-    // the EXACT form, to attribute its distance to the float64 gradient ("which instruction").
-#if defined(FRG_AB_POWER)
-    static __device__ __forceinline__ float4 stage(float4 co) { return co; }
-    static __device__ __forceinline__ float power(float x, float y, float4 co, float px, float py, float& dx, float& dy)
-    {
-        dx = x - px; dy = y - py;
-        return -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-    }
-    static __device__ __forceinline__ float expo(float p) { return __builtin_amdgcn_exp2f(1.4426950408889634f * p); }
-#else
+    // (round 5's one-ingredient-at-a-time A/B switches of this arithmetic: profiles/r05_blend_ab_switches.diff)
     static __device__ __forceinline__ float4 stage(float4 co)
     {
         const float l2e = 1.4426950408889634f;
@@ -90,28 +80,9 @@ struct BlendMath<false> {
         const float t = __builtin_fmaf(sc.x, dx, sc.y * dy);
         return __builtin_fmaf(t, dx, (sc.z * dy) * dy);
     }
-#if defined(FRG_AB_EXP)
-    static __device__ __forceinline__ float expo(float p) { return exp2f(p); }          // libm's exp2f instead of the raw v_exp_f32
-#else
     static __device__ __forceinline__ float expo(float p) { return __builtin_amdgcn_exp2f(p); }
-#endif
-#endif
     static __device__ __forceinline__ float mul3(float a, float b, float c) { return a * b * c; }
-#if defined(FRG_AB_RCP)
-    static __device__ __forceinline__ float recip(float x) { return 1.0f / x; }
-#else
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
-#endif
-#if defined(FRG_AB_NOFMA)
-    static __device__ __forceinline__ float mad(float a, float b, float c) { return a * b + c; }
-    static __device__ __forceinline__ float attenuate(float T, float alpha) { return T * (1 - alpha); }
-    static __device__ __forceinline__ void accumulate(float4 c, float alpha, float T, float& C0, float& C1, float& C2)
-    {
-        C0 = mad(c.x * alpha, T, C0);
-        C1 = mad(c.y * alpha, T, C1);
-        C2 = mad(c.z * alpha, T, C2);
-    }
-#else
     static __device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     // T (1 - alpha) as one FMA; the weight alpha T once per pixel and one FMA per channel (four instructions
     // instead of six, one instead of two: 3 of the forward blend's 24 vector instructions per list entry)
@@ -123,7 +94,6 @@ struct BlendMath<false> {
         C1 = __builtin_fmaf(c.y, w, C1);
         C2 = __builtin_fmaf(c.z, w, C2);
     }
-#endif
 };
 
 #define BLEND_THREADS 256   // 4 waves = the 4 quadrants of one tile
@@ -165,7 +135,10 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     __shared__ uint32_t s_deep, s_done;
     if (threadIdx.x == 0) { s_deep = 0u; s_done = 0u; }
     __syncthreads();                   // the only workgroup barrier of the kernel: the four waves start together anyway
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters->bwd_seg_log = (uint32_t)seg_log;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters->bwd_seg_log = (uint32_t)seg_log;
+        counters->fwd_flags = FRG_FWD_STAMPED | (EXACT ? FRG_FWD_EXACT : 0u) | (ckpt ? 0u : FRG_FWD_ONLY);
+    }
     int tile;
     if (class_tiles) {
         // The tiles LONGEST LIST FIRST (the sort's size classes, longest class first, eight descending buckets inside a
@@ -189,11 +162,6 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
-#ifdef FRG_AB_PRIO
-    // A tile's four waves walk its list sequentially: the frame ends with its longest lists (C4: the limb of the shell, 5 000
-    // entries where the mean tile has 800).  Their waves are given issue priority over the short tiles' waves they share a SIMD with.
-    if (n > FRG_AB_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
 
     __shared__ float4 s_a_all[4][64];    // x, y, -, contributor (1-based list position)
     __shared__ float4 s_co_all[4][64];   // conic a, b, c, opacity
@@ -258,54 +226,6 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             col = rgb_clamped[FRG_REC * id];
             hit = quadrant_hit(a.x, a.y, co, qx0, qy0);
         }
-#ifdef FRG_AB_HALVES
-        // LANE-EFFICIENCY EXPERIMENT (an A/B build, not the product path): the quadrant's upper and lower
-        // 8x4 halves cull the staged entries SEPARATELY and walk their own compacted index lists side by side -- lanes 0..31
-        // take entry t of the upper list while lanes 32..63 take entry t of the lower one -- so a trip serves two different
-        // entries and the round takes max(|upper|, |lower|) trips instead of |union|.  Culling is conservative per half, so
-        // every pixel still blends exactly the entries that can reach it, in list order: outputs bit-identical.
-        const bool hit_u = hit && rect_hit_xy<7, 3>(a.x, a.y, co, qx0, qy0);
-        const bool hit_l = hit && rect_hit_xy<7, 3>(a.x, a.y, co, qx0, qy0 + 4);
-        const uint64_t keep_u = wave_ballot(hit_u), keep_l = wave_ballot(hit_l);
-        const int n_u = __popcll(keep_u), n_l = __popcll(keep_l);
-        __shared__ uint32_t s_idx_all[4][2][64];
-        uint32_t* s_iu = s_idx_all[q][0];
-        uint32_t* s_il = s_idx_all[q][1];
-        wave_lds_sync();                          // previous round's readers are done
-        if (hit_u | hit_l) {
-            s_a[lane] = make_float4(a.x, a.y, 0.f, __uint_as_float((uint32_t)(base + lane + 1)));
-            s_co[lane] = M::stage(co);
-            s_rgb[lane] = col;
-        }
-        if (hit_u) s_iu[lanes_before(keep_u, lane)] = (uint32_t)lane;
-        if (hit_l) s_il[lanes_before(keep_l, lane)] = (uint32_t)lane;
-        wave_lds_sync();
-        {
-            const uint32_t* mine = lane < 32 ? s_iu : s_il;
-            const int n_mine = lane < 32 ? n_u : n_l;
-            const int ntrip = max(n_u, n_l);
-            for (int t = 0; t < ntrip; t++) {
-                const bool there = t < n_mine;
-                const uint32_t j = mine[min(t, 63)] & 63u;
-                const float4 ga = s_a[j];
-                const float4 gco = s_co[j];
-                float dx, dy;
-                const float power = M::power(ga.x, ga.y, gco, pxf, pyf, dx, dy);
-                const float alpha = there ? fminf(0.99f, gco.w * M::expo(power)) : 0.0f;
-                const bool keep_px = there & !(power > 0.0f) & !(alpha * alive < 1.0f / 255.0f);
-                const float test_T = M::attenuate(Tr, alpha);
-                const bool stop = keep_px & (test_T < 0.0001f);
-                alive = stop ? 0.0f : alive;
-                if (keep_px & !stop) {
-                    const float4 gc = s_rgb[j];
-                    M::accumulate(gc, alpha, Tr, C0, C1, C2);
-                    Tr = test_T;
-                    last = __float_as_uint(ga.w);
-                }
-                if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
-            }
-        }
-#else
         const uint64_t keep = wave_ballot(hit);
         const int nkeep = __popcll(keep);
         wave_lds_sync();                          // previous round's readers are done
@@ -376,7 +296,6 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
         }
 #endif
-#endif   // FRG_AB_HALVES
     }
     }
 

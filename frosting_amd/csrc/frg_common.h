@@ -120,7 +120,7 @@ __device__ __forceinline__ int sh_slot_of(uint64_t vis, int lane, bool sparse_la
 // ---- image chunk ----------------------------------------------------------
 #define FRG_BWD_LEN_BUCKETS 32   // length buckets of the tiles' last segments (backward blend items, longest first)
 #define FRG_SORT_CLASSES 5    // tile-list size classes of the sort: <=512, <=2048, <=4096, <=8192, >8192
-struct Counters {            // written by the scan kernel, 48 bytes read back by the host
+struct Counters {            // written by the forward's kernels; 56 bytes, posted to / read back by the host
     uint32_t num_rendered;
     uint32_t max_tile_count;
     uint32_t filtered;       // prefiltered assertion (auxiliary.h:154-162)
@@ -136,7 +136,16 @@ struct Counters {            // written by the scan kernel, 48 bytes read back b
     // of the two (a wrong offset would silently read other tiles' checkpoints for every walk deeper than one segment)
     uint32_t carved_R;
     uint32_t bwd_seg_log;    // log2 of the segment length the forward blend left its checkpoints at (stamped by blend_fwd_kernel)
+    // the forward's blend modes, stamped by blend_fwd_kernel: FRG_FWD_STAMPED | FRG_FWD_EXACT (the reference's arithmetic) |
+    // FRG_FWD_ONLY (frg_forward_args::forward_only: nothing was kept for a backward).  A backward whose host side does
+    // not know the forward that filled its buffers (a geometry buffer cloned or restored at another address, a process that
+    // forgot it) reads THIS word back (api.hip) instead of falling back to a process option
+    uint32_t fwd_flags;
 };
+#define FRG_FWD_EXACT 1u
+#define FRG_FWD_ONLY 2u
+#define FRG_FWD_STAMPED 0x80000000u
+static_assert(sizeof(Counters) == 56, "Counters: 14 words (the mailbox's second line is 8 + 56 bytes)");
 // Pinned HOST memory the scan workgroups write with system-scope stores, polled by the forward's host thread: the
 // instance count as soon as the chunk scan has it (the host sizes the binning buffer and enqueues the scatter while the
 // reorder is still running), the full counters when the tile scan is done (the sort's grid sizes).  Replaces the
@@ -146,6 +155,7 @@ struct Mailbox {
     uint32_t seq_r, num_rendered, pad0[14];      // one 64-byte line per stage
     uint32_t seq_c, pad1[1];
     Counters c;                                  // (8 + 56 bytes: the second line)
+#define FRG_MAILBOX_HEAVY_OFFSET 128
     // third post, by the scatter (not waited for): how many 64-Gaussian waves own more than FRG_BWD_HEAVY_SLOTS
     // backward slots -- a backward that finds its forward's post here and reads 0 skips the 16-wave launch of the
     // per-Gaussian backward and its fork / join (~11 us per step at C3)
@@ -154,6 +164,8 @@ struct Mailbox {
     unsigned long long heavy_post;
     uint32_t visible, pad2[13];                 // visible: Counters::num_visible (the next forward's sparse_sh hint only)
 };
+static_assert(offsetof(Mailbox, c) == 72 && offsetof(Mailbox, heavy_post) == FRG_MAILBOX_HEAVY_OFFSET && sizeof(Mailbox) == 192,
+              "Mailbox: one 64-byte line per post");
 __device__ __forceinline__ void mailbox_post(uint32_t* flag, uint32_t seq)
 {
     __threadfence_system();

@@ -744,6 +744,7 @@ __device__ __forceinline__ void scan_tiles(ScanShared& sh, uint32_t* tot, bool o
         c.tight_binning = tight;
         c.num_visible = 0;
         c.carved_R = __hip_atomic_load(&counters->carved_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.bwd_seg_log = 0; c.fwd_flags = 0;     // (the forward blend's stamps: not made yet, and nothing the host reads here)
         for (int k = 0; k < FRG_SORT_CLASSES; k++) c.class_count[k] = sh.cls[k];
         mail->c = c;
         mailbox_post(&mail->seq_c, seq);

@@ -77,7 +77,8 @@ forward_common(const torch::Tensor& background, const torch::Tensor& means3D, co
                const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
                const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
                const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-               const bool prefiltered, const bool debug, const torch::Tensor* keep_mask, const bool forward_only = false)
+               const bool prefiltered, const bool debug, const torch::Tensor* keep_mask, const bool forward_only = false,
+               const int exact_blend = -1)
 {
     TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");  // rasterize_points.cu:57-59
     TORCH_CHECK(means3D.is_cuda(), "frosting_amd rasterizer: means3D must live on a ROCm device (no CPU path)");
@@ -124,7 +125,9 @@ forward_common(const torch::Tensor& background, const torch::Tensor& means3D, co
     a.instance_capacity = 0;
     a.keep_mask = nullptr;
     a.forward_only = forward_only ? 1 : 0;
-    if (keep_mask && keep_mask->defined() && P && !(forward_only && keep_mask->numel() == 0)) {   // (the forward-only export takes an empty tensor for "no mask")
+    TORCH_CHECK(exact_blend >= -1 && exact_blend <= 1, "exact_blend must be -1 (the process option), 0 or 1");
+    a.exact_blend = exact_blend + 1;      // frg_forward_args: 0 = the process-wide option, k + 1 = value k for this call
+    if (keep_mask && keep_mask->defined() && P && keep_mask->numel() != 0) {   // (the forward-only / _ex exports take an empty tensor for "no mask")
         TORCH_CHECK(keep_mask->dim() == 1 && keep_mask->size(0) == P && keep_mask->device() == dev &&
                         (keep_mask->scalar_type() == torch::kBool || keep_mask->scalar_type() == torch::kUInt8),
                     "keep_mask must be a bool / uint8 tensor of shape (num_points,) on the Gaussians' device");
@@ -181,16 +184,18 @@ RasterizeGaussiansForwardOnlyHIP(const torch::Tensor& background, const torch::T
                           &keep_mask, true);
 }
 
-// DGR/rasterize_points.h:40-62; returns the reference's eight gradients in its order (rasterize_points.cu:195)
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
-RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
-                              const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
-                              const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
-                              const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
-                              const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
-                              const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
-                              const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug)
+// exact_blend: -1 = the arithmetic of the forward that filled the buffers (what the library remembers of it, else what it
+// stamped into imageBuffer), 0 | 1 = the caller carried the forward's mode itself (the autograd ctx of frosting_amd/rasterizer.py)
+static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+backward_common(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
+                const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug, const int exact_blend)
 {
+    TORCH_CHECK(exact_blend >= -1 && exact_blend <= 1, "exact_blend must be -1 (as the forward), 0 or 1");
     TORCH_CHECK(means3D.is_cuda(), "frosting_amd rasterizer: means3D must live on a ROCm device (no CPU path)");
     const torch::Device dev = means3D.device();
     const c10::hip::HIPGuard guard(dev.index());
@@ -217,24 +222,94 @@ RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tens
         TORCH_CHECK(radii_c.scalar_type() == torch::kInt32 && radii_c.device() == dev, "radii must be int32 on ", dev);
         TORCH_CHECK(geomBuffer.device() == dev && binningBuffer.device() == dev && imageBuffer.device() == dev,
                     "the forward's scratch buffers must be on ", dev);
-        const int rc = frg_backward(
-            P, degree, M, R, opt_f32(background, dev, "background", k[0]), W, H, opt_f32(means3D, dev, "means3D", k[1]),
-            opt_f32(sh, dev, "sh", k[2]), opt_f32(colors, dev, "colors", k[3]), opt_f32(scales, dev, "scales", k[4]),
-            scale_modifier, opt_f32(rotations, dev, "rotations", k[5]), opt_f32(cov3D_precomp, dev, "cov3D_precomp", k[6]),
-            opt_f32(viewmatrix, dev, "viewmatrix", k[7]), opt_f32(projmatrix, dev, "projmatrix", k[8]),
-            opt_f32(campos, dev, "campos", k[9]), tan_fovx, tan_fovy, radii_c.data_ptr<int>(),
-            reinterpret_cast<char*>(geomBuffer.data_ptr()), reinterpret_cast<char*>(binningBuffer.data_ptr()),
-            reinterpret_cast<char*>(imageBuffer.data_ptr()), opt_f32(dL_dout_color, dev, "dL_dout_color", k[10]),
-            dL_dmeans2D.data_ptr<float>(), /*dL_dconic (never returned, rasterize_points.cu:195)*/ nullptr,
-            dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
-            dL_dcov3D.data_ptr<float>(), has_sh ? dL_dsh.data_ptr<float>() : nullptr,
-            has_sr ? dL_dscales.data_ptr<float>() : nullptr, has_sr ? dL_drotations.data_ptr<float>() : nullptr,
-            reinterpret_cast<char*>(workspace.data_ptr()), ws_bytes, debug ? 1 : 0,
-            c10::hip::getCurrentHIPStream(dev.index()).stream());
+        frg_backward_args a{};
+        a.struct_size = sizeof(a);
+        a.P = P; a.D = degree; a.M = M; a.R = R;
+        a.background = opt_f32(background, dev, "background", k[0]);
+        a.width = W; a.height = H;
+        a.means3D = opt_f32(means3D, dev, "means3D", k[1]);
+        a.shs = opt_f32(sh, dev, "sh", k[2]);
+        a.colors_precomp = opt_f32(colors, dev, "colors", k[3]);
+        a.scales = opt_f32(scales, dev, "scales", k[4]);
+        a.scale_modifier = scale_modifier;
+        a.rotations = opt_f32(rotations, dev, "rotations", k[5]);
+        a.cov3D_precomp = opt_f32(cov3D_precomp, dev, "cov3D_precomp", k[6]);
+        a.viewmatrix = opt_f32(viewmatrix, dev, "viewmatrix", k[7]);
+        a.projmatrix = opt_f32(projmatrix, dev, "projmatrix", k[8]);
+        a.campos = opt_f32(campos, dev, "campos", k[9]);
+        a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+        a.radii = radii_c.data_ptr<int>();
+        a.geom_buffer = reinterpret_cast<char*>(geomBuffer.data_ptr());
+        a.binning_buffer = reinterpret_cast<char*>(binningBuffer.data_ptr());
+        a.image_buffer = reinterpret_cast<char*>(imageBuffer.data_ptr());
+        a.dL_dpix = opt_f32(dL_dout_color, dev, "dL_dout_color", k[10]);
+        a.dL_dmean2D = dL_dmeans2D.data_ptr<float>();
+        a.dL_dconic = nullptr;                      // never returned (rasterize_points.cu:195)
+        a.dL_dopacity = dL_dopacity.data_ptr<float>();
+        a.dL_dcolor = dL_dcolors.data_ptr<float>();
+        a.dL_dmean3D = dL_dmeans3D.data_ptr<float>();
+        a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
+        a.dL_dsh = has_sh ? dL_dsh.data_ptr<float>() : nullptr;
+        a.dL_dscale = has_sr ? dL_dscales.data_ptr<float>() : nullptr;
+        a.dL_drot = has_sr ? dL_drotations.data_ptr<float>() : nullptr;
+        a.workspace = reinterpret_cast<char*>(workspace.data_ptr());
+        a.workspace_bytes = ws_bytes;
+        a.debug = debug ? 1 : 0;
+        a.hip_stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        a.exact_blend = exact_blend + 1;            // frg_backward_args: 0 = as the forward, k + 1 = value k
+        const int rc = frg_backward_ex(&a);
         check_rc(rc, "frg_backward");
         // `workspace` returns to the caching allocator here; reuse is ordered on this same stream
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+}
+
+// DGR/rasterize_points.h:40-62; returns the reference's eight gradients in its order (rasterize_points.cu:195)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                              const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                              const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                              const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                              const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
+                              const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                              const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug)
+{
+    return backward_common(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                           projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
+                           imageBuffer, debug, -1);
+}
+
+// The same with the forward's blend arithmetic handed over by the caller (who carried it beside the buffers -- the autograd
+// ctx): nothing about the forward has to be remembered by the library or read back from the buffers.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansBackwardExHIP(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                                const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                                const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                                const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                                const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
+                                const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                                const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug,
+                                const int exact_blend)
+{
+    return backward_common(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                           projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
+                           imageBuffer, debug, exact_blend);
+}
+
+// every forward option of the Python layer in one export: the 19 arguments, keep_mask (may be empty), exact_blend
+// (-1 = the process option | 0 | 1, for THIS call), forward_only
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansExHIP(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                        const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+                        const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                        const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                        const int image_height, const int image_width, const torch::Tensor& sh, const int degree,
+                        const torch::Tensor& campos, const bool prefiltered, const bool debug,
+                        const torch::Tensor& keep_mask, const int exact_blend, const bool forward_only)
+{
+    return forward_common(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                          projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                          &keep_mask, forward_only, exact_blend);
 }
 
 // DGR/rasterize_points.h:64-67, rasterize_points.cu:198-217
@@ -264,5 +339,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("mark_visible", &markVisibleHIP);
     m.def("rasterize_gaussians_masked", &RasterizeGaussiansMaskedHIP);
     m.def("rasterize_gaussians_forward_only", &RasterizeGaussiansForwardOnlyHIP);
+    m.def("rasterize_gaussians_ex", &RasterizeGaussiansExHIP);
+    m.def("rasterize_gaussians_backward_ex", &RasterizeGaussiansBackwardExHIP);
+    m.def("get_option", [](const std::string& name) { return frg_get_option(name.c_str()); });
     m.def("library_version", []() { return frg_version(); });
 }

@@ -125,6 +125,9 @@ class FlatAdam:
             raise RuntimeError("FlatAdam runs on the GPU only (no CPU path)")
         if g.dtype != torch.float32 or g.numel() != self.numel or not g.is_contiguous() or g.device != self.flat.device:
             raise RuntimeError(f"expected a contiguous float32 gradient buffer of {self.numel} elements on {self.flat.device}")
+        if row_live is None and getattr(g, "_frg_rows_partial", False):
+            raise RuntimeError("this gradient buffer was written in live_rows mode (only the rows of Gaussians with a gradient): "
+                               "pass row_live=, or ViewParallelRasterizer.zero_dead_rows() first")
         lrs = (C.c_float * len(self.names))(*[self.lrs[k] for k in self.names])
         head_lrs = (C.c_float * len(self.names))(*[(self.sh_dc_lr if (k == "shs" and self.sh_dc_lr is not None) else 0.0)
                                                     for k in self.names])
@@ -234,6 +237,30 @@ class ShardedFlatAdam(FlatAdam):
         dist.all_gather_into_tensor(self.flat_padded, mine.clone(), group=self.group)
         self.steps += 1
         return self.params
+
+    def reset(self, name: str, values: torch.Tensor = None, rows=None):
+        """FlatAdam.reset on the sharded state (gaussian_model.py:replace_tensor_to_optimizer, the opacity reset): the
+        parameter rows are overwritten on EVERY rank (they are replicated: every rank calls this with the same arguments),
+        the moments only where the group's elements meet this rank's shard [rank * shard, (rank + 1) * shard)."""
+        if name not in self.params:
+            raise KeyError(name)
+        sel = slice(None) if rows is None else rows
+        if values is not None:
+            self.params[name][sel] = values.to(self.device)
+        off, n = self.layout[name]
+        lo = self.rank * self.shard
+        if rows is None:
+            a, b = max(off, lo), min(off + n, lo + self.shard)
+            if a < b:
+                self.exp_avg[a - lo: b - lo] = 0.0
+                self.exp_avg_sq[a - lo: b - lo] = 0.0
+            return
+        # flat positions of the selected rows' elements, those inside the shard shifted to its origin
+        idx = torch.arange(n, device=self.device).view(self.shapes[name])[sel].reshape(-1) + off
+        idx = idx[(idx >= lo) & (idx < lo + self.shard)] - lo
+        if idx.numel():
+            self.exp_avg.index_fill_(0, idx, 0.0)
+            self.exp_avg_sq.index_fill_(0, idx, 0.0)
 
     def prune(self, keep_mask):
         raise RuntimeError("ShardedFlatAdam: prune / append re-shard the moments -- not implemented; rebuild the optimizer")

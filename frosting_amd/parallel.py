@@ -699,6 +699,11 @@ class ViewParallelRasterizer:
         factored plan under a process group, views["shs"] is only valid after wait_exchange(slot).
         payload: also fill this view's share of the factored exchange (masked colour gradient and
         camera centre); default: only when a process group is live.
+        live_rows = True: ONLY the rows of the Gaussians marked in self.row_live are written -- every other row of the returned
+        views, of dL_dmeans2D (the viewspace gradient) and of dL_dcolors holds whatever an earlier step left there.  The one
+        consumer that may take the buffer as it is is FlatAdam.step(flat, row_live=self.row_live) (it rejects the buffer
+        without the mask); anything else -- densification statistics, gradient norms, a plain optimizer -- calls
+        zero_dead_rows(slot) first.
         phase (frg_backward_args::phase): 1 = the backward blend + the per-Gaussian slot sums -- the payload of the
         factored exchange is complete when this call's kernels are, so its all-gather can be started before phase 2
         (backward_overlapped does that); 2 = the rest; 0 = both in one call."""
@@ -708,6 +713,7 @@ class ViewParallelRasterizer:
         H, W = cam.image_height, cam.image_width
         self.exchange = ex = self.exchanges[slot]
         g = ex.views
+        ex.flat._frg_rows_partial = bool(self.live_rows)     # (FlatAdam.step refuses such a buffer without its row mask)
         # factored plan with live collectives: the per-view SH rows are not materialised -- wait()
         # rebuilds their sum over views from the exchanged colour gradients
         defer_sh = ex.factor_sh and ex._active()
@@ -746,6 +752,19 @@ class ViewParallelRasterizer:
             # the caching allocator placed at the previous one's address from the previous one
             ex.own_campos.copy_(cam.campos.reshape(-1)[:3], non_blocking=True)
         return g
+
+    def zero_dead_rows(self, slot: int = 0):
+        """live_rows mode: make the gradients of buffer `slot` (and the rank-local dL_dmeans2D / dL_dcolors / dL_dcov3D) DENSE
+        -- the rows of Gaussians the last backward did not mark are filled with zeros, which is what the dense form writes
+        there -- for consumers other than the masked optimizer step.  Costs what the mode saved; returns the views."""
+        ex = self.exchanges[slot]
+        if not self.live_rows:
+            return ex.views
+        dead = self.row_live == 0
+        for t in list(ex.views.values()) + [self.dL_dmeans2D, self.dL_dcolors] + ([self.dL_dcov3D] if self.dL_dcov3D is not None else []):
+            t[dead] = 0.0
+        ex.flat._frg_rows_partial = False
+        return ex.views
 
     def _backward_plain(self, L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream):
         return L.frg_backward(self.P, s.sh_degree, self.K, self.num_rendered, _p(bg), W, H,

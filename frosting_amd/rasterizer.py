@@ -139,9 +139,32 @@ class _NativeOps:
         return _NativeOps.rasterize_gaussians(*args[:19], keep_mask=mask, modes={"forward_only": 1})
 
     @staticmethod
+    def rasterize_gaussians_ex(*args):
+        """(the 19 arguments of rasterize_gaussians, keep_mask or an empty tensor, exact_blend -1 | 0 | 1, forward_only):
+        every forward option of the Python layer in one export -- same name as the compiled module's.  exact_blend -1 =
+        the process-wide option, 0 | 1 = the blend arithmetic of THIS call."""
+        mask = args[19] if args[19] is not None and args[19].numel() else None
+        modes = {"forward_only": int(bool(args[21]))}
+        if int(args[20]) >= 0:
+            modes["exact_blend"] = int(args[20])
+        return _NativeOps.rasterize_gaussians(*args[:19], keep_mask=mask, modes=modes)
+
+    @staticmethod
+    def get_option(name):
+        return _lib.get_option(name)
+
+    @staticmethod
+    def rasterize_gaussians_backward_ex(*args):
+        """(the 21 arguments of rasterize_gaussians_backward, exact_blend -1 | 0 | 1): the forward's blend arithmetic handed
+        over by the caller, who carried it beside the buffers (the autograd ctx) -- same name as the compiled module's export."""
+        return _NativeOps.rasterize_gaussians_backward(*args[:21], exact_blend=int(args[21]))
+
+    @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
-                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, exact_blend=-1):
+        """exact_blend (extension): -1 = the arithmetic of the forward that filled the buffers (what the library remembers
+        of it, else what that forward stamped into imageBuffer); 0 | 1 = stated by the caller (frg_backward_args::exact_blend)."""
         L = _lib.lib()
         dev = means3D.device
         P = int(means3D.shape[0])
@@ -165,16 +188,33 @@ class _NativeOps:
                          scales=_f32c(scales, dev), rots=_f32c(rotations, dev), cov=_f32c(cov3D_precomp, dev),
                          view=_f32c(viewmatrix, dev), proj=_f32c(projmatrix, dev), sh=_f32c(sh, dev),
                          campos=_f32c(campos, dev), dpix=_f32c(dL_dout_color, dev), radii=radii.contiguous())
-                rc = L.frg_backward(P, int(degree), M, int(R), _ptr(t["bg"]), W, H,
-                                    _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]),
-                                    _ptr(t["scales"]), float(scale_modifier), _ptr(t["rots"]), _ptr(t["cov"]),
-                                    _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
-                                    float(tan_fovx), float(tan_fovy), _ptr(t["radii"]),
-                                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(t["dpix"]),
-                                    _ptr(dL_dmeans2D), None, _ptr(dL_dopacity), _ptr(dL_dcolors),
-                                    _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh) if has_sh else None,
-                                    _ptr(dL_dscales) if has_sr else None, _ptr(dL_drotations) if has_sr else None,
-                                    _ptr(workspace), ws_bytes, int(bool(debug)), _stream_ptr(dev))
+                if int(exact_blend) < 0:      # the reference-shaped entry point (rasterizer.h:58-84)
+                    rc = L.frg_backward(P, int(degree), M, int(R), _ptr(t["bg"]), W, H,
+                                        _ptr(t["means"]), _ptr(t["sh"]), _ptr(t["colors"]),
+                                        _ptr(t["scales"]), float(scale_modifier), _ptr(t["rots"]), _ptr(t["cov"]),
+                                        _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]),
+                                        float(tan_fovx), float(tan_fovy), _ptr(t["radii"]),
+                                        _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(t["dpix"]),
+                                        _ptr(dL_dmeans2D), None, _ptr(dL_dopacity), _ptr(dL_dcolors),
+                                        _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh) if has_sh else None,
+                                        _ptr(dL_dscales) if has_sr else None, _ptr(dL_drotations) if has_sr else None,
+                                        _ptr(workspace), ws_bytes, int(bool(debug)), _stream_ptr(dev))
+                else:
+                    def vp(x):
+                        return None if x is None else x.value
+                    a = _lib.BackwardArgs(
+                        struct_size=C.sizeof(_lib.BackwardArgs), P=P, D=int(degree), M=M, R=int(R), background=vp(_ptr(t["bg"])),
+                        width=W, height=H, means3D=vp(_ptr(t["means"])), shs=vp(_ptr(t["sh"])), colors_precomp=vp(_ptr(t["colors"])),
+                        scales=vp(_ptr(t["scales"])), scale_modifier=float(scale_modifier), rotations=vp(_ptr(t["rots"])),
+                        cov3D_precomp=vp(_ptr(t["cov"])), viewmatrix=vp(_ptr(t["view"])), projmatrix=vp(_ptr(t["proj"])),
+                        campos=vp(_ptr(t["campos"])), tan_fovx=float(tan_fovx), tan_fovy=float(tan_fovy), radii=vp(_ptr(t["radii"])),
+                        geom_buffer=vp(_ptr(geomBuffer)), binning_buffer=vp(_ptr(binningBuffer)), image_buffer=vp(_ptr(imageBuffer)),
+                        dL_dpix=vp(_ptr(t["dpix"])), dL_dmean2D=vp(_ptr(dL_dmeans2D)), dL_dconic=None, dL_dopacity=vp(_ptr(dL_dopacity)),
+                        dL_dcolor=vp(_ptr(dL_dcolors)), dL_dmean3D=vp(_ptr(dL_dmeans3D)), dL_dcov3D=vp(_ptr(dL_dcov3D)),
+                        dL_dsh=vp(_ptr(dL_dsh)) if has_sh else None, dL_dscale=vp(_ptr(dL_dscales)) if has_sr else None,
+                        dL_drot=vp(_ptr(dL_drotations)) if has_sr else None, workspace=vp(_ptr(workspace)), workspace_bytes=ws_bytes,
+                        debug=int(bool(debug)), hip_stream=_stream_ptr(dev).value, exact_blend=int(exact_blend) + 1)
+                    rc = L.frg_backward_ex(C.byref(a))
                 if rc < 0:
                     raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
                 # keep the workspace alive until the stream has consumed it
@@ -238,8 +278,17 @@ def _make_autograd_function(ops):
 
             # no input needs a gradient (or torch.no_grad()): no backward can follow -- the native forward keeps nothing for one
             forward_only = not any(ctx.needs_input_grad) and hasattr(ops, "rasterize_gaussians_forward_only")
+            # The modes of THIS forward travel with the autograd ctx, beside the buffers (the reference's ctx carries
+            # num_rendered the same way, __init__.py:93-97): the blend arithmetic is fixed here -- the process option read once
+            # and handed to the native forward as its per-call mode -- and given back to the native backward, which then
+            # depends neither on what the library remembers of this forward nor on the option's value by then.
+            carried = hasattr(ops, "rasterize_gaussians_ex") and hasattr(ops, "rasterize_gaussians_backward_ex")
+            exact = int(ops.get_option("exact_blend")) if carried else -1
 
             def run():
+                if carried:
+                    return ops.rasterize_gaussians_ex(*native_args, keep_mask if keep_mask is not None else torch.empty(0),
+                                                      exact, forward_only)
                 if forward_only:
                     return ops.rasterize_gaussians_forward_only(*native_args, keep_mask if keep_mask is not None else torch.empty(0))
                 if keep_mask is None:
@@ -258,6 +307,7 @@ def _make_autograd_function(ops):
             num_rendered, color, radii, geom, binning, img = out
             ctx.raster_settings = s
             ctx.num_rendered = num_rendered
+            ctx.exact_blend, ctx.forward_only = exact, forward_only
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
             ctx.mark_non_differentiable(radii)
             return color, radii
@@ -269,16 +319,23 @@ def _make_autograd_function(ops):
             native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                            s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, sh, s.sh_degree, s.campos,
                            geom, ctx.num_rendered, binning, img, s.debug)
+            if ctx.forward_only:
+                raise RuntimeError("backward of a forward that was run with no input requiring a gradient (forward_only): "
+                                   "nothing was kept for it")
+            backward_op = ops.rasterize_gaussians_backward
+            if ctx.exact_blend >= 0:          # the forward's arithmetic, carried by this ctx
+                def backward_op(*a):
+                    return ops.rasterize_gaussians_backward_ex(*a, ctx.exact_blend)
             if s.debug:
                 saved = _snapshot(native_args)
                 try:
-                    grads = ops.rasterize_gaussians_backward(*native_args)
+                    grads = backward_op(*native_args)
                 except Exception:
                     torch.save(saved, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise
             else:
-                grads = ops.rasterize_gaussians_backward(*native_args)
+                grads = backward_op(*native_args)
             g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots = grads
             return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None, None
 

@@ -157,8 +157,9 @@ typedef struct frg_forward_args {
      * autograd function keeps nothing either when no input needs a gradient, __init__.py:44-98).  The forward then leaves
      * out what it only writes for a backward -- the blend's checkpoints and final colours, the walked depths, cutoff keys
      * and work items of the tiles, and d(colour)/d(direction) of the SH pass: image, radii and the returned count are the
-     * same bits.  frg_backward on its buffers is refused with FRG_EINVAL (should the host have forgotten the forward --
-     * more than 64 forwards ago -- the backward finds no work item and returns zero gradients).  Not offered with
+     * same bits.  frg_backward on its buffers is refused with FRG_EINVAL -- also on a copy of them at another address, and however
+     * many forwards ago: the forward's blend kernel stamps "nothing kept" into the image chunk, and a backward whose host side
+     * does not remember the forward reads that stamp.  Not offered with
      * instance_capacity > 0.  Forward alone, same process: C3 0.733 -> 0.696 ms, C2 0.0968 -> 0.0926 (the binning chunk is
      * sized as before: the checkpoints' 8 ... 16 bytes per instance are carved and left unwritten). */
     int forward_only;
@@ -227,9 +228,12 @@ typedef struct frg_backward_args {
     const long long* shell_cells;
     float *dL_dshell_logits, *dL_dshell_cell_verts;
     /* second generation (struct_size tells): exact_blend 1 | 2 = fast | exact arithmetic of THIS backward's blend
-     * pass; 0 (and frg_backward, which has no such argument) = the arithmetic of the forward that last filled
-     * geom_buffer -- per-call mode or process default, remembered by the library for the 64 most recent geometry
-     * buffers of the process -- and frg_set_option's value when that forward is no longer remembered.
+     * pass; 0 (and frg_backward, which has no such argument) = the arithmetic of the forward that filled the buffers --
+     * per-call mode or process default at the time of THAT call: the library remembers it for the 1024 most recent
+     * geometry buffers of the process, and for a buffer it does not know (cloned, restored at another address, older) it
+     * reads the word the forward's blend kernel stamped into image_buffer (one blocking 4-byte copy on hip_stream).
+     * frg_set_option's value at the time of the backward plays no part.  A caller that carries the forward's mode beside
+     * the buffers (the autograd ctx of frosting_amd/rasterizer.py does) states it here and saves that lookup.
      * shell_bary_mode as in frg_forward_args, and equal to the forward's */
     int exact_blend;
     int shell_bary_mode;
@@ -468,7 +472,9 @@ int frg_adam_step_shard(long long n, long long first, float* params, const float
  * Gaussian of segment k (0: the segment is not per-Gaussian -- its gradients are always read).  The gradient of an
  * element whose Gaussian is unmarked is taken as zero WITHOUT being read (the moments still decay and the parameter still
  * moves by its momentum: the reference's dense semantics); everything else as frg_adam_step.  Bit-identical to
- * frg_adam_step on the dense gradient. */
+ * frg_adam_step on the dense gradient.  A per-Gaussian segment whose rows are a multiple of 4 elements long must BEGIN on
+ * a multiple of 4 elements (FRG_EINVAL otherwise: the kernel reads one mask byte per aligned group of four there); the
+ * 16-byte aligned segments of frosting_amd.parallel.flat_layout satisfy this. */
 int frg_adam_step_rows(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                        const long long* segment_ends, const float* segment_lrs, const int* segment_period,
                        const int* segment_head, const float* segment_head_lrs, int n_segments,

@@ -189,12 +189,25 @@ def backward_f64(state, dL_dout_color):
     g["dL_dsh"] = np.ascontiguousarray(g["dL_dsh"])
     if P == 0:
         return g
-    bg, m2, co, col = d(state["bg"]), d(state["means2D"]), d(state["conic_opacity"]), d(state["colors"])
-    fT, dpix = d(state["final_T"]), d(dL_dout_color)
+    # The per-Gaussian arrays of a forward state are only defined on the VISIBLE rows (the reference leaves the rest of its
+    # geometry chunk as the allocator handed it over: arbitrary bit patterns, signalling NaNs among them).  No list entry and
+    # no radii > 0 row refers to them, but the float32 -> float64 cast would raise "invalid value" on them -- and a warning
+    # that is always there would also hide a NaN that matters.  They are zeroed first, and the casts run with invalid = raise.
+    invisible = radii <= 0
+
+    def dv(a):
+        a32 = np.array(a, dtype=np.float32, copy=True)
+        a32[invisible] = 0.0
+        with np.errstate(invalid="raise"):
+            return np.ascontiguousarray(a32.astype(np.float64))
+    bg, m2, co, col = d(state["bg"]), dv(state["means2D"]), dv(state["conic_opacity"]), dv(state["colors"])
+    with np.errstate(invalid="raise"):
+        fT, dpix = d(state["final_T"]), d(dL_dout_color)
     L.gso_render_backward(C.c_int(P), C.c_int(R), C.c_int(W), C.c_int(H), _p(ranges), _p(plist), _p(bg), _p(m2), _p(co),
                           _p(col), _p(fT), _p(ncon), _p(dpix), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]),
                           _p(g["dL_dopacity"]), _p(g["dL_dcolors"]))
-    m3, cov, vm, pm, cam = (d(state[k]) for k in ("means3D", "cov3D", "viewmatrix", "projmatrix", "campos"))
+    m3, vm, pm, cam = (d(state[k]) for k in ("means3D", "viewmatrix", "projmatrix", "campos"))
+    cov = dv(state["cov3D"])
     L.gso_preprocess_backward(C.c_int(P), C.c_int(D), C.c_int(M), _p(m3), _p(radii), _p(shs), _p(clamped), _p(sc), _p(rot),
                               C.c_double(float(state.get("scale_modifier", 1.0))), _p(cov), _p(vm), _p(pm), C.c_int(W),
                               C.c_int(H), C.c_double(float(state["tanfovx"])), C.c_double(float(state["tanfovy"])),

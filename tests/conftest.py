@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+    # a numpy "invalid value" / overflow warning is a NaN on its way into a comparison: an error in both tiers (round 5's GPU
+    # tier carried "invalid value encountered in cast" from the float64 yardstick's uninitialised rows: oracle/gs_oracle.py)
+    config.addinivalue_line("filterwarnings", "error::RuntimeWarning")
 
 
 @pytest.fixture(scope="session")

@@ -326,7 +326,22 @@ def test_c4_refine_step_vs_reference_on_compacted_tensors(gpu_device, P):
             assert not g[~keep].any(), name                    # culled Gaussians: zero rows
         # the kept rows beside the reference's four runs on the compacted tensors, against the float64 gradient of that
         # forward state (round 3: floors x 3 and a flat 1e-3 on dL_dmeans3D for this thin shell seen edge-on)
-        Hh.judge_gradients({name: g[keep] for name, g in zip(Hh.GRAD_NAMES, grads)}, runs, Hh.truth_from_ref_state(rst, gpix),
-                           fast=False, label="c4 culled refine step")
+        truth = Hh.truth_from_ref_state(rst, gpix)
+        Hh.judge_gradients({name: g[keep] for name, g in zip(Hh.GRAD_NAMES, grads)}, runs, truth, fast=False, label="c4 culled refine step")
+        # ... and in the arithmetic bench.py's `c4` line runs: the default blend, with the frame's mask
+        # from the one-call occlusion culling (mesh.occlusion_keep_mask -> frg_mesh_occlusion_mask) -- image within the 1e-4
+        # per-pixel L1 of north_star, radii and instance count equal, gradients judged as everywhere
+        _lib.set_option("exact_blend", 0)
+        keep2 = M.occlusion_keep_mask(sh.verts, sh.faces, cam.projmatrix.to(dev), H, W, sh.cell)
+        assert torch.equal(keep2.bool(), keep.bool())
+        R2, color2, radii2, geom2, binning2, img2 = D._C.rasterize_gaussians_masked(*args, keep2)
+        assert R2 == Rr and torch.equal(radii2[keep], rradii) and not radii2[~keep].any()
+        assert float((color2 - rcolor).abs().mean()) <= 1e-4
+        b2 = b[:2] + (radii2,) + b[3:16] + (geom2, R2, binning2, img2, False)
+        grads2 = D._C.rasterize_gaussians_backward(*b2)
+        for name, g in zip(Hh.GRAD_NAMES, grads2):
+            assert not g[~keep].any(), name
+        Hh.judge_gradients({name: g[keep] for name, g in zip(Hh.GRAD_NAMES, grads2)}, runs, truth, fast=True,
+                           label="c4 culled refine step, default arithmetic")
     finally:
         _lib.set_option("exact_blend", 0)

@@ -195,6 +195,19 @@ def test_live_rows_training_steps_equal_the_dense_path(gpu_device):
             opt.step(vpr.exchange.flat, row_live=vpr.row_live)
         torch.cuda.synchronize(dev)
         if live_rows:
+            # the partially written buffer is refused without its mask; zero_dead_rows makes it the dense form
+            with pytest.raises(RuntimeError, match="live_rows"):
+                opt.step(vpr.exchange.flat)
+            vpr.exchange.flat.fill_(float("nan"))
+            vpr.forward(cam_d, bg_d)
+            vpr.backward(dimg, 0)
+            live_grads = {k: v.clone() for k, v in vpr.zero_dead_rows(0).items()}
+            assert all(bool(torch.isfinite(v).all()) for v in live_grads.values()) and bool(torch.isfinite(vpr.dL_dmeans2D).all())
+            dense = ViewParallelRasterizer(raw_scene, dev, raw_params=True)
+            dense.forward(cam_d, bg_d)
+            dense.backward(dimg, 0)
+            assert all(torch.equal(live_grads[k], dense.exchange.views[k]) for k in live_grads)
+            assert torch.equal(vpr.dL_dmeans2D, dense.dL_dmeans2D)
             assert 0.2 < min(fractions) and max(fractions) < 0.8, fractions         # a saturating frame: many visible Gaussians are never reached
         results.append((opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
     for a, b in zip(*results):

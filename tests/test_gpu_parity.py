@@ -1225,6 +1225,59 @@ def test_forward_tile_order_changes_nothing(gpu_device):
 
 
 
+def test_a_backward_finds_its_forwards_modes_in_the_buffers_and_in_the_ctx(gpu_device, ops):
+    """What a backward must know about its forward beyond the three buffers -- the blend arithmetic, and whether anything was
+    kept at all -- travels WITH them: stamped by the forward's blend kernel into the image chunk
+    (Counters::fwd_flags) and carried by the autograd ctx of the Python layer.  So
+      * the first of 1100 forwards still gets its own arithmetic in its backward (the library's notes hold 1024), with the
+        process option flipped meanwhile;
+      * buffers CLONED to other addresses (offloaded and restored, copied by a checkpointing wrapper) give the same bits;
+      * the clone of a forward_only forward's buffers is refused like the original;
+      * the module's backward follows the mode its ctx carried, whatever the option says by then."""
+    dev = gpu_device
+    scene, cam, bg = scenes.config_scene("c2", 1, P=30_000)
+    tiny, tcam, tbg = scenes.config_scene("mini", 0, P=300)
+    _lib.set_option("exact_blend", 1)
+    out, args = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
+    gpix, _ = scenes.l1_target_grad(out[1].cpu(), 5)
+    gpix = gpix.to(dev)
+    want = [g.clone() for g in ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix))]
+    _lib.set_option("exact_blend", 0)
+    fast_out, _ = Hh.run_ours_native(scene, cam, bg, dev, ops=ops)
+    fast = [g.clone() for g in ops.rasterize_gaussians_backward(*_bwd_args(args, fast_out, gpix))]
+    assert not all(torch.equal(a, b) for a, b in zip(want, fast))          # the two arithmetics do differ on this frame
+    keep_alive = [Hh.run_ours_native(tiny, tcam, tbg, dev, ops=ops)[0] for _ in range(1100)]   # 1100 other geometry buffers, all alive
+    assert len({o[3].data_ptr() for o in keep_alive}) == 1100
+    got = ops.rasterize_gaussians_backward(*_bwd_args(args, out, gpix))        # process option: fast; the forward was exact
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    del keep_alive
+    for src, ref in ((out, want), (fast_out, fast)):
+        clone = (src[0], src[1], src[2], src[3].clone(), src[4].clone(), src[5].clone())
+        for opt in (0, 1):
+            _lib.set_option("exact_blend", opt)
+            got = ops.rasterize_gaussians_backward(*_bwd_args(args, clone, gpix))
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), opt
+    fo = ops.rasterize_gaussians_forward_only(*args, torch.empty(0))
+    fo_clone = (fo[0], fo[1], fo[2], fo[3].clone(), fo[4].clone(), fo[5].clone())
+    with pytest.raises(RuntimeError, match="forward_only"):
+        ops.rasterize_gaussians_backward(*_bwd_args(args, fo_clone, gpix))
+    with pytest.raises(RuntimeError, match="stamp"):                            # buffers no forward ever filled
+        ops.rasterize_gaussians_backward(*_bwd_args(args, (out[0], out[1], out[2], torch.zeros_like(out[3]), torch.zeros_like(out[4]),
+                                                                 torch.zeros_like(out[5])), gpix))
+    # the module: the ctx carries the forward's arithmetic
+    from frosting_amd.rasterizer import make_rasterizer_class
+    Rast, _ = make_rasterizer_class(ops)
+    sc = scene.to(dev)
+    kw = dict(means2D=torch.zeros_like(sc.means3D), opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    for fwd_opt, ref in ((1, want), (0, fast)):
+        _lib.set_option("exact_blend", fwd_opt)
+        leaf = sc.means3D.clone().requires_grad_(True)
+        img, _ = Rast(Hh.settings_for(cam, bg, 3, dev))(means3D=leaf, **kw)
+        _lib.set_option("exact_blend", 1 - fwd_opt)
+        img.backward(gpix)
+        assert torch.equal(leaf.grad, ref[GRAD_NAMES.index("dL_dmeans3D")]), fwd_opt
+
+
 @pytest.mark.parametrize("exact", [1, 0])
 def test_forward_only_keeps_nothing_for_a_backward_and_changes_no_output_bit(gpu_device, ops, exact):
     """frg_forward_args::forward_only (ADVICE r04: every forward paid for the backward's checkpoints): the image, radii and

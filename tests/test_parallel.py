@@ -464,6 +464,9 @@ def _sharded_worker(rank, world, port, P, K, steps, q):
     for it in range(steps):
         g = torch.Generator().manual_seed(1000 * it + rank)
         opt.step(torch.randn(opt.numel, generator=g))
+        if it == 0:      # the reference loop's opacity reset (replace_tensor_to_optimizer) + a reset of some rows of another group
+            opt.reset("opacities", torch.full((P, 1), 0.01))
+            opt.reset("shs", rows=torch.arange(P) % 3 == 0)
     q.put((rank, opt.flat.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -474,7 +477,9 @@ def _sharded_worker(rank, world, port, P, K, steps, q):
 def test_sharded_adam_equals_the_replicated_update_gloo(world):
     """ShardedFlatAdam on N ranks (reduce-scatter of the per-view gradients, each rank's update of its shard, all-gather of
     the parameters; the shard boundaries fall inside the SH rows, off the DC / rest period) == the same update of the
-    whole buffer on the summed gradients in one process, bit for bit, on every rank."""
+    whole buffer on the summed gradients in one process, bit for bit, on every rank -- with the reference loop's opacity
+    reset and a reset of selected rows between two steps (ShardedFlatAdam.reset: the values on every rank, the moments where
+    the group meets the rank's shard)."""
     P, K, steps = 131, 16, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -507,5 +512,14 @@ def test_sharded_adam_equals_the_replicated_update_gloo(world):
             total = g if total is None else total + g
         _torch_shard_step(ref, 0, flat, total, [lrs[k] for k in names], [2.5e-3 if k == "shs" else 0.0 for k in names], 1.0)
         ref.steps += 1
+        if it == 0:      # FlatAdam.reset on the whole buffer: values + both moments of the group / of the selected rows
+            o, n = layout["opacities"]
+            flat[o:o + n] = 0.01
+            ref.exp_avg[o:o + n] = 0.0
+            ref.exp_avg_sq[o:o + n] = 0.0
+            o, n = layout["shs"]
+            rows = torch.arange(P) % 3 == 0
+            ref.exp_avg[o:o + n].view(P, K, 3)[rows] = 0.0
+            ref.exp_avg_sq[o:o + n].view(P, K, 3)[rows] = 0.0
     for r in range(world):
         assert (torch.from_numpy(res[r]) == flat).all(), r

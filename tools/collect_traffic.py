@@ -1,4 +1,4 @@
-"""Turn rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected by tools/pmc_round.sh in
+"""Turn rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected by tools/gpu_session.sh (WHAT=pmc) in
 separate --pmc runs with --kernel-trace only) into profiles/<tag>_pmc_traffic.json:
 per-stage HBM-side bytes per launch, with the gfx950 correction MI355X_MICROARCH.md
 prescribes (FETCH_SIZE counts a wide coalesced read at half its bytes -> doubled;

@@ -1,13 +1,19 @@
 #!/usr/bin/env bash
-# One gpurun call of round 5.  WHAT selects the parts (default: tests sparse smoke bench prof).
+# One gpurun call: `gpurun --timeout S -- 'WHAT="tests bench" TAG=r06 bash tools/gpu_session.sh'`.  The ONE GPU-session script
+# (rounds 1-5 each had their own gpu_round*.sh / gpu_ab*.sh / pmc_round*.sh: folded into the modes below).
+# WHAT selects the parts (default: tests sparse smoke bench prof); output under gpurun_out/$TAG.
 #   tests     pytest -m gpu                                   sparse   tools/sparse_grad_check.py (gradients vs reference AND float64)
 #   smoke     __graft_entry__.smoke()                         bench    the driver's bench line
 #   prof      rocprofv3 --kernel-trace --stats of bench.py    ab       tools/ab.py with $AB_ARGS (one line per setting)
 #   train     tools/train_step.py                             exchange single-rank exchange schedules
-#   pmc       PMC passes LAST (FETCH/WRITE/SQ), collected into profiles/r05_pmc_*.json with the build fingerprint
+#   pmc       PMC passes LAST (FETCH/WRITE/SQ), collected into profiles/${TAG}_pmc_*.json with the build fingerprint
+#   trace     kernel timeline of one step (TRACE_CFGS="c2 c3 c4")     gradab   default-arithmetic A/B builds vs float64
+#   ab4/ab4b  alternating bench.py passes of library builds / options (SETTINGS, CONFIGS)
+#   tworank   bench.py's multi-rank path on one GPU: two ranks share GPU 0 over gloo (functional only)
+#   cmd       run $CMD (a one-off measurement) with its output in $O/cmd.log
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG="${TAG:-r05}"
+TAG="${TAG:-r06}"
 mkdir -p gpurun_out/$TAG
 WHAT="${WHAT:-tests sparse smoke bench prof}"
 export TMPDIR=/tmp
@@ -60,6 +66,16 @@ pmc)
   cp profiles/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_sq.json $O/ 2>/dev/null
   rm -rf gpurun_out/pmc
   tail -3 $O/collect.err; ls $O ;;
+tworank)
+  : > $O/two_rank.log
+  for ex in ${TWORANK_PLANS:-slotsum factored allreduce}; do
+    echo "== $ex" >> $O/two_rank.log
+    FRG_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+      bench.py --gpus 2 --steps 6 --warmup 3 --spinup-steps 2 --backend gloo --exchange $ex --points 400000 --no-cpu-baseline --no-extras 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|^\*\*\*\|OMP_NUM" | tail -4 | cut -c1-900 >> $O/two_rank.log
+  done
+  cat $O/two_rank.log ;;
+cmd)
+  timeout ${CMD_TIMEOUT:-900} bash -c "$CMD" > $O/cmd.log 2>&1; echo "cmd rc=$?" >> $O/cmd.log; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" $O/cmd.log | tail -${CMD_TAIL:-60} ;;
 gradab)
   # the default arithmetic's distance to float64, one A/B build (tools/build_variants.sh) at a time: $GRADAB_LIBS = names under frosting_amd/lib_ab/
   : > $O/grad_ab.log
