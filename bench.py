@@ -73,21 +73,27 @@ def parse_args():
     ap.add_argument("--deferred-counters", action="store_true",
                     help="use frg_forward_deferred (no host synchronisation inside the step) instead of frg_forward, "
                          "which like the reference blocks on a read-back of num_rendered")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "sparse", "factored", "allreduce"],
-                    help="N>1: 'allreduce' = all 59 floats per Gaussian are summed across ranks; 'factored' = the 11 non-SH "
+    ap.add_argument("--exchange", default="slotsum", choices=["slotsum", "auto", "sparse", "factored", "allreduce"],
+                    help="N>1: 'slotsum' (default, round 6) = the ranks all-gather the nine per-Gaussian SLOT SUMS of their view's "
+                         "backward (36-byte rows of the Gaussians with a gradient, index-ordered behind a bit mask, fixed-capacity "
+                         "packets: no host wait for a count) and every rank runs the per-Gaussian chain for every view's rows in "
+                         "view order in ONE pass that writes each gradient row once (csrc/slot_exchange.hip) -- the plan the "
+                         "arithmetic of DESIGN.md section 5 puts first at every bus bandwidth, and ONE kind of collective "
+                         "(all_gather_into_tensor); 'allreduce' = all 59 floats per Gaussian are summed across ranks; 'factored' = the 11 non-SH "
                          "floats are summed + all-gather of the 3-float colour gradient, summed SH gradient rebuilt on "
                          "every rank; 'sparse' = only the ROWS of the Gaussians with a gradient travel -- (index, 11 floats, "
                          "dRGB), one visible Gaussian in seven at C3: counts, one padded all-gather, scatter-add in view order, "
-                         "SH rebuild (frosting_amd/parallel.py); 'auto' (default) = N>1 on RCCL: 'factored' and 'sparse' are "
-                         "both timed for a few steps before the warm-up and the faster one runs (the arithmetic of DESIGN.md "
-                         "section 5 puts them within 10 % of each other, the order depending on the collective bandwidth RCCL "
-                         "reaches on the node); otherwise 'factored'")
-    ap.add_argument("--reduce", default="auto", choices=["auto", "allreduce", "direct"],
+                         "SH rebuild (frosting_amd/parallel.py); 'auto' = an explicit PROBE: N>1 on RCCL, 'slotsum', 'factored' and "
+                         "'sparse' are each timed for a few steps before the warm-up and the fastest one runs (never the default: "
+                         "the first multi-rank run of a build should execute as few never-executed collectives as possible)")
+    ap.add_argument("--chunks", type=int, default=2,
+                    help="slotsum: index ranges of Gaussians with a packet and a collective each -- the combine pass of one range "
+                         "runs while the next range's packets travel")
+    ap.add_argument("--reduce", default="allreduce", choices=["auto", "allreduce", "direct"],
                     help="N>1: how the summed part travels: 'allreduce' = one RCCL all-reduce; 'direct' = one RCCL reduce-scatter "
                          "of 1/N shards + one all-gather (every GPU talks to every other over its own xGMI link: SURVEY 8(e)); "
-                         "'auto' (default) = both are timed on this run's buffers before the warm-up (RCCL backend, N>1) and the "
-                         "faster one is used -- which of the two RCCL serves better on a fully connected xGMI node is not "
-                         "something the arithmetic of DESIGN.md section 5 can settle; single rank / gloo: allreduce")
+                         "'auto' = an explicit PROBE: both are timed on this run's buffers before the warm-up (RCCL backend, N>1) and "
+                         "the faster one is used.  Only the 'factored' / 'allreduce' plans sum anything; default: allreduce")
     ap.add_argument("--probe-exchange", action="store_true",
                     help="run the 'auto' probe of --exchange on any backend (it is skipped on gloo otherwise: functional tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -435,8 +441,9 @@ def main():
         args.reduce = "allreduce"
     vpr = ViewParallelRasterizer(scene_d, dev, process_group=dist.group.WORLD if dist else None,
                                  factor_sh=(args.exchange in ("factored", "sparse")), deferred_counters=args.deferred_counters,
-                                 reduce=args.reduce, sparse=(args.exchange == "sparse"))
-    if auto_reduce and dist is not None and world > 1 and args.backend == "nccl" and args.exchange != "sparse":
+                                 reduce=args.reduce, sparse=(args.exchange == "sparse"), slotsum=(args.exchange == "slotsum"),
+                                 chunks=args.chunks)
+    if auto_reduce and dist is not None and world > 1 and args.backend == "nccl" and args.exchange in ("factored", "allreduce"):
         # the sum of the dense part timed both ways on this run's buffers, max over ranks; the faster plan is used
         from frosting_amd.parallel import probe_reduce_plan
         reduce_probe, args.reduce = probe_reduce_plan(vpr.exchanges)
@@ -504,10 +511,11 @@ def main():
         overlapped = ex and schedule[0] == "in-step" and not args.deferred_counters
         if overlapped:
             # in-step, factored plan: the all-gather of the colour-gradient payloads leaves after phase 1 of the backward
-            # (blend + slot sums) and travels while phase 2 (the per-Gaussian chain) computes
+            # (blend + slot sums) and travels while phase 2 (the per-Gaussian chain) computes; slot-sum plan: phase 1 only,
+            # its sums are packed and travel, the chain runs in the exchange's combine pass
             vpr.backward_overlapped(g_d, slot)
         else:
-            vpr.backward(g_d, slot)          # writes straight into the flat gradient buffer
+            vpr.backward(g_d, slot, local=not ex)          # writes straight into the flat gradient buffer
         if not vpr.finish():                 # deferred counters: more instances than the arena holds -> redo
             vpr.forward(c_d, bg_d, deferred=False, keep_mask=cull_mask(c_d))
             vpr.backward(g_d, slot)
@@ -552,7 +560,7 @@ def main():
         # measured since round 2, is the fallback.
         try:
             exchange_probe = {}
-            for plan in ("factored", "sparse"):
+            for plan in ("slotsum", "factored", "sparse"):
                 vpr.set_exchange_plan(plan, reduce=args.reduce)
                 timed(3)
                 t_, _ = timed(6)
@@ -638,16 +646,18 @@ def main():
         dt_c, _ = timed(args.steps, with_drain=False)
         exchange_on[0] = True
         compute_only = 1e3 * max_over_ranks(dt_c) / args.steps
-        # and the other schedule, for the record (in-step <-> stale overlap)
+        # and the other schedule, for the record (in-step <-> stale overlap; not for the slot-sum plan: its packets can only be
+        # packed again -- a view that wants more rows than last step's -- while the backward's workspace is intact, in-step)
         mine = schedule[0]
-        schedule[0] = "in-step" if mine == "stale" else "stale"
-        for _ in range(4):
-            step()
-        drain()
-        dt_o, _ = timed(args.steps)
-        other_schedule = {"schedule": schedule[0], "ms_per_step": 1e3 * max_over_ranks(dt_o) / args.steps}
-        other_schedule["exposed_ms_per_step"] = other_schedule["ms_per_step"] - compute_only
-        drain()
+        if args.exchange != "slotsum":
+            schedule[0] = "in-step" if mine == "stale" else "stale"
+            for _ in range(4):
+                step()
+            drain()
+            dt_o, _ = timed(args.steps)
+            other_schedule = {"schedule": schedule[0], "ms_per_step": 1e3 * max_over_ranks(dt_o) / args.steps}
+            other_schedule["exposed_ms_per_step"] = other_schedule["ms_per_step"] - compute_only
+            drain()
         schedule[0] = mine
         cycle[0] = False
     single = world == 1 and not exchanging
@@ -776,13 +786,17 @@ def main():
                        "tile_list_mean": float(tile_len.mean()), "tile_list_max": int(tile_len.max()),
                        "parallelism": f"view-parallel x{world}", "ranks": world, "backend": (args.backend if dist else "none"),
                        "exchange": ("none" if not exchanging else
-                                    ("all 59 floats/Gaussian summed" if args.exchange == "allreduce" else
+                                    ("slot sums: 36-byte rows {masked dRGB, six pixel moments} of the Gaussians with a gradient, index-ordered "
+                                     f"behind a bit mask, all-gathered in {len(vpr.exchange.chunks)} fixed-capacity packets per view; every rank "
+                                     "runs the per-Gaussian chain for every view's rows in view order in one pass (frg_backward_combine)"
+                                     if args.exchange == "slotsum" else
+                                     "all 59 floats/Gaussian summed" if args.exchange == "allreduce" else
                                      "sparse: rows (index, 11 floats, dRGB: 64 B) of the Gaussians with a gradient -- counts, "
                                      "one padded all-gather, scatter-add in view order, summed SH gradient rebuilt per rank"
                                      if args.exchange == "sparse" else
                                      "factored: 11 floats/Gaussian summed + all-gather of dRGB (3 floats), "
                                      "summed SH gradient rebuilt per rank") +
-                                    ("" if args.exchange == "sparse" else ", RCCL all-reduce" if args.reduce == "allreduce" else
+                                    ("" if args.exchange in ("sparse", "slotsum") else ", RCCL all-reduce" if args.reduce == "allreduce" else
                                      ", direct: all-to-all of 1/N shards + local sum + all-gather") +
                                     {"in-step": ", in-step schedule: complete before the step ends (valid with a parameter update between "
                                                 "views); SH rebuild beside the dense sum",

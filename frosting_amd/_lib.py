@@ -97,6 +97,24 @@ class BackwardArgs(C.Structure):
                 ("row_live", C.c_void_p)]
 
 
+class CombineArgs(C.Structure):
+    """frg_combine_args (include/frosting_rasterizer.h)."""
+    _fields_ = [("struct_size", C.c_size_t),
+                ("P", C.c_int), ("first", C.c_int), ("count", C.c_int), ("n_views", C.c_int),
+                ("packets", C.c_void_p),
+                ("packet_stride_bytes", C.c_size_t),
+                ("capacity_rows", C.c_longlong),
+                ("M", C.c_int),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("opacities", C.c_void_p),
+                ("raw_opacities", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_rotations", C.c_void_p),
+                ("dL_dmean3D", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dsh", C.c_void_p),
+                ("status", C.c_void_p),
+                ("status_seq", C.c_uint),
+                ("row_live", C.c_void_p),
+                ("hip_stream", C.c_void_p)]
+
+
 def build(verbose: bool = False) -> str:
     """Compile every HIP translation unit for gfx950 (hipcc cross-compiles on CPU-only hosts)."""
     out = None if verbose else subprocess.DEVNULL
@@ -213,6 +231,12 @@ def lib():
     L.frg_pack_grad_rows.argtypes = [i, vp, vp, vp, vp, vp, vp, C.c_longlong, vp, vp]
     L.frg_scatter_grad_rows.restype = i
     L.frg_scatter_grad_rows.argtypes = [C.c_longlong, i, vp, vp, vp, vp, vp, vp, vp]
+    L.frg_sum_packet_bytes.restype = sz
+    L.frg_sum_packet_bytes.argtypes = [i, C.c_longlong]
+    L.frg_pack_sum_rows.restype = i
+    L.frg_pack_sum_rows.argtypes = [i, i, i, i, vp, sz, vp, vp, vp, vp, f, f, i, i, f, i, vp, sz, C.c_longlong, vp]
+    L.frg_backward_combine.restype = i
+    L.frg_backward_combine.argtypes = [C.POINTER(CombineArgs)]
     _lib = L
     return L
 
@@ -261,6 +285,7 @@ EXPORTED_SYMBOLS = [
     "frg_binning_bytes", "frg_geometry_layout", "frg_geometry_layout_n", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_mesh_visible_faces", "frg_mesh_occlusion_workspace_bytes", "frg_mesh_occlusion_mask", "frg_sh_color_grad", "frg_sh_grad_from_views",
     "frg_pack_grad_rows", "frg_scatter_grad_rows", "frg_adam_step_rows", "frg_adam_step_shard",
+    "frg_sum_packet_bytes", "frg_pack_sum_rows", "frg_backward_combine",
     "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_backward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",
     "frg_knn_workspace_bytes", "frg_knn_mean_dist2", "frg_shell_points", "frg_shell_points_backward",

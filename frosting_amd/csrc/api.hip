@@ -542,9 +542,12 @@ size_t frg_binning_bytes(int R, int max_tile_count) { return frg::BinningState::
 static size_t slots_bytes(int R) { return frg::align_up((size_t)(R > 0 ? R : 1) * FRG_SLOT_STRIDE * sizeof(float), 256); }
 // ... + the nine per-Gaussian sums a two-call backward (frg_backward_args::phase) keeps between its calls.  (The backward
 // blend's work items are listed by the forward, in its own chunks: frg_common.h, BinningState::bwd_full, ImageState::bwd_last.)
+static size_t sums_bytes(int P) { return frg::align_up((size_t)(P > 0 ? P : 1) * FRG_SLOT_FLOATS * sizeof(float), 256); }
+// ... + one bit per Gaussian, "its sums are not all zero", left by phase 1 for the slot-sum exchange (whole 256-Gaussian workgroups)
+static size_t live_mask_words(int P) { return (size_t)(P > 0 ? P : 1) / 64 + 8; }
 size_t frg_backward_workspace_bytes(int P, int R)
 {
-    return slots_bytes(R) + frg::align_up((size_t)(P > 0 ? P : 1) * FRG_SLOT_FLOATS * sizeof(float), 256);
+    return slots_bytes(R) + sums_bytes(P) + frg::align_up(live_mask_words(P) * 8, 256);
 }
 
 int frg_geometry_layout_n(int P, long long* out, int n)
@@ -957,6 +960,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     const frg::BinningState b = frg::BinningState::carve(binning_buffer, R, 0);
     float* slots = reinterpret_cast<float*>(workspace);
     float* sums = reinterpret_cast<float*>(workspace + slots_bytes(R));
+    unsigned long long* live_masks = phase == 1 ? reinterpret_cast<unsigned long long*>(workspace + slots_bytes(R) + sums_bytes(P)) : nullptr;
     if (phase < 0 || phase > 2) return fail(FRG_EINVAL, "frg_backward_args: phase %d (0 whole | 1 blend + slot sums | 2 the rest)", phase);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
@@ -1008,8 +1012,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         hipStream_t s_heavy = heavy_first ? stream : hs, s_plain = heavy_first ? hs : stream;
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
         if (!skip_heavy)
-            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy, sums), "preprocess_bwd (long runs)");
-        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain, sums), "preprocess_bwd");
+            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy, sums, live_masks), "preprocess_bwd (long runs)");
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain, sums, live_masks), "preprocess_bwd");
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
     }
     return FRG_OK;
@@ -1106,6 +1110,62 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
     if (reinterpret_cast<uintptr_t>(rows) % 16 != 0) return fail(FRG_EINVAL, "rows must be 16-byte aligned");
     FRG_HIP(frg::launch_scatter_grad_rows((unsigned int)n_rows, P, rows, dL_dmeans3D, dL_dscales, dL_drotations, dL_dopacity, drgb_dense,
                                           (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows)
+{
+    if (n_gaussians < 0 || capacity_rows < 0) return 0;
+    return frg::sum_packet_bytes((size_t)n_gaussians, (size_t)capacity_rows);
+}
+
+int frg_pack_sum_rows(int P, int R, int first, int count, const char* workspace, size_t workspace_bytes, const float* drgb_masked,
+                      const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                      int width, int height, float scale_modifier, int D, void* packet, size_t packet_bytes, long long capacity_rows,
+                      void* hip_stream)
+{
+    if (P < 0 || R < 0 || first < 0 || count < 0 || (long long)first + count > P || first % 64 != 0)
+        return fail(FRG_EINVAL, "bad range: P=%d first=%d (a multiple of 64) count=%d", P, first, count);
+    if (capacity_rows < 0 || capacity_rows > 0x7fffffffLL) return fail(FRG_EINVAL, "capacity_rows %lld", capacity_rows);
+    if (!workspace || workspace_bytes < frg_backward_workspace_bytes(P, R)) return fail(FRG_EALLOC, "not the workspace of a backward with P=%d R=%d", P, R);
+    if (!packet || packet_bytes < frg_sum_packet_bytes(count, capacity_rows) || reinterpret_cast<uintptr_t>(packet) % 16 != 0)
+        return fail(FRG_EALLOC, "packet: need %zu bytes, 16-byte aligned", frg_sum_packet_bytes(count, capacity_rows));
+    if (!drgb_masked || !viewmatrix || !projmatrix || !campos) return fail(FRG_EINVAL, "null pointer");
+    if (width <= 0 || height <= 0 || D < 0 || D > 3) return fail(FRG_EINVAL, "bad view: %dx%d degree %d", width, height, D);
+    const float* sums = reinterpret_cast<const float*>(workspace + slots_bytes(R));
+    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(workspace + slots_bytes(R) + sums_bytes(P));
+    const frg::SumCamera cam{tan_fovx, tan_fovy, scale_modifier, width, height, D};
+    FRG_HIP(frg::launch_pack_sum_rows(first, count, (uint32_t)capacity_rows, masks, sums, drgb_masked, cam, viewmatrix, projmatrix, campos, packet,
+                                      (hipStream_t)hip_stream));
+    return FRG_OK;
+}
+
+int frg_backward_combine(const frg_combine_args* a)
+{
+    if (!a || a->struct_size != sizeof(frg_combine_args))
+        return fail(FRG_EINVAL, "frg_combine_args: struct_size %zu, this library expects %zu", a ? a->struct_size : (size_t)0, sizeof(frg_combine_args));
+    if (a->P < 0 || a->first < 0 || a->count < 0 || (long long)a->first + a->count > a->P || a->first % 64 != 0)
+        return fail(FRG_EINVAL, "bad range: P=%d first=%d (a multiple of 64) count=%d", a->P, a->first, a->count);
+    if (a->n_views < 1 || a->n_views > 16) return fail(FRG_EINVAL, "1..16 views expected, got %d", a->n_views);
+    if (a->M != 16) return fail(FRG_EINVAL, "the combine pass takes SH rows of 16 coefficients (M = %d)", a->M);
+    if (a->count == 0) return FRG_OK;
+    if (!a->packets || a->packet_stride_bytes % 16 != 0 || a->packet_stride_bytes < frg_sum_packet_bytes(a->count, a->capacity_rows))
+        return fail(FRG_EINVAL, "packets: stride %zu, a packet of %d Gaussians and %lld rows has %zu bytes", a->packet_stride_bytes, a->count,
+                    a->capacity_rows, frg_sum_packet_bytes(a->count, a->capacity_rows));
+    if ((a->means3D == nullptr) || !a->shs) return fail(FRG_EINVAL, "means3D and shs are required (shell-bound centres are not offered here)");
+    if ((a->opacities == nullptr) == (a->raw_opacities == nullptr)) return fail(FRG_EINVAL, "provide exactly one of opacities / raw_opacities");
+    const bool raw_sr = a->raw_scales && a->raw_rotations;
+    if (raw_sr == (a->scales && a->rotations) || (a->raw_scales == nullptr) != (a->raw_rotations == nullptr) || (a->scales == nullptr) != (a->rotations == nullptr))
+        return fail(FRG_EINVAL, "provide (scales, rotations) or (raw_scales, raw_rotations)");
+    if (!a->dL_dmean3D || !a->dL_dscale || !a->dL_drot || !a->dL_dopacity || !a->dL_dsh) return fail(FRG_EINVAL, "null gradient output");
+    if ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(a->dL_dsh) | reinterpret_cast<uintptr_t>(a->dL_drot) |
+         reinterpret_cast<uintptr_t>(a->rotations) | reinterpret_cast<uintptr_t>(a->packets)) % 16 != 0)
+        return fail(FRG_EINVAL, "shs, rotations, dL_dsh, dL_drot and the packets must be 16-byte aligned");
+    frg::FwdInputs in{a->means3D, a->scales, a->rotations, a->opacities, a->shs, nullptr, nullptr, nullptr, nullptr, nullptr};
+    in.raw.raw_opacity = a->raw_opacities; in.raw.raw_scale = a->raw_scales; in.raw.raw_rot = a->raw_rotations;
+    frg::BwdOutputs out{nullptr, nullptr, a->dL_dopacity, nullptr, a->dL_dmean3D, nullptr, a->dL_dsh, a->dL_dscale, a->dL_drot};
+    FRG_HIP(frg::launch_backward_combine(a->first, a->count, a->n_views, a->packets, a->packet_stride_bytes, in, out, a->status, a->status_seq,
+                                         a->row_live, (hipStream_t)a->hip_stream));
     return FRG_OK;
 }
 

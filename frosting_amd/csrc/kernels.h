@@ -69,9 +69,10 @@ struct BwdOutputs {
 #define FRG_PBW_NO_HEAVY_LAUNCH 2  // the 16-wave launch is skipped: the plain kernel reduces waves of any slot count itself
 #define FRG_PBW_SUMS_ONLY 4        // phase 1 of a two-call backward: reduce the slots, store the nine sums per Gaussian (`sums`) and dL_dcolor, stop
 #define FRG_PBW_FROM_SUMS 8        // phase 2: take the nine sums from `sums` instead of reducing the slots; dL_dcolor is already written
+// live_masks (phase 1, optional): one bit per Gaussian -- "its nine sums are not all zero" -- as 64-bit words per wave of 64
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s, float* sums = nullptr);
+                                 bool heavy_only, hipStream_t s, float* sums = nullptr, unsigned long long* live_masks = nullptr);
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);
@@ -84,6 +85,22 @@ hipError_t launch_pack_grad_rows(int P, const float* g_means3D, const float* g_s
                                  const float* drgb, float* rows, unsigned int capacity, unsigned int* count, hipStream_t s);
 hipError_t launch_scatter_grad_rows(unsigned int n, int P, const float* rows, float* g_means3D, float* g_scales, float* g_rot,
                                     float* g_opac, float* drgb_dense, hipStream_t s);
+
+// slot-sum exchange (slot_exchange.hip): rows of the nine per-Gaussian sums of phase 1, packed in index order behind a bit mask;
+// one combine pass runs the per-Gaussian chain for every view's row in view order
+#define FRG_SUM_HDR_WORDS 64
+#define FRG_SUM_ROW_FLOATS 9
+#define FRG_SUM_MAGIC 0x46534d36u
+struct SumCamera { float tan_fovx, tan_fovy, scale_modifier; int width, height, D; };
+size_t sum_packet_bytes(size_t n, size_t capacity);
+// live_masks: one bit per Gaussian, as phase 1 of the backward leaves them in its workspace; sums: [P][9] of the same workspace
+hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsigned long long* live_masks, const float* sums,
+                                const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, void* packet, hipStream_t s);
+// in: means3D, shs, scales, rotations, opacities (or their raw forms); out: dL_dmean3D, dL_dscale, dL_drot, dL_dopacity, dL_dsh
+hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
+                                   const FwdInputs& in, const BwdOutputs& out, uint32_t* status, uint32_t seq, unsigned char* row_live,
+                                   hipStream_t s);
 
 // fused Adam over the flat parameter layout (adam.hip)
 #ifndef FRG_ADAM_MAX_SEGMENTS

@@ -62,7 +62,8 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int ablate,
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
                       const float* __restrict__ sh_dir, int flags, const uint32_t* __restrict__ heavy,
-                      const uint32_t* __restrict__ sh_layout, float* __restrict__ sums, unsigned char* __restrict__ row_live)
+                      const uint32_t* __restrict__ sh_layout, float* __restrict__ sums, unsigned char* __restrict__ row_live,
+                      unsigned long long* __restrict__ live_masks)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -278,6 +279,13 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // dL_dcolor, complete after the reduction, is written: with shs given and dL_dsh == NULL it is the clamp-masked colour
     // gradient, the payload of the factored view-parallel exchange, which can travel while phase 2 computes.
     if (flags & FRG_PBW_SUMS_ONLY) {
+        if (live_masks) {      // the slot-sum exchange packs the rows of these Gaussians (slot_exchange.hip): has_grad of phase 2
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < FRG_SLOT_FLOATS; c++) any |= part[c] != 0.0f;
+            const uint64_t m = __ballot(any && visible);
+            if (lane == 0) live_masks[idx0 / 64] = m;
+        }
         if (valid) {
 #pragma unroll
             for (int c = 0; c < FRG_SLOT_FLOATS; c++) sums[(size_t)idx * FRG_SLOT_FLOATS + c] = part[c];
@@ -618,7 +626,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s, float* sums)
+                                 bool heavy_only, hipStream_t s, float* sums, unsigned long long* live_masks)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
@@ -629,7 +637,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums, o.row_live)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums, o.row_live, live_masks)
     // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }

@@ -182,6 +182,8 @@ class GradientExchange:
         (csrc/view_exchange.hip).  2.6x fewer bytes over xGMI; identical on every rank and
         independent of the collective's reduction order for the SH part."""
 
+    slotsum = False      # (SlotSumExchange: the plan of round 6)
+
     def __init__(self, shapes: dict, device, process_group=None, average: bool = False,
                  factor_sh: bool = False, sh_reducer=None, reduce: str = "allreduce", sparse: bool = False,
                  row_packer=None, row_scatterer=None):
@@ -458,6 +460,225 @@ class GradientExchange:
             self._joined = None
 
 
+# ---- slot-sum exchange (round 6) ---------------------------------------------------------------------------------------------
+SUM_HDR_WORDS = 64      # frosting_amd/csrc/slot_exchange.hip: the packet's header ...
+SUM_ROW_FLOATS = 9      # ... and its rows {masked dRGB[3], six pixel moments}
+SUM_TILE = 1024         # chunk boundaries fall on the combine pass's tiles
+
+
+def sum_packet_words(n: int, capacity: int) -> int:
+    """32-bit words of a packet of n Gaussians with room for `capacity` rows (= frg_sum_packet_bytes / 4): header, one bit per
+    Gaussian, one row offset per block of 64, the rows."""
+    nblk = (n + 63) // 64
+    rows_at = (SUM_HDR_WORDS + 2 * nblk + nblk + 3) // 4 * 4
+    return (rows_at + SUM_ROW_FLOATS * capacity + 3) // 4 * 4
+
+
+def _hip_sum_packer(ex: "SlotSumExchange", chunk: int, dest: torch.Tensor):
+    """dest <- the packet of chunk `chunk` of THIS rank's view (frg_pack_sum_rows on the workspace phase 1 of the backward left)."""
+    if dest.device.type != "cuda":
+        raise RuntimeError("the slot-sum exchange packs its rows with a HIP kernel (no CPU path; tests inject their own packer)")
+    c = ex.view_ctx
+    first, count = ex.chunks[chunk]
+    cam = c["cam"]
+    stream = C.c_void_p(torch.cuda.current_stream(dest.device).cuda_stream)
+    rc = _lib.lib().frg_pack_sum_rows(ex.P, int(c["R"]), first, count, _p(c["work"]), c["work"].numel(), _p(ex.own_drgb),
+                                      _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos), float(cam.tanfovx), float(cam.tanfovy),
+                                      int(cam.image_width), int(cam.image_height), float(c.get("scale_modifier", 1.0)), int(c["D"]),
+                                      _p(dest), dest.numel() * 4, int(ex.capacity[chunk]), stream)
+    if rc < 0:
+        raise RuntimeError(f"frg_pack_sum_rows failed ({rc}): {_lib.last_error()}")
+
+
+def _hip_sum_combiner(ex: "SlotSumExchange", chunk: int, packets: torch.Tensor, n_views: int, seq: int):
+    """The flat gradient buffer's rows of chunk `chunk` <- the sum over the views' packets, in view order (frg_backward_combine)."""
+    if packets.device.type != "cuda":
+        raise RuntimeError("the slot-sum exchange combines the views with a HIP kernel (no CPU path; tests inject their own)")
+    first, count = ex.chunks[chunk]
+    g, pr = ex.views, ex.params
+    raw = ex.raw_params
+    v = lambda t: None if t is None else t.data_ptr()
+    a = _lib.CombineArgs(struct_size=C.sizeof(_lib.CombineArgs), P=ex.P, first=first, count=count, n_views=int(n_views),
+                         packets=v(packets), packet_stride_bytes=packets.shape[1] * 4, capacity_rows=int(ex.capacity[chunk]),
+                         M=int(ex.shapes["shs"][1]), means3D=v(pr["means3D"]), shs=v(pr["shs"]),
+                         scales=None if raw else v(pr["scales"]), rotations=None if raw else v(pr["rotations"]),
+                         opacities=None if raw else v(pr["opacities"]), raw_opacities=v(pr["opacities"]) if raw else None,
+                         raw_scales=v(pr["scales"]) if raw else None, raw_rotations=v(pr["rotations"]) if raw else None,
+                         dL_dmean3D=v(g["means3D"]), dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), dL_dopacity=v(g["opacities"]),
+                         dL_dsh=v(g["shs"]), status=v(ex.status[chunk]), status_seq=int(seq), row_live=None,
+                         hip_stream=torch.cuda.current_stream(packets.device).cuda_stream)
+    rc = _lib.lib().frg_backward_combine(C.byref(a))
+    if rc < 0:
+        raise RuntimeError(f"frg_backward_combine failed ({rc}): {_lib.last_error()}")
+
+
+class SlotSumExchange(GradientExchange):
+    """The exchange plan of round 6: ranks all-gather the nine per-Gaussian SLOT SUMS of their view's backward (phase 1) for
+    the Gaussians that have any -- 36-byte rows in index order behind a bit mask, a fixed-capacity packet per chunk of
+    Gaussians -- and every rank runs the per-Gaussian chain (phase 2) for EVERY view's rows itself, in view order, in one pass
+    that writes each of the 59 gradient floats of a Gaussian once (csrc/slot_exchange.hip).  Bit-identical to accumulating the
+    per-view gradients in one process.  Against the factored plan: a quarter of the wire bytes, no dense zero fills, no
+    per-view scatters, no SH rebuild, and no host wait for a count in front of the collective:
+
+      * capacity: the packets are sized from what the PREVIOUS step's views wanted (x slack), the first step for every
+        Gaussian; the wanted counts arrive with the packets and the combine pass posts them to pinned host memory as it
+        starts -- the host learns the verdict while the pass runs.  A view that wants more than the capacity makes every
+        rank (they all see the same headers) pack, gather and combine that chunk again with a larger one: rare, and correct.
+      * chunks: the Gaussians are cut into `chunks` index ranges with a packet and a collective each, so that the combine pass
+        of one range runs while the next range's packets are still on the wire.
+
+    Rank-local outputs of the backward (dL_dmeans2D -- the viewspace gradient --, dL_dcov3D, dL_dcolors) are NOT produced on
+    this path: phase 2 never runs for the own view alone."""
+
+    slotsum = True
+
+    def __init__(self, shapes: dict, device, process_group=None, average: bool = False, chunks: int = 2, slack: float = 1.25,
+                 packer=None, combiner=None, raw_params: bool = False):
+        super().__init__(shapes, device, process_group, average)
+        if "shs" not in self.shapes:
+            raise ValueError("the slot-sum exchange needs the SH parameterisation (shs)")
+        P = self.shapes["means3D"][0]
+        self.P = P
+        self.raw_params = raw_params
+        self.own_drgb = torch.zeros((P, 3), dtype=torch.float32, device=self.device)   # clamp-masked colour gradient, by phase 1
+        # chunk boundaries on whole tiles of the combine pass
+        tiles = (P + SUM_TILE - 1) // SUM_TILE
+        k = max(1, min(int(chunks), tiles))
+        cuts = [min(P, (tiles * i // k) * SUM_TILE) for i in range(k)] + [P]
+        self.chunks = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(k) if cuts[i + 1] > cuts[i]]
+        self.capacity = [n for _, n in self.chunks]                # first step: room for every Gaussian's row
+        self.slack = float(slack)
+        self.packer = packer or _hip_sum_packer
+        self.combiner = combiner or _hip_sum_combiner
+        pin = self.device.type == "cuda"
+        self.status = [torch.zeros(2 + 16, dtype=torch.int32, pin_memory=pin) for _ in self.chunks]
+        self.seq = 0
+        self.packet_own = [None] * len(self.chunks)
+        self.packets_all = [None] * len(self.chunks)
+        self.view_ctx = None
+        self.params = None
+        self.stats = {"rows_wanted_max": 0, "repacks": 0, "packet_bytes": 0}
+        self._no_post = False
+
+    def set_params(self, params: dict):
+        """The replicated parameters the combine pass reads: {'means3D','shs','scales','rotations','opacities'} (raw forms
+        with raw_params)."""
+        self.params = params
+
+    def note_view(self, **ctx):
+        """What the packer needs of the backward that just ran its phase 1: P-sized workspace `work`, R, cam, D, scale_modifier."""
+        self.view_ctx = ctx
+
+    @property
+    def wire_floats_per_rank(self) -> int:
+        return sum(sum_packet_words(n, cap) for (_, n), cap in zip(self.chunks, self.capacity))
+
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group)
+
+    def _ensure(self, c: int, world: int):
+        words = sum_packet_words(self.chunks[c][1], self.capacity[c])
+        if self.packet_own[c] is None or self.packet_own[c].numel() != words:
+            self.packet_own[c] = torch.zeros(words, dtype=torch.int32, device=self.device)
+        if self.packets_all[c] is None or tuple(self.packets_all[c].shape) != (world, words):
+            self.packets_all[c] = torch.zeros((world, words), dtype=torch.int32, device=self.device)
+
+    def _gather(self, c: int, world: int, async_op: bool):
+        import torch.distributed as dist
+        self._ensure(c, world)
+        self.packer(self, c, self.packet_own[c])
+        return dist.all_gather_into_tensor(self.packets_all[c].view(-1), self.packet_own[c], group=self.group, async_op=async_op)
+
+    def start(self, part: str = "all"):
+        """Pack this view's chunks and enqueue their all-gathers (one per chunk, in order) behind the work on the current stream."""
+        self._works = []
+        if not self._active():
+            return None
+        if self.view_ctx is None:
+            raise RuntimeError("slot-sum exchange: note_view() after the backward's phase 1 first")
+        world = self._world()
+        self._works = [self._gather(c, world, True) for c in range(len(self.chunks))]
+        self.stats["packet_bytes"] = 4 * self.wire_floats_per_rank
+        return self._works
+
+    def _finish_on_current_stream(self):
+        import torch.distributed as dist
+        if self.params is None:
+            raise RuntimeError("slot-sum exchange: call set_params() first")
+        world = self._world()
+        self.seq = self.seq % 0x7fffffff + 1
+        for c, w in enumerate(self._works):                       # chunk c's combine pass runs while chunk c + 1 travels
+            w.wait()
+            self.combiner(self, c, self.packets_all[c], world, self.seq)
+        self._works = []
+        wanted = [self._verdict(c, world) for c in range(len(self.chunks))]
+        for c, (over, counts) in enumerate(wanted):
+            if over:         # every rank reads the same headers: the same decision everywhere, no collective about it
+                intact = (self.view_ctx or {}).get("intact")
+                if intact is not None and not intact():
+                    raise RuntimeError("slot-sum exchange: a view wanted more rows than its packet holds, and the backward's workspace has "
+                                       "been overwritten since (the stale-overlap schedule): use the in-step schedule")
+                self.capacity[c] = min(self.chunks[c][1], (int(max(counts) * self.slack) // 256 + 1) * 256)
+                self.stats["repacks"] += 1
+                self._gather(c, world, False)
+                self.seq = self.seq % 0x7fffffff + 1
+                self.combiner(self, c, self.packets_all[c], world, self.seq)
+                over2, counts = self._verdict(c, world)
+                if over2:
+                    raise RuntimeError(f"slot-sum exchange: chunk {c} still overflows a capacity of {self.capacity[c]} rows (wanted {max(counts)})")
+            else:            # the next step's packets: what this step's views wanted, with slack (shrinks only by a clear margin)
+                want = min(self.chunks[c][1], (int(max(counts) * self.slack) // 256 + 1) * 256)
+                if want < 0.8 * self.capacity[c] or want > self.capacity[c]:
+                    self.capacity[c] = want
+            self.stats["rows_wanted_max"] = max(self.stats["rows_wanted_max"], max(counts))
+        if self.average:
+            self.flat.mul_(1.0 / dist.get_world_size(self.group))
+
+    def _verdict(self, c: int, world: int):
+        """(overflow?, rows wanted per view) of chunk c's last combine pass: posted by the pass to pinned host memory as it
+        starts (GPU), so the host polls instead of synchronising; written by the stand-in directly (CPU tests)."""
+        st = self.status[c]
+        if self.device.type == "cuda":
+            stream = torch.cuda.current_stream(self.device)
+            spins = 0
+            while not self._no_post and int(st[0]) != self.seq:
+                spins += 1
+                if spins % 256 == 0 and stream.query() and int(st[0]) != self.seq:
+                    self._no_post = True        # the stream drained without the post becoming visible: read the headers instead, from now on
+            if self._no_post:
+                hdr = self.packets_all[c][:world, :6].cpu()        # (synchronises: the plain way)
+                wants, caps = [int(x) for x in hdr[:, 1].tolist()], [int(x) for x in hdr[:, 3].tolist()]
+                return any(w > k for w, k in zip(wants, caps)), wants
+        elif int(st[0]) != self.seq:
+            raise RuntimeError("slot-sum exchange: the combine stand-in posted no verdict")
+        return bool(int(st[1])), [int(x) for x in st[2:2 + world].tolist()]
+
+    def finish_in_step(self):
+        if not self._works:
+            return self.flat
+        self._finish_on_current_stream()
+        return self.flat
+
+    # ---- one process playing every rank (tests, tools/combine_bench.py): view after view, then one combine ----
+    def pack_local_view(self, view_index: int, world: int):
+        """The packets of the view whose phase 1 just ran go where an all-gather would have put rank `view_index`'s."""
+        for c in range(len(self.chunks)):
+            self._ensure(c, world)
+            self.packer(self, c, self.packets_all[c][view_index])
+
+    def combine_local(self, world: int):
+        """The combine pass over `world` locally packed views -> [(overflow?, rows wanted per view)] per chunk."""
+        self.seq = self.seq % 0x7fffffff + 1
+        for c in range(len(self.chunks)):
+            self.combiner(self, c, self.packets_all[c], world, self.seq)
+        return [self._verdict(c, world) for c in range(len(self.chunks))]
+
+    def wait_on_side_stream(self):
+        if self._works:
+            self._finish_on_current_stream()
+
+
 def probe_reduce_plan(exchanges, iters: int = 5, warm: int = 3):
     """Time the sum of the dense part both ways -- the backend's all-reduce, and reduce-scatter + all-gather of 1/N shards
     ("direct") -- on the exchange buffers as they are (contents are summed over and over: garbage in, garbage out; the
@@ -562,7 +783,8 @@ class ViewParallelRasterizer:
 
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
                  deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce",
-                 write_all_outputs: bool = True, raw_params: bool = False, sparse: bool = False, live_rows: bool = False):
+                 write_all_outputs: bool = True, raw_params: bool = False, sparse: bool = False, live_rows: bool = False,
+                 slotsum: bool = False, chunks: int = 2):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
@@ -587,11 +809,10 @@ class ViewParallelRasterizer:
         # two gradient buffers: the exchange of step k may still be in flight on the
         # collective stream while step k+1 renders and writes the other buffer
         # sparse: the exchange moves rows of the Gaussians with a gradient (GradientExchange, third plan)
-        self.exchanges = [GradientExchange(shapes, self.dev, process_group, average, factor_sh=factor_sh, reduce=reduce, sparse=sparse)
+        # slotsum: the ranks exchange the slot sums of phase 1 and every rank runs phase 2 for every view (SlotSumExchange, round 6)
+        self._chunks = chunks
+        self.exchanges = [self._make_exchange(shapes, "slotsum" if slotsum else "sparse" if sparse else "factored" if factor_sh else "allreduce", reduce)
                           for _ in range(2)]
-        for ex in self.exchanges:
-            if ex.factor_sh:
-                ex.set_sh_context(scene.means3D, scene.sh_degree)
         self.exchange = self.exchanges[0]
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.dev)
         # rank-local (not exchanged) backward outputs.  dL_dcov3D is an intermediate of the chain when the covariance
@@ -610,19 +831,27 @@ class ViewParallelRasterizer:
         self.num_rendered = 0
         self._view = None
 
+    def _make_exchange(self, shapes, plan: str, reduce: str):
+        s = self.scene
+        if plan == "slotsum":
+            ex = SlotSumExchange(shapes, self.dev, self._group, self._average, chunks=self._chunks, raw_params=self.raw_params)
+            ex.set_params(dict(means3D=s.means3D, shs=s.shs, scales=s.scales, rotations=s.rotations, opacities=s.opacities))
+            return ex
+        ex = GradientExchange(shapes, self.dev, self._group, self._average, factor_sh=(plan != "allreduce"), reduce=reduce,
+                              sparse=(plan == "sparse"))
+        if ex.factor_sh:
+            ex.set_sh_context(s.means3D, s.sh_degree)
+        return ex
+
     def set_exchange_plan(self, plan: str, reduce: str = None):
-        """Replace the gradient exchange: 'allreduce' | 'factored' | 'sparse' (GradientExchange).  Pending collectives of the
-        old plan must have been waited for; the gradient buffers are new (zeroed)."""
+        """Replace the gradient exchange: 'allreduce' | 'factored' | 'sparse' (GradientExchange) | 'slotsum' (SlotSumExchange).
+        Pending collectives of the old plan must have been waited for; the gradient buffers are new (zeroed)."""
         old = self.exchanges[0]
         shapes = old.shapes
         reduce = reduce or old.reduce
         self.exchanges = None
         del old
-        self.exchanges = [GradientExchange(shapes, self.dev, self._group, self._average, factor_sh=(plan != "allreduce"), reduce=reduce,
-                                           sparse=(plan == "sparse")) for _ in range(2)]
-        for ex in self.exchanges:
-            if ex.factor_sh:
-                ex.set_sh_context(self.scene.means3D, self.scene.sh_degree)
+        self.exchanges = [self._make_exchange(shapes, plan, reduce) for _ in range(2)]
         self.exchange = self.exchanges[0]
 
     def forward(self, cam, bg, deferred=None, keep_mask=None, forward_only=False):
@@ -694,7 +923,7 @@ class ViewParallelRasterizer:
         self.true_num_rendered = n.value
         return True
 
-    def backward(self, dL_dimage, slot: int = 0, payload=None, phase: int = 0):
+    def backward(self, dL_dimage, slot: int = 0, payload=None, phase: int = 0, slot_sums: bool = False, local: bool = False):
         """Gradients of the last forward, written in place into exchange buffer `slot`.  In the
         factored plan under a process group, views["shs"] is only valid after wait_exchange(slot).
         payload: also fill this view's share of the factored exchange (masked colour gradient and
@@ -714,9 +943,19 @@ class ViewParallelRasterizer:
         self.exchange = ex = self.exchanges[slot]
         g = ex.views
         ex.flat._frg_rows_partial = bool(self.live_rows)     # (FlatAdam.step refuses such a buffer without its row mask)
+        # (slot_sums=True: one process playing every rank -- tests, tools; local=True: no exchange follows this backward --
+        # the whole backward of the own view, as without a process group)
+        slot_sums = ex.slotsum and not local and (ex._active() or slot_sums)
+        self._bwd_gen = getattr(self, "_bwd_gen", 0) + 1            # (the workspace now holds THIS backward's sums)
+        if slot_sums:
+            # slot-sum plan with live collectives: only phase 1 runs here -- the blend backward and the per-Gaussian slot sums;
+            # the sums travel, and the per-Gaussian chain runs for every view's rows in the exchange's combine pass
+            if phase == 2:
+                return g
+            phase = 1
         # factored plan with live collectives: the per-view SH rows are not materialised -- wait()
         # rebuilds their sum over views from the exchanged colour gradients
-        defer_sh = ex.factor_sh and ex._active()
+        defer_sh = (ex.factor_sh and ex._active()) or slot_sums
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -740,6 +979,11 @@ class ViewParallelRasterizer:
             rc = self._backward_plain(L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream)
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
+        if slot_sums:
+            gen = self._bwd_gen
+            ex.note_view(work=work, R=self.num_rendered, cam=cam, D=s.sh_degree, scale_modifier=1.0,
+                         intact=lambda: self._bwd_gen == gen)
+            return g
         if phase == 2:
             return g              # (the payload left with phase 1)
         if ex.factor_sh and (ex._active() if payload is None else payload):
@@ -786,7 +1030,7 @@ class ViewParallelRasterizer:
         exchanges[slot].finish_in_step() (or exchange_in_step(slot, started=True)).  Without a live factored exchange:
         a plain backward + start_exchange."""
         ex = self.exchanges[slot]
-        if not (ex.factor_sh and ex._active()) or ex.sparse:      # (sparse: one call -- its rows are packed from the finished gradients)
+        if not (ex.factor_sh and ex._active()) or ex.sparse:      # (sparse: one call -- its rows are packed from the finished gradients; slotsum: backward() runs phase 1 only)
             g = self.backward(dL_dimage, slot)
             ex.start()
             return g

@@ -167,7 +167,7 @@ typedef struct frg_forward_args {
 int frg_forward_ex(const frg_forward_args* args);
 
 /* Bytes of scratch frg_backward needs for a forward that returned R instances. */
-size_t frg_backward_workspace_bytes(int P, int R);   /* slots (36 B per instance) + the backward blend's work items + per-Gaussian sums (36 B per Gaussian) */
+size_t frg_backward_workspace_bytes(int P, int R);   /* slots (36 B per instance) + per-Gaussian sums (36 B per Gaussian) + one bit per Gaussian (phase 1: "has a gradient") */
 
 /* Replaces Rasterizer::backward (rasterizer.h:58-84, rasterizer_impl.cu:340-434).
  * All nine gradient arrays are fully written (zero rows for culled Gaussians);
@@ -407,6 +407,53 @@ int frg_pack_grad_rows(int P, const float* dL_dmeans3D, const float* dL_dscales,
                        const float* drgb, float* rows, long long capacity_rows, unsigned int* count, void* hip_stream);
 int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_dmeans3D, float* dL_dscales, float* dL_drotations,
                           float* dL_dopacity, float* drgb_dense, void* hip_stream);
+
+/* Slot-sum form of the exchange (round 6).  After phase 1 of a two-call backward (frg_backward_args::phase = 1) everything a
+ * view contributes to a Gaussian's gradient is determined by the nine per-Gaussian sums that call leaves in its workspace --
+ * the clamp-masked colour gradient and six pixel moments -- together with the parameters and the view's camera, which every
+ * rank holds.  Only the Gaussians a pixel reached have such sums (one in eight at 3 M Gaussians).  Ranks therefore exchange
+ * PACKETS of those sums instead of finished gradients, and every rank runs the per-Gaussian chain of phase 2 itself, for
+ * every view, in one pass:
+ *   frg_pack_sum_rows     (after phase 1, same P / R / workspace; drgb_masked = the dL_dcolor that call wrote with shs given
+ *                         and dL_dsh == NULL) writes the packet of Gaussians [first, first + count), first a multiple of 64:
+ *                         a 256-byte header (rows wanted / packed, the camera), one bit per Gaussian, one row offset per 64
+ *                         Gaussians, and the 36-byte rows {dRGB[3], moments[6]} of the marked Gaussians IN INDEX ORDER, at
+ *                         most capacity_rows of them.  Fixed size frg_sum_packet_bytes(count, capacity_rows): it can be
+ *                         all-gathered without any host knowing a count.  Header word 1 > capacity_rows: overflow, the
+ *                         packet is incomplete (pack again with a larger capacity; the workspace is untouched).
+ *   frg_backward_combine  n_views packets of the same range (packets + v * packet_stride_bytes, as an all-gather leaves them)
+ *                         -> dL_dmean3D, dL_dscale, dL_drot, dL_dopacity, dL_dsh of Gaussians [first, first + count): the sum
+ *                         over the views, IN VIEW ORDER, of what frg_backward phase 2 writes for each view -- every row
+ *                         written once (zeros where no view has a row; with row_live != NULL those are not written and the
+ *                         byte says so, as frg_backward_args::row_live).  Same expressions without contraction and the same
+ *                         order of additions as accumulating the per-view gradients in one process: the same bits.  M = 16
+ *                         coefficients; raw opacity / scale / rotation inputs as in frg_backward_ex (their Jacobians are applied
+ *                         per view, as there); shell-bound centres are not offered.
+ *                         status (optional; device or pinned host memory, 2 + n_views words): word 2 + v <- the rows view v
+ *                         wanted, word 1 <- 1 if any packet overflowed its capacity or does not describe this range, then
+ *                         word 0 <- status_seq (system-scope release): a host polling pinned memory learns the verdict while
+ *                         the pass runs, without synchronising the stream.  On overflow the outputs are incomplete. */
+size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows);
+int frg_pack_sum_rows(int P, int R, int first, int count, const char* workspace, size_t workspace_bytes, const float* drgb_masked,
+                      const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                      int width, int height, float scale_modifier, int D, void* packet, size_t packet_bytes, long long capacity_rows,
+                      void* hip_stream);
+typedef struct frg_combine_args {
+    size_t struct_size;
+    int P, first, count, n_views;
+    const void* packets;
+    size_t packet_stride_bytes;
+    long long capacity_rows;
+    int M;
+    const float *means3D, *shs, *scales, *rotations, *opacities;
+    const float *raw_opacities, *raw_scales, *raw_rotations;
+    float *dL_dmean3D, *dL_dscale, *dL_drot, *dL_dopacity, *dL_dsh;
+    unsigned int* status;
+    unsigned int status_seq;
+    unsigned char* row_live;
+    void* hip_stream;
+} frg_combine_args;
+int frg_backward_combine(const frg_combine_args* args);
 
 /* ---- fused Adam over the flat per-Gaussian parameter layout ---------------------------
  * SURVEY.md 8(f) rank 1, the step right after the backward / the gradient exchange.  Replaces

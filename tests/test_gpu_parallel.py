@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from frosting_amd import scenes
-from frosting_amd.parallel import GradientExchange, ViewParallelRasterizer, PARAM_ORDER
+from frosting_amd.parallel import GradientExchange, SlotSumExchange, ViewParallelRasterizer, PARAM_ORDER
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,83 @@ def test_rebuild_lower_degree_and_zero_views(gpu_device):
     assert float(ex.views["shs"].abs().max()) == 0.0
 
 
+def _slot_sum_views(vpr, name, views, dev, P, world=None, seed0=555):
+    """One process playing every rank of the slot-sum exchange: per view the one-call backward (the reference gradient of that
+    view) and, from the same forward, phase 1 + the view's packets where an all-gather would have put them."""
+    ex = vpr.exchange
+    world = world or len(views)
+    acc = {n: torch.zeros_like(ex.views[n]) for n in PARAM_ORDER}
+    for slot_v, k in enumerate(views):
+        scene, cam, bg = scenes.config_scene(name, k, P=P)
+        img, _ = vpr.forward(cam.to(dev), bg.to(dev))
+        gpix, _ = scenes.l1_target_grad(img.cpu(), seed0 + k)
+        gpix = gpix.to(dev)
+        g = vpr.backward(gpix, 0)                               # every gradient of this view, one call
+        for n in PARAM_ORDER:
+            acc[n] += g[n]                                      # the single-process accumulation, in view order
+        vpr.backward(gpix, 0, slot_sums=True)                   # phase 1 only: the nine sums + their bit mask in the workspace
+        ex.pack_local_view(slot_v, world)
+    return acc
+
+
+@pytest.mark.parametrize("name,P,views,chunks,degree,raw", [("mini", 5000, [0, 3, 5, 6], 1, 3, False), ("mini", 4807, [1, 2], 3, 1, False),
+                                                           ("c2", 80_000, list(range(8)), 2, 3, False), ("c2", 50_000, [0, 1, 2, 4], 2, 3, True)])
+def test_slot_sum_combine_is_the_accumulation_of_the_view_gradients_bit_for_bit(gpu_device, name, P, views, chunks, degree, raw):
+    """frg_pack_sum_rows + frg_backward_combine (round 6): the rows of the nine per-Gaussian sums phase 1 leaves, packed per view
+    in index order behind a bit mask, and ONE pass that runs the per-Gaussian chain for every view's row in view order --
+    against the gradients of the same views from one-call backwards, accumulated in view order in one process: every one of the
+    59 floats per Gaussian the same bits; lower SH degree; raw parameters (activation Jacobians per view); several chunks."""
+    dev = gpu_device
+    scene, _, _ = scenes.config_scene(name, 0, P=P)
+    scene.sh_degree = degree
+    if raw:
+        scene = scenes.Scene(scene.means3D, torch.log(scene.scales), scene.rotations * 1.7, torch.log(scene.opacities / (1 - scene.opacities)),
+                             scene.shs, degree)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, slotsum=True, chunks=chunks, raw_params=raw)
+    ex = vpr.exchange
+    assert isinstance(ex, SlotSumExchange) and len(ex.chunks) == chunks and sum(n for _, n in ex.chunks) == P
+    acc = _slot_sum_views(vpr, name, views, dev, P)
+    for t in ex.views.values():
+        t.fill_(float("nan"))                                   # every row must be written by the pass
+    verdicts = ex.combine_local(len(views))
+    torch.cuda.synchronize(dev)
+    total = [0] * len(views)
+    for over, counts in verdicts:
+        assert not over
+        total = [a + b for a, b in zip(total, counts)]
+    assert all(0 < t < P for t in total)                        # some Gaussians have a gradient in each view, not all
+    for n in PARAM_ORDER:
+        assert float(acc[n].abs().max()) > 0
+        assert torch.equal(ex.views[n], acc[n]), n
+
+
+def test_slot_sum_packets_report_an_overflow_and_fit_after_it(gpu_device):
+    """A packet is all-gathered at a fixed capacity; a view that wants more rows says so in its header, the combine pass posts
+    the verdict (pinned host memory), and the chunk is packed again with room for it: the sums are still in the workspace."""
+    dev = gpu_device
+    P, views = 20_000, [0, 1, 2]
+    scene, _, _ = scenes.config_scene("mini", 0, P=P)
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, slotsum=True, chunks=2)
+    ex = vpr.exchange
+    acc = _slot_sum_views(vpr, "mini", views, dev, P)
+    (o0, c0), (o1, c1) = ex.combine_local(len(views))
+    assert not o0 and not o1
+    want = [ex.views[n].clone() for n in PARAM_ORDER]
+    assert all(torch.equal(w, acc[n]) for w, n in zip(want, PARAM_ORDER))
+    ex.capacity = [max(c0) - 5, max(c1) + 3]                     # chunk 0: too small for its fullest view; chunk 1: just enough
+    ex.packets_all = [None, None]
+    _slot_sum_views(vpr, "mini", views, dev, P)
+    (o0, d0), (o1, d1) = ex.combine_local(len(views))
+    assert o0 and not o1 and d0 == c0 and d1 == c1               # the wanted counts arrive whatever the capacity
+    ex.capacity[0] = max(c0)
+    ex.packets_all[0] = None
+    _slot_sum_views(vpr, "mini", views, dev, P)
+    (o0, _), (o1, _) = ex.combine_local(len(views))
+    assert not o0 and not o1
+    assert all(torch.equal(ex.views[n], acc[n]) for n in PARAM_ORDER)
+
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -89,8 +166,9 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
     try:
         scene, cam, bg = scenes.config_scene("mini", 2, P=6000)
         ref = None
-        for factored in (False, True, "sparse"):
-            vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=bool(factored), sparse=factored == "sparse")
+        for factored in (False, True, "sparse", "slotsum"):
+            vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored is True or factored == "sparse",
+                                         sparse=factored == "sparse", slotsum=factored == "slotsum")
             img, _ = vpr.forward(cam.to(dev), bg.to(dev))
             gpix, _ = scenes.l1_target_grad(img.cpu(), 77)
             gpix = gpix.to(dev)
@@ -113,13 +191,17 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
             # the in-step schedule with the backward in two calls: the payload's all-gather is enqueued between the phases
             # (backward_overlapped), finish_in_step completes everything -- the same bits again
             vpr.forward(cam.to(dev), bg.to(dev))
-            own_before = vpr.exchanges[0].own.clone() if factored else None
+            own_before = vpr.exchanges[0].own.clone() if factored in (True, "sparse") else None
             vpr.backward_overlapped(gpix, 0)
             flat = vpr.exchange_in_step(0, started=True).clone()
             torch.cuda.synchronize(dev)
             assert torch.equal(flat, ref)
-            if factored:
+            if factored in (True, "sparse"):
                 assert torch.equal(vpr.exchanges[0].own, own_before)       # the payload phase 1 wrote = the one-call payload
+            if factored == "slotsum":    # one view: its rows, fewer than the visible Gaussians; the next step's packets are sized from them
+                st = vpr.exchanges[0].stats
+                assert 0 < st["rows_wanted_max"] <= int((vpr.radii > 0).sum()) and st["repacks"] == 0
+                assert sum(vpr.exchanges[0].capacity) < 6000
             if factored == "sparse":     # rows of the Gaussians with a gradient only: fewer than are visible, packed without a re-pack at this size
                 st = vpr.exchanges[0].sparse_stats
                 assert 0 < st["rows_own"] <= int((vpr.radii > 0).sum()) and st["rows_max"] == st["rows_own"]
@@ -212,7 +294,7 @@ def test_deferred_counters_forward_matches_blocking_forward(gpu_device):
     assert torch.equal(img, img0) and torch.equal(vpr.exchange.flat, flat0)
 
 
-def _rank_worker(rank, world, port, factored, P, q, sparse=False):
+def _rank_worker(rank, world, port, factored, P, q, sparse=False, slotsum=False):
     """One rank of a 2-rank job on GPU 0 (gloo carries the collectives: RCCL refuses two ranks per device)."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -222,7 +304,7 @@ def _rank_worker(rank, world, port, factored, P, q, sparse=False):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         scene, cam, bg = scenes.config_scene("mini", rank + 1, P=P)       # rank k renders view k + 1
-        vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored, sparse=sparse)
+        vpr = ViewParallelRasterizer(scene.to(dev), dev, process_group=dist.group.WORLD, factor_sh=factored, sparse=sparse, slotsum=slotsum)
         img, _ = vpr.forward(cam.to(dev), bg.to(dev))
         gpix, _ = scenes.l1_target_grad(img.cpu(), 555 + rank + 1)
         gpix = gpix.to(dev)
@@ -246,16 +328,16 @@ def _rank_worker(rank, world, port, factored, P, q, sparse=False):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("factored", [False, True, "sparse"])
+@pytest.mark.parametrize("factored", [False, True, "sparse", "slotsum"])
 def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
     import torch.multiprocessing as mp
     world, P = 2, 5000
-    sparse = factored == "sparse"
-    factored = bool(factored)
+    sparse, slotsum = factored == "sparse", factored == "slotsum"
+    factored = bool(factored) and not slotsum
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, factored, P, q, sparse)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, factored, P, q, sparse, slotsum)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -270,14 +352,14 @@ def test_two_ranks_sum_equals_single_process_sum(gpu_device, factored):
     want = torch.cat([(grads[0][n] + grads[1][n]).reshape(-1) for n in PARAM_ORDER]).cpu()
     for r in range(world):
         got = torch.from_numpy(res[r])
-        if factored:   # SH part: in-order sum, bit-exact; dense part: the all-reduce of two terms, exact as well
+        if factored or slotsum:   # SH part: in-order sum, bit-exact; dense part: the all-reduce of two terms (slot sums: the in-order sum), exact as well
             assert torch.equal(got, want)
         else:
             torch.testing.assert_close(got, want, rtol=0, atol=0)
     assert (res[0] == res[1]).all()
 
 
-@pytest.mark.parametrize("exchange", ["factored", "allreduce", "sparse", "auto"])
+@pytest.mark.parametrize("exchange", ["slotsum", "factored", "allreduce", "sparse", "auto"])
 def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
     """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under
     torch.distributed.run, both ranks share GPU 0 (FRG_BENCH_ONE_GPU) and exchange over gloo; rank 0 prints
@@ -300,7 +382,7 @@ def test_bench_two_ranks_from_a_bare_shell(gpu_device, exchange):
     assert out["config"]["exchange_bytes_per_rank"] > 0 and "exchange_timing" in out
     if exchange == "auto":      # both row-level plans were timed and one of them runs
         probe = out["config"]["exchange_probe_ms_per_step"]
-        assert set(probe) == {"factored", "sparse"} and all(v > 0 for v in probe.values()), probe
+        assert set(probe) == {"slotsum", "factored", "sparse"} and all(v > 0 for v in probe.values()), probe
     assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
 
 

@@ -213,7 +213,8 @@ def test_ctypes_structs_have_the_headers_layout(tmp_path):
     import subprocess
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     lines = []
-    for cname, ct in (("frg_forward_args", _lib.ForwardArgs), ("frg_backward_args", _lib.BackwardArgs)):
+    structs = (("frg_forward_args", _lib.ForwardArgs), ("frg_backward_args", _lib.BackwardArgs), ("frg_combine_args", _lib.CombineArgs))
+    for cname, ct in structs:
         lines.append(f'printf("{cname} sizeof %zu\\n", sizeof({cname}));')
         for fname, _ in ct._fields_:
             lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
@@ -227,7 +228,17 @@ def test_ctypes_structs_have_the_headers_layout(tmp_path):
         if ln.strip():
             cname, fname, val = ln.split()
             want[(cname, fname)] = int(val)
-    for cname, ct in (("frg_forward_args", _lib.ForwardArgs), ("frg_backward_args", _lib.BackwardArgs)):
+    for cname, ct in structs:
         assert C.sizeof(ct) == want[(cname, "sizeof")], cname
         for fname, _ in ct._fields_:
             assert getattr(ct, fname).offset == want[(cname, fname)], (cname, fname)
+
+
+def test_sum_packet_size_formula():
+    """frosting_amd.parallel.sum_packet_words (what the Python layer sizes its all-gather buffers with, on any backend) is the
+    library's frg_sum_packet_bytes: header, one bit per Gaussian, one row offset per 64 Gaussians, 36-byte rows."""
+    from frosting_amd.parallel import sum_packet_words
+    L = _lib.lib()
+    for n, cap in ((1, 0), (64, 64), (65, 7), (1000, 1000), (1_500_000, 204_800), (3_000_000, 3_000_000)):
+        assert 4 * sum_packet_words(n, cap) == L.frg_sum_packet_bytes(n, cap), (n, cap)
+    assert sum_packet_words(1_500_000, 204_800) * 4 < 0.15 * 1_500_000 * 36 + 400_000

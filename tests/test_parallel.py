@@ -296,6 +296,174 @@ def test_exchange_then_adam_then_next_forward_equals_single_process_accumulation
             assert (torch.from_numpy(res[r][k]) == params[k].detach()).all(), (r, k)     # bit for bit
 
 
+# ---- slot-sum exchange (round 6): the nine per-Gaussian sums of phase 1 travel, every rank runs the chain for every view ----------
+# Stand-ins for csrc/slot_exchange.hip (the product kernels are HIP-only) that write and read the SAME packet layout: header, one
+# bit per Gaussian, one row offset per 64 Gaussians, 36-byte rows in index order.
+
+def _sum_chain(params, rows, campos, S):
+    """A deterministic stand-in for the per-Gaussian backward chain: the 59 gradient floats of the Gaussians `rows` in one view
+    from their nine sums S [k, 9], the parameters and the view's camera centre.  Multiplications and additions only (the same
+    bits whatever the batch shape); zero sums give a zero row."""
+    m, sc, q, o, sh = (params[k][rows] for k in ("means3D", "scales", "rotations", "opacities", "shs"))
+    d = m - campos
+    w = S[:, 3:6] * d + S[:, 6:9]
+    return dict(means3D=w * sc + S[:, 0:3] * d,
+                scales=S[:, 3:6] * sc * sc + S[:, 6:9] * d,
+                rotations=q * (S[:, 3:4] * d[:, 0:1] + S[:, 8:9]) + S[:, 4:5] * o,
+                opacities=S[:, 8:9] * o + S[:, 5:6] * d[:, 1:2],
+                shs=sh * 0.0 + (S[:, None, 0:3] * (d[:, None, :] + 0.25)) * torch.arange(1, sh.shape[1] + 1, dtype=torch.float32)[None, :, None])
+
+
+def _view_sums(params, view, it, P):
+    """Phase 1 of view `view` at iteration `it`: nine sums per Gaussian, zero rows for the Gaussians no pixel reached -- one in
+    four in the first two iterations, three in four from the third (the packets sized from the earlier steps then overflow)."""
+    campos = torch.tensor([1.0 + view, 0.5 - view, 2.0]) * 0.5
+    base = torch.cat([params["means3D"], params["scales"], params["rotations"][:, :3]], 1)     # [P, 9]
+    S = base * (0.25 + 0.125 * view) + 0.0625 * (1 + it)
+    reached = (torch.arange(P) * 7 + 3 * view) % 4 == 0 if it < 2 else (torch.arange(P) * 7 + 3 * view) % 4 != 0
+    S[~reached] = 0.0
+    return campos, S
+
+
+def torch_sum_packer(ex, c, dest):
+    import numpy as np
+    from frosting_amd.parallel import SUM_HDR_WORDS, SUM_ROW_FLOATS, sum_packet_words
+    first, n = ex.chunks[c]
+    cap = ex.capacity[c]
+    S = ex.view_ctx["sums"][first:first + n]
+    live = (S != 0).any(1).numpy()
+    nblk = (n + 63) // 64
+    bits = np.zeros(nblk * 64, dtype=bool)
+    bits[:n] = live
+    masks = np.packbits(bits.reshape(nblk, 64), axis=1, bitorder="little").view(np.uint64).reshape(nblk)
+    counts = bits.reshape(nblk, 64).sum(1)
+    words = np.zeros(sum_packet_words(n, cap), dtype=np.int32)
+    assert words.size == dest.numel()
+    want = int(live.sum())
+    words[0:6] = [min(want, cap), want, n, cap, first, 0x46534d36]
+    words[40:43] = ex.view_ctx["campos"].numpy().view(np.int32)
+    words[SUM_HDR_WORDS:SUM_HDR_WORDS + 2 * nblk] = masks.view(np.int32)
+    b_at = SUM_HDR_WORDS + 2 * nblk
+    words[b_at:b_at + nblk] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+    r_at = (b_at + nblk + 3) // 4 * 4
+    rows = S.numpy()[live][:cap]
+    words[r_at:r_at + SUM_ROW_FLOATS * rows.shape[0]] = rows.reshape(-1).view(np.int32)
+    dest.copy_(torch.from_numpy(words))
+
+
+def torch_sum_combiner(ex, c, packets, n_views, seq):
+    import numpy as np
+    from frosting_amd.parallel import SUM_HDR_WORDS, SUM_ROW_FLOATS
+    first, n = ex.chunks[c]
+    nblk = (n + 63) // 64
+    b_at = SUM_HDR_WORDS + 2 * nblk
+    r_at = (b_at + nblk + 3) // 4 * 4
+    acc = {k: torch.zeros((n,) + tuple(ex.shapes[k][1:])) for k in PARAM_ORDER}
+    over, wants = False, []
+    for v in range(n_views):                                   # view order
+        w = packets[v].numpy()
+        assert int(w[2]) == n and int(w[4]) == first and int(w[5]) == 0x46534d36
+        want, cap = int(w[1]), int(w[3])
+        wants.append(want)
+        over |= want > cap
+        masks = w[SUM_HDR_WORDS:b_at].view(np.uint64)
+        bits = np.unpackbits(masks.view(np.uint8).reshape(nblk, 8), axis=1, bitorder="little").reshape(-1)[:n].astype(bool)
+        bases = w[b_at:b_at + nblk]
+        idx = np.nonzero(bits)[0]
+        # every Gaussian finds its row as base[block] + popcount(bits below it): here for all of them at once
+        rank_in_block = (np.cumsum(bits.reshape(-1)) - 1)[idx] - np.concatenate([[0], np.cumsum(bits[: nblk * 64 if n == nblk * 64 else n].astype(np.int64))])[idx // 64 * 64]
+        row = bases[idx // 64] + rank_in_block
+        ok = row < cap
+        idx, row = idx[ok], row[ok]
+        S = torch.from_numpy(w[r_at:].view(np.float32)[: SUM_ROW_FLOATS * cap].reshape(cap, SUM_ROW_FLOATS)[row].copy())
+        campos = torch.from_numpy(w[40:43].view(np.float32).copy())
+        rows = torch.from_numpy(idx).long()
+        g = _sum_chain(ex.params, rows + first, campos, S)
+        for k in PARAM_ORDER:
+            acc[k][rows] += g[k]                               # (indices are unique within a view)
+    for k in PARAM_ORDER:
+        ex.views[k][first:first + n] = acc[k]
+    st = ex.status[c]
+    st[1] = int(over)
+    st[2:2 + n_views] = torch.tensor(wants, dtype=torch.int32)
+    st[0] = seq
+
+
+def _slotsum_worker(rank, world, port, P, K, steps, chunks, q):
+    import torch.distributed as dist
+    from frosting_amd.parallel import SlotSumExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes, init = _initial_params(P, K)
+    params = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.Adam([params[k] for k in PARAM_ORDER], lr=0.01, eps=1e-15)
+    ex = SlotSumExchange(shapes, "cpu", dist.group.WORLD, chunks=chunks, packer=torch_sum_packer, combiner=torch_sum_combiner)
+    ex.set_params({k: v.detach() for k, v in params.items()})
+    caps = []
+    for it in range(steps):
+        with torch.no_grad():
+            campos, S = _view_sums({k: v.detach() for k, v in params.items()}, rank, it, P)
+        ex.note_view(sums=S, campos=campos)
+        ex.start()
+        ex.finish_in_step()                  # complete here, the re-pack of an overflowing chunk included
+        assert not ex._works
+        caps.append((list(ex.capacity), ex.stats["repacks"]))
+        for k in PARAM_ORDER:
+            params[k].grad = ex.views[k].clone()
+        opt.step()
+    q.put((rank, {k: params[k].detach().numpy().copy() for k in PARAM_ORDER}, caps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2)])
+def test_slot_sum_exchange_then_adam_equals_single_process_accumulation_gloo(world, chunks):
+    """SlotSumExchange on N ranks -- pack the view's rows at the capacity the previous step's views called for, all-gather the
+    packets chunk by chunk, run the chain for every view's rows in view order -- with Adam between the views equals the
+    single-process accumulation of the same views bit for bit; the packets shrink after the first step (every Gaussian has
+    room in it), and the step in which three times as many Gaussians have a gradient overflows them: every rank packs,
+    gathers and combines those chunks again, and the result is still the same bits."""
+    P, K, steps = 2500, 16, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slotsum_worker, args=(r, world, port, P, K, steps, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    res = {r: prm for r, prm, _ in got}
+    caps = {r: c for r, _, c in got}
+    shapes, init = _initial_params(P, K)
+    params = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.Adam([params[k] for k in PARAM_ORDER], lr=0.01, eps=1e-15)
+    allrows = torch.arange(P)
+    for it in range(steps):
+        acc = {k: torch.zeros(shapes[k]) for k in PARAM_ORDER}
+        with torch.no_grad():
+            cur = {k: t.detach() for k, t in params.items()}
+            for v in range(world):
+                campos, S = _view_sums(cur, v, it, P)
+                g = _sum_chain(cur, allrows, campos, S)         # the dense per-view gradient (zero rows where the sums are zero)
+                for k in PARAM_ORDER:
+                    acc[k] += g[k]
+        for k in PARAM_ORDER:
+            params[k].grad = acc[k].clone()
+        opt.step()
+    for r in range(world):
+        for k in PARAM_ORDER:
+            assert (torch.from_numpy(res[r][k]) == params[k].detach()).all(), (r, k)     # bit for bit
+    assert all(caps[r] == caps[0] for r in range(world))               # every rank took the same decisions
+    sizes = [sum(c) for c, _ in caps[0]]
+    repacks = [n for _, n in caps[0]]
+    assert sizes[0] < 0.5 * P and repacks[:2] == [0, 0]                # after step 0 the packets hold a quarter of the Gaussians + slack
+    assert repacks[2] == len(caps[0][0][0]) and sizes[2] > sizes[1]    # step 2: every chunk overflowed once and was packed again
+
+
 def _densify_worker(rank, world, port, P, steps, q):
     import torch.distributed as dist
     from frosting_amd.parallel import DensificationStats

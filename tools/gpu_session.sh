@@ -47,7 +47,7 @@ train)
   timeout 600 python tools/train_step.py > $O/train_step.log 2>&1; tail -6 $O/train_step.log ;;
 exchange)
   : > $O/exchange_1rank.log
-  for mode in "--exchange factored" "--exchange factored --sync-exchange" "--exchange factored --reduce direct" "--exchange allreduce" "--exchange sparse"; do
+  for mode in "--exchange slotsum" "--exchange slotsum --chunks 1" "--exchange slotsum --chunks 4" "--exchange factored" "--exchange factored --sync-exchange" "--exchange factored --reduce direct" "--exchange allreduce" "--exchange sparse"; do
     echo "== bench.py --force-exchange $mode" >> $O/exchange_1rank.log
     timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --force-exchange $mode 2>&1 | grep -v "^Librccl\|^RCCL\|^HIP\|^ROCm\|^Hostname\|amdgpu.ids" | tail -2 >> $O/exchange_1rank.log
   done
@@ -76,6 +76,13 @@ tworank)
   cat $O/two_rank.log ;;
 cmd)
   timeout ${CMD_TIMEOUT:-900} bash -c "$CMD" > $O/cmd.log 2>&1; echo "cmd rc=$?" >> $O/cmd.log; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" $O/cmd.log | tail -${CMD_TAIL:-60} ;;
+combine)
+  # the local terms of the slot-sum exchange: phase 1, pack, the combine pass over eight views' packets (tools/combine_bench.py)
+  : > $O/combine_bench.log
+  for a in "${COMBINE_ARGS:---config c3}" ; do
+    timeout 600 python tools/combine_bench.py $a 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" >> $O/combine_bench.log
+  done
+  cat $O/combine_bench.log | cut -c1-1500 ;;
 gradab)
   # the default arithmetic's distance to float64, one A/B build (tools/build_variants.sh) at a time: $GRADAB_LIBS = names under frosting_amd/lib_ab/
   : > $O/grad_ab.log

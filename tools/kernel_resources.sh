@@ -11,7 +11,7 @@ OUT="${OUT:-/tmp/kres}"; mkdir -p "$OUT"
 base="$(basename "$src" .hip)"
 extra=()
 case "$base" in
-  preprocess|preprocess_bwd|view_exchange|adam) extra=(-ffp-contract=off) ;;
+  preprocess|preprocess_bwd|view_exchange|slot_exchange|adam) extra=(-ffp-contract=off) ;;
   blend_exact) extra=(-ffp-contract=off -fno-slp-vectorize) ;;
   blend_fast) extra=(-ffp-contract=off -fno-slp-vectorize) ;;
 esac
