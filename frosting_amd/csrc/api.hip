@@ -214,13 +214,12 @@ std::atomic<int> g_bwd_heavy_first{1};
 std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
 
 // What the host remembers about the forward that last filled a geometry buffer (process-wide: autograd runs the backward
-// on another thread than the forward): which mailbox post is its scatter's, and the arithmetic of its blend, so that a
-// backward called without an explicit mode (the reference's 21-argument signature has no place for one) follows ITS
-// forward, not whatever frg_set_option says by then.  A ring of kFwdNotes entries: with more forwards than that
-// outstanding the oldest are forgotten -- their backward then launches both forms of the per-Gaussian backward (as if
-// nothing had been posted) and reads the forward's blend modes back from the image chunk, where the forward blend stamped
-// them (Counters::fwd_flags: one blocking 4-byte copy -- the same path serves buffers that were cloned or restored at another
-// address).  The notes are a convenience that saves that copy, never the only carrier of a mode.  The pinned mailboxes are never freed.
+// on another thread than the forward): which mailbox post is its scatter's, how many instances it rendered, whether it was
+// told that no backward follows.  Scheduling hints and early refusals only -- keyed by ADDRESS, a note can be stale (a buffer
+// copied to an address an earlier forward used), so nothing that decides a gradient bit hangs on one: the blend arithmetic
+// and "nothing kept" are stamped into the image chunk by the forward's blend kernel (Counters::fwd_flags) and read there
+// (backward_impl).  A ring of kFwdNotes entries; a forgotten forward's backward launches both forms of the per-Gaussian
+// backward (as if nothing had been posted).  The pinned mailboxes are never freed.
 struct FwdNote { const void* geom = nullptr; const frg::Mailbox* mail = nullptr; uint32_t seq = 0; int exact = -1; int rendered = -1; bool fwd_only = false; };
 constexpr int kFwdNotes = 1024;
 std::mutex g_heavy_mu;
@@ -258,13 +257,6 @@ void note_heavy_post(const void* geom, const frg::Mailbox* mail, uint32_t seq)
 {
     std::lock_guard<std::mutex> lk(g_heavy_mu);
     for (auto& n : g_fwd_notes) if (n.geom == geom) { n.mail = mail; n.seq = seq; return; }
-}
-// -> the blend arithmetic (0 fast | 1 exact) of the forward that last filled `geom`, or -1 when it is not remembered
-int forward_exact_mode(const void* geom)
-{
-    std::lock_guard<std::mutex> lk(g_heavy_mu);
-    for (const auto& n : g_fwd_notes) if (n.geom == geom) return n.exact;
-    return -1;
 }
 // -> the number of heavy waves of the forward that last filled `geom`, or -1 when unknown (no post, not arrived yet,
 // the mailbox already belongs to a later forward)
@@ -923,30 +915,34 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     // R sizes the slots and the backward blend's item list: fewer than the forward rendered would overrun them.  (More is
     // fine -- a deferred forward's capacity: where the forward's checkpoints lie in the binning chunk is taken from what the
     // forward stamped, Counters::carved_R, not from R.)
-    // The arithmetic of this backward's blend pass (the backward recomputes its forward's alpha, T and contributor tests:
-    // the same arithmetic keeps them consistent) and whether that forward kept anything for a backward: what the host
-    // remembers of the forward that last filled geom_buffer -- or, for a buffer it does not know (cloned, offloaded and
-    // restored at another address, more than kFwdNotes forwards ago), what that forward's blend kernel stamped into the image
-    // chunk, read back here with one blocking 4-byte copy.  An explicit frg_backward_args::exact_blend only overrides the
-    // arithmetic.  Never the process-wide option of the moment: that only shapes forwards.
-    int noted_exact = forward_exact_mode(geom_buffer), noted_only = forward_was_forward_only(geom_buffer);
-    if (noted_only < 0 && phase != 2) {
-        uint32_t flags = 0;
+    // The arithmetic of this backward's blend pass (the backward recomputes its forward's alpha, T and contributor tests: the
+    // same arithmetic keeps them consistent) and whether that forward kept anything for a backward were stamped into the
+    // image chunk by the forward's blend kernel (Counters::fwd_flags): they travel with the buffers.  The host's notes are
+    // keyed by ADDRESS -- a buffer copied to an address some earlier forward used would inherit that forward's note -- so
+    // they decide nothing a stamp can contradict:
+    //   * arithmetic: what the caller states (frg_backward_args::exact_blend; the Python layer carries it in its autograd
+    //     ctx), else BOTH instantiations are launched and each leaves at once unless the stamp names it (exact = -1 below);
+    //   * forward_only: a note that says "an ordinary forward" lets the call through (a forward_only stamp then still leaves
+    //     the kernels without work); anything else -- no note, or a note that says forward_only -- is settled by reading the
+    //     stamp back, one blocking 4-byte copy, which also tells the arithmetic.
+    //   * R: a note that says the forward rendered MORE instances than this call's R (slots and item lists would overrun) is
+    //     checked against the stamped count the same way before the call is refused.
+    int exact = exact_mode == 0 ? -1 : FwdModes::pick(exact_mode, 1, 0);
+    const int noted_rendered = forward_rendered(geom_buffer);
+    if ((forward_was_forward_only(geom_buffer) != 0 || (noted_rendered >= 0 && R < noted_rendered)) && phase != 2) {
+        frg::Counters* host = pinned_counters();
+        if (!host) return fail(FRG_EHIP, "hipHostMalloc failed");
         const frg::ImageState img0 = frg::ImageState::carve(image_buffer, width, height, false);
-        FRG_HIP(hipMemcpyAsync(&flags, &img0.counters->fwd_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+        FRG_HIP(hipMemcpyAsync(host, img0.counters, sizeof(frg::Counters), hipMemcpyDeviceToHost, stream));
         FRG_HIP(hipStreamSynchronize(stream));
+        const uint32_t flags = host->fwd_flags;
         if (!(flags & FRG_FWD_STAMPED))
             return fail(FRG_EINVAL, "the image buffer carries no forward's stamp: these are not the buffers of a completed frg_forward");
-        noted_exact = (flags & FRG_FWD_EXACT) ? 1 : 0;
-        noted_only = (flags & FRG_FWD_ONLY) ? 1 : 0;
-    }
-    const int exact = FwdModes::pick(exact_mode, 1, noted_exact >= 0 ? noted_exact : exact_blend());
-    if (noted_only > 0)
-        return fail(FRG_EINVAL, "the forward that filled these buffers was called with forward_only = 1: it kept nothing for a backward");
-    {
-        const int rendered = forward_rendered(geom_buffer);
-        if (rendered >= 0 && R < rendered)
-            return fail(FRG_EINVAL, "R = %d, but the forward that filled this geometry buffer rendered %d instances", R, rendered);
+        if (flags & FRG_FWD_ONLY)
+            return fail(FRG_EINVAL, "the forward that filled these buffers was called with forward_only = 1: it kept nothing for a backward");
+        if ((uint32_t)R < host->num_rendered)
+            return fail(FRG_EINVAL, "R = %d, but the forward that filled this geometry buffer rendered %u instances", R, host->num_rendered);
+        if (exact < 0) exact = (flags & FRG_FWD_EXACT) ? 1 : 0;
     }
     (void)colors_precomp;  // forward copied precomputed colours into the geometry state
 
@@ -989,10 +985,10 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     }
     {
         StageScope sc_(ST_BLEND_BWD, stream);
-        if (exact)
-            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream), "blend_bwd");
-        else
-            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream), "blend_bwd");
+        if (exact != 0)
+            FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream, exact < 0), "blend_bwd");
+        if (exact <= 0)
+            FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream, exact < 0), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
     {
@@ -1113,6 +1109,31 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
     return FRG_OK;
 }
 
+// side stream of the combine pass's SH kernel (one per host thread, re-created when the thread's current device changes)
+namespace {
+struct CombineSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+    bool ensure()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev == device) return true;
+        if (stream) (void)hipStreamDestroy(stream);
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        stream = nullptr; fork = nullptr; join = nullptr; device = -1;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        device = dev;
+        return true;
+    }
+};
+thread_local CombineSide g_combine_side;
+}  // namespace
+
 size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows)
 {
     if (n_gaussians < 0 || capacity_rows < 0) return 0;
@@ -1164,8 +1185,14 @@ int frg_backward_combine(const frg_combine_args* a)
     frg::FwdInputs in{a->means3D, a->scales, a->rotations, a->opacities, a->shs, nullptr, nullptr, nullptr, nullptr, nullptr};
     in.raw.raw_opacity = a->raw_opacities; in.raw.raw_scale = a->raw_scales; in.raw.raw_rot = a->raw_rotations;
     frg::BwdOutputs out{nullptr, nullptr, a->dL_dopacity, nullptr, a->dL_dmean3D, nullptr, a->dL_dsh, a->dL_dscale, a->dL_drot};
+    // the dense pass (latency / instruction bound) on the caller's stream, the SH pass (708 MB of rows: HBM bound) beside it
+    hipStream_t stream = (hipStream_t)a->hip_stream;
+    const bool side = g_combine_side.ensure();
+    hipStream_t s_sh = side ? g_combine_side.stream : stream;
+    if (side) { FRG_HIP(hipEventRecord(g_combine_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(s_sh, g_combine_side.fork, 0)); }
     FRG_HIP(frg::launch_backward_combine(a->first, a->count, a->n_views, a->packets, a->packet_stride_bytes, in, out, a->status, a->status_seq,
-                                         a->row_live, (hipStream_t)a->hip_stream));
+                                         a->row_live, stream, s_sh));
+    if (side) { FRG_HIP(hipEventRecord(g_combine_side.join, s_sh)); FRG_HIP(hipStreamWaitEvent(stream, g_combine_side.join, 0)); }
     return FRG_OK;
 }
 

@@ -14,8 +14,8 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
 }
 
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s)
+                                 const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s, bool as_stamped)
 {
-    return launch_blend_bwd_t<false>(vp, g, img, b, bg, dL_dpix, slots, R, batch, s);
+    return launch_blend_bwd_t<false>(vp, g, img, b, bg, dL_dpix, slots, R, batch, s, as_stamped);
 }
 }  // namespace frg

@@ -455,10 +455,20 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
                  const float* __restrict__ dL_dpix, float* __restrict__ slots, uint2* __restrict__ cutoff,
                  const uint32_t* __restrict__ bwd_cnt, const uint32_t* __restrict__ bwd_last, uint32_t cap_b,
                  const uint32_t* __restrict__ tile_work,
-                 const char* __restrict__ binning_base, const Counters* __restrict__ counters, const float4* __restrict__ final_C)
+                 const char* __restrict__ binning_base, const Counters* __restrict__ counters, const float4* __restrict__ final_C,
+                 int as_stamped)
 {
     using M = BlendMath<EXACT>;
     const int lane = threadIdx.x;
+    // What the forward's blend kernel stamped into the image chunk: a forward that kept nothing for a backward leaves no work
+    // (and no valid checkpoints); and when the host does not state the arithmetic (as_stamped: it launches BOTH instantiations,
+    // api.hip) only the one whose arithmetic is the forward's runs -- the stamp travels with the buffers, wherever they were
+    // copied to and however long ago the forward ran.
+    {
+        const uint32_t flags = counters->fwd_flags;
+        if (flags & FRG_FWD_ONLY) return;
+        if (as_stamped && ((flags & FRG_FWD_EXACT) != 0u) != EXACT) return;
+    }
     // The forward's checkpoints and its list of full-segment items: behind point_list and pairs of the chunk as the FORWARD
     // carved it (Counters::carved_R) -- the R this backward was called with may be the frame's instance count or a deferred
     // forward's capacity; the segment length is the one the forward blend stamped.
@@ -773,7 +783,7 @@ static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, c
 extern int g_bwd_waves;       // tuning (frg_set_option("bwd_waves")): single-wave workgroups of the backward blend (0: the default)
 template <bool EXACT>
 static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                     const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s)
+                                     const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s, bool as_stamped)
 {
     const int T = vp.gx * vp.gy;
     // waves: one per item while the frame has at most FRG_BWD_MAX_WAVES items (an upper bound on their number), beyond
@@ -784,7 +794,7 @@ static hipError_t launch_blend_bwd_t(const ViewParams& vp, const GeomState& g, c
     hipLaunchKernelGGL((blend_bwd_kernel<EXACT, B>), dim3(nwaves), dim3(64), 0, s, T, vp.gx, vp.gy, vp.W, vp.H,               \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, g.point_offsets, bg, img.final_T,     \
                        img.n_contrib, dL_dpix, slots, img.cutoff, img.bwd_cnt, img.bwd_last, img.bwd_cap_b, img.tile_work,     \
-                       reinterpret_cast<const char*>(b.point_list), img.counters, img.final_C)
+                       reinterpret_cast<const char*>(b.point_list), img.counters, img.final_C, as_stamped ? 1 : 0)
     if (batch == 2) FRG_BWD(2); else FRG_BWD(3);
 #undef FRG_BWD
     return hipGetLastError();

@@ -50,10 +50,12 @@ hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const
                                  const float* bg, float* out_color, hipStream_t s, bool forward_only = false);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 // R: the instance count the caller sized the slots for (bounds the number of work items: the grid)
+// as_stamped: the host launches BOTH arithmetics and each kernel leaves at once unless the forward's stamp (Counters::fwd_flags)
+// names it; either way a forward_only stamp leaves the launch without work
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s);
+                                  const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s, bool as_stamped = false);
 hipError_t launch_blend_bwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s);
+                                 const float* bg, const float* dL_dpix, float* slots, uint32_t R, int batch, hipStream_t s, bool as_stamped = false);
 
 struct BwdOutputs {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
@@ -98,9 +100,10 @@ hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsig
                                 const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, void* packet, hipStream_t s);
 // in: means3D, shs, scales, rotations, opacities (or their raw forms); out: dL_dmean3D, dL_dscale, dL_drot, dL_dopacity, dL_dsh
+// s: the dense pass (11 floats per Gaussian); s_sh: the SH pass (48) -- the same stream, or a side stream ordered by the caller
 hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
                                    const FwdInputs& in, const BwdOutputs& out, uint32_t* status, uint32_t seq, unsigned char* row_live,
-                                   hipStream_t s);
+                                   hipStream_t s, hipStream_t s_sh);
 
 // fused Adam over the flat parameter layout (adam.hip)
 #ifndef FRG_ADAM_MAX_SEGMENTS

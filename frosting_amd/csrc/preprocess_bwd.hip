@@ -142,6 +142,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     uint16_t* live = reinterpret_cast<uint16_t*>(shbuf + 96);           // [BWD_WIN] behind own_co / own_xy
     if (ablate & 1) S = 0;   // TIMING EXPERIMENT ONLY (frg_set_option("ablate")): no slot reduction
     if (flags & FRG_PBW_FROM_SUMS) S = 0;   // phase 2 of a two-call backward: the sums were left by phase 1
+    if (counters->fwd_flags & FRG_FWD_ONLY) S = 0;   // the forward kept nothing for a backward (and the blend backward wrote no slot): zero rows
     const uint32_t nwin = (S + BWD_WIN - 1) / BWD_WIN;                   // wave-uniform
     // on the forward's list: the 16-wave launch has it -- unless the host skipped that launch (FRG_PBW_NO_HEAVY_LAUNCH:
     // its forward posted "no such wave"), in which case a wave that does own that many slots is reduced right here,

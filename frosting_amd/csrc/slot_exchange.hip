@@ -29,7 +29,7 @@ namespace frg {
 // ---- packet layout (uint32 words) -------------------------------------------------------------------------------------------
 //   [0] rows packed  [1] rows wanted (> capacity: overflow)  [2] Gaussians of the packet  [3] capacity  [4] first Gaussian
 //   [5] magic  [8..23] viewmatrix  [24..39] projmatrix  [40..42] camera centre  [43] tan_fovx  [44] tan_fovy
-//   [45] width  [46] height  [47] scale_modifier  [48] active SH degree
+//   [45] width  [46] height  [47] scale_modifier  [48] active SH degree  [49] focal_x  [50] focal_y (api.hip make_view's)
 //   masks   uint64[nblk]  at word 64                 (nblk = blocks of 64 Gaussians)
 //   bases   uint32[nblk]  behind them, 16-byte aligned
 //   rows    float[capacity][9] behind them, 16-byte aligned
@@ -39,36 +39,49 @@ __host__ __device__ inline size_t sum_packet_rows_word(size_t n) { return (sum_p
 size_t sum_packet_bytes(size_t n, size_t capacity) { return ((sum_packet_rows_word(n) + FRG_SUM_ROW_FLOATS * capacity + 3) / 4 * 4) * 4; }
 
 // One workgroup: the packet's masks (copied from the phase-1 workspace), the exclusive prefix of their popcounts, the header.
+// Rounds of 16 x 1024 blocks: a thread's sixteen mask words are requested together (coalesced across the workgroup), then
+// sixteen workgroup scans of 1024 counts (DPP wave scans + one LDS hop) carry the running total.  (Round 6's first form -- a
+// contiguous run of blocks per thread, read one after the other -- took 70 us per 23 000 blocks: a chain of dependent
+// uncoalesced loads.)
+#define SUM_SCAN_PER 16
 __global__ void __launch_bounds__(1024)
 sum_rows_scan_kernel(int first, int n, uint32_t capacity, const unsigned long long* __restrict__ live_masks,
                      uint32_t* __restrict__ packet, SumCamera cam, const float* __restrict__ viewmatrix,
                      const float* __restrict__ projmatrix, const float* __restrict__ campos)
 {
-    __shared__ uint32_t part[1024];
-    const int nblk = (int)sum_packet_blocks((size_t)n), tid = threadIdx.x;
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int nblk = (int)sum_packet_blocks((size_t)n), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(packet + FRG_SUM_HDR_WORDS);
     uint32_t* bases = packet + sum_packet_bases_word((size_t)n);
-    const int per = (nblk + 1023) / 1024, b0 = tid * per, b1 = min(nblk, b0 + per);
     const unsigned long long* src = live_masks + first / 64;
-    uint32_t sum = 0;
-    for (int b = b0; b < b1; b++) sum += (uint32_t)__popcll(src[b]);
-    part[tid] = sum;
+    if (tid == 0) carry_s = 0u;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {           // inclusive scan of the threads' totals
-        const uint32_t up = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += up;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - sum;
-    for (int b = b0; b < b1; b++) {
-        const unsigned long long m = src[b];
-        masks[b] = m;
-        bases[b] = run;
-        run += (uint32_t)__popcll(m);
+    for (int r0 = 0; r0 < nblk; r0 += 1024 * SUM_SCAN_PER) {
+        unsigned long long m[SUM_SCAN_PER];
+#pragma unroll
+        for (int i = 0; i < SUM_SCAN_PER; i++) {
+            const int b = r0 + i * 1024 + tid;
+            m[i] = b < nblk ? src[b] : 0ull;
+        }
+#pragma unroll 1
+        for (int i = 0; i < SUM_SCAN_PER; i++) {
+            if (r0 + i * 1024 >= nblk) break;                    // workgroup-uniform
+            const int b = r0 + i * 1024 + tid;
+            const uint32_t c = (uint32_t)__popcll(m[i]);
+            const uint32_t incl = wave_incl_scan_dpp(c);
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            uint32_t before = carry_s;
+            for (int w = 0; w < wave; w++) before += wave_tot[w];
+            if (b < nblk) { masks[b] = m[i]; bases[b] = before + incl - c; }
+            __syncthreads();
+            if (tid == 1023) carry_s = before + incl;
+            __syncthreads();
+        }
     }
     if (tid == 0) {
-        const uint32_t want = part[1023];
+        const uint32_t want = carry_s;
         packet[0] = want < capacity ? want : capacity;
         packet[1] = want;
         packet[2] = (uint32_t)n; packet[3] = capacity; packet[4] = (uint32_t)first; packet[5] = FRG_SUM_MAGIC;
@@ -79,7 +92,9 @@ sum_rows_scan_kernel(int first, int n, uint32_t capacity, const unsigned long lo
         f[43] = cam.tan_fovx; f[44] = cam.tan_fovy;
         packet[45] = (uint32_t)cam.width; packet[46] = (uint32_t)cam.height;
         f[47] = cam.scale_modifier; packet[48] = (uint32_t)cam.D;
-        for (int i = 49; i < FRG_SUM_HDR_WORDS; i++) packet[i] = 0u;
+        f[49] = cam.width / (2.0f * cam.tan_fovx);        // rasterizer_impl.cu:222-223, as api.hip make_view forms them
+        f[50] = cam.height / (2.0f * cam.tan_fovy);
+        for (int i = 51; i < FRG_SUM_HDR_WORDS; i++) packet[i] = 0u;
     }
 }
 
@@ -114,21 +129,82 @@ hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsig
 }
 
 // ---- combine ------------------------------------------------------------------------------------------------------------------
+// Two kernels over the same packets, independent of each other (api.hip launches them on two streams):
+//   combine_dense_kernel   dL_dmean3D, dL_dscale, dL_drot, dL_dopacity (11 floats per Gaussian): the geometric chain.  A (Gaussian,
+//                          view) pair costs ~700 vector instructions and only one Gaussian in eight has a row in a given view
+//                          (their union over eight ring views: 45 % of the Gaussians), so the Gaussians with a row anywhere are
+//                          COMPACTED over a tile of 1024 and one lane per such Gaussian walks its views in view order.
+//   combine_sh_kernel      dL_dsh (48 floats per Gaussian): sum over the views of basis(dir_v) (x) dRGB_v -- cheap per pair (the
+//                          basis and 48 products), dominated by its 192-byte rows: one lane per Gaussian, the views in a
+//                          wave-uniform loop, the rows leave as one float4 stream through an LDS transpose (the form of
+//                          view_exchange.hip's rebuild, with the colour gradients looked up in the packets instead of dense planes).
+// (One kernel holding all 59 accumulators, the camera and the chain's temporaries took 334 VGPRs -- one wave per SIMD -- and
+// 1.0 ms for eight C3 views.)
 #define CMB_THREADS 256
-#define CMB_TILE 1024                   // Gaussians per workgroup: the ones with a row in some view are compacted over the tile
+#define CMB_TILE 1024                   // Gaussians per workgroup of the dense pass
 #define CMB_MAX_VIEWS 16
 
 struct CmbCam { float view[16], proj[16], campos[3], tan_fovx, tan_fovy, focal_x, focal_y, half_w, half_h, scale_modifier; int D; };
 
-// sections 2 - 5 of preprocess_bwd_kernel for ONE (Gaussian, view): `part` = the view's nine slot sums of the Gaussian, the
-// colour part already clamp-masked.  Adds the view's gradient to the accumulators.  Expression for expression the chain of
-// preprocess_bwd.hip (has_grad branch, SH16, the backward forms d(colour)/d(direction)); tests pin the two bit for bit.
-// raw-parameter mode (raw_params.h): the activations' Jacobians are applied per view, as phase 2 applies them.
+// A view's camera from its packet header.  The address is wave-uniform, but behind the passes' stores the compiler does not
+// prove these loads unclobbered and issues vector loads: every value is moved to a scalar register by hand (v_readfirstlane),
+// so that the camera costs no vector registers across the chain.
+__device__ __forceinline__ float uniform_f(const uint32_t* __restrict__ h, int i) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)h[i])); }
+__device__ __forceinline__ void load_cam(const uint32_t* __restrict__ h, CmbCam& cm)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) { cm.view[i] = uniform_f(h, 8 + i); cm.proj[i] = uniform_f(h, 24 + i); }
+    cm.campos[0] = uniform_f(h, 40); cm.campos[1] = uniform_f(h, 41); cm.campos[2] = uniform_f(h, 42);
+    cm.tan_fovx = uniform_f(h, 43); cm.tan_fovy = uniform_f(h, 44);
+    cm.focal_x = uniform_f(h, 49); cm.focal_y = uniform_f(h, 50);
+    cm.half_w = 0.5f * (float)__builtin_amdgcn_readfirstlane((int)h[45]); cm.half_h = 0.5f * (float)__builtin_amdgcn_readfirstlane((int)h[46]);
+    cm.scale_modifier = uniform_f(h, 47); cm.D = __builtin_amdgcn_readfirstlane((int)h[48]);
+}
+
+// sections 2, 3 and 5 of preprocess_bwd_kernel, and the view-direction term of section 4, for ONE (Gaussian, view): `part` = the
+// view's nine slot sums of the Gaussian, the colour part already clamp-masked.  Adds the view's terms to the accumulators.
+// Expression for expression the chain of preprocess_bwd.hip (has_grad branch; d(colour)/d(direction) formed from the SH row
+// as its sh_dir_in_backward form does); tests pin the two bit for bit.  Raw-parameter mode (raw_params.h): the activations'
+// Jacobians are applied per view, as phase 2 applies them.
 __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 mean, const float3 sc, const float4 q, const float o,
                                                  const bool raw_opacity, const bool raw_scale, const bool raw_rot, const float4 q_raw,
                                                  const float4* __restrict__ sh_row, float (&part)[FRG_SLOT_FLOATS],
-                                                 float (&a_mean)[3], float (&a_scale)[3], float (&a_rot)[4], float& a_opac, float (&a_sh)[48])
+                                                 float (&a_mean)[3], float (&a_scale)[3], float (&a_rot)[4], float& a_opac)
 {
+    // d(colour)/d(direction) from the SH row, coefficient after coefficient as the forward's SH pass adds them
+    const float dox = mean.x - cm.campos[0], doy = mean.y - cm.campos[1], doz = mean.z - cm.campos[2];
+    float dd0, dd1, dd2;
+    {
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        float shd[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) shd[k] = 0.0f;
+        const ShDir sd(cm.D, x, y, z);
+        const int ncoef = (cm.D + 1) * (cm.D + 1);
+        // three groups of four float4: the next group's loads are not issued before this group is consumed (twelve requests in
+        // flight would hold 48 registers through the whole chain's register peak)
+#pragma unroll
+        for (int jg = 0; jg < 3; jg++) {
+            float4 v4[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) v4[jj] = sh_row[4 * jg + jj];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const float f[4] = {v4[jj].x, v4[jj].y, v4[jj].z, v4[jj].w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int ee = 4 * (4 * jg + jj) + t, i = ee / 3, ch = ee % 3;
+                    if (i < ncoef) sd.feed(i, f[t], shd[ch], shd[3 + ch], shd[6 + ch]);
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+        }
+        dd0 = shd[0] * part[0] + shd[1] * part[1] + shd[2] * part[2];
+        dd1 = shd[3] * part[0] + shd[4] * part[1] + shd[5] * part[2];
+        dd2 = shd[6] * part[0] + shd[7] * part[1] + shd[8] * part[2];
+    }
+    __asm__ volatile("" ::: "memory");
     // the forward's conic (preprocess.hip preprocess_one): cov3D -> EWA cov2D -> + 0.3 -> inverse
     float cov[6];
     cov3d_from_scale_rot(sc, cm.scale_modifier, q, cov);
@@ -139,27 +215,6 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
     const float denom = a * c - b * b;
     const float det_inv = 1.f / denom;
     const float4 kc = make_float4(c * det_inv, -b * det_inv, a * det_inv, o);
-    // d(colour)/d(direction) from the SH row, coefficient after coefficient as the forward's SH pass adds them
-    const float dox = mean.x - cm.campos[0], doy = mean.y - cm.campos[1], doz = mean.z - cm.campos[2];
-    const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-    const float x = dox / len, y = doy / len, z = doz / len;
-    float shd[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) shd[k] = 0.0f;
-    {
-        const ShDir sd(cm.D, x, y, z);
-        const int ncoef = (cm.D + 1) * (cm.D + 1);
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const float4 v = sh_row[j];
-            const float f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int ee = 4 * j + t, i = ee / 3, ch = ee % 3;
-                if (i < ncoef) sd.feed(i, f[t], shd[ch], shd[3 + ch], shd[6 + ch]);
-            }
-        }
-    }
     // pixel moments -> the reference's terms (backward.cu:536-554), once per Gaussian
     {
         const float m3 = part[3], m4 = part[4];
@@ -225,36 +280,13 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
         dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
         dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
     }
-    // ---- SH path (backward.cu:20-139) ----
+    // ---- view-direction term of the SH path (backward.cu:130-138; auxiliary.h:107-117 dnormvdv) ----
     {
-        const float dRGB[3] = {part[0], part[1], part[2]};       // (masked by the view's clamp flags where it was packed)
-        float wgt[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
-        const int deg = cm.D;
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        wgt[0] = kSH0;
-        if (deg > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
-        if (deg > 1) {
-            wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
-            wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
-        }
-        if (deg > 2) {
-            wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
-            wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-            wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
-            wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
-        }
-        const float dd0 = shd[0] * dRGB[0] + shd[1] * dRGB[1] + shd[2] * dRGB[2];
-        const float dd1 = shd[3] * dRGB[0] + shd[4] * dRGB[1] + shd[5] * dRGB[2];
-        const float dd2 = shd[6] * dRGB[0] + shd[7] * dRGB[1] + shd[8] * dRGB[2];
         const float sum2 = dox * dox + doy * doy + doz * doz;
         const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
         dmean[0] += ((+sum2 - dox * dox) * dd0 - doy * dox * dd1 - doz * dox * dd2) * invsum32;
         dmean[1] += (-dox * doy * dd0 + (sum2 - doy * doy) * dd1 - doz * doy * dd2) * invsum32;
         dmean[2] += (-dox * doz * dd0 - doy * doz * dd1 + (sum2 - doz * doz) * dd2) * invsum32;
-#pragma unroll
-        for (int i = 0; i < 48; i++) a_sh[i] += wgt[i / 3] * dRGB[i % 3];
     }
     a_mean[0] += dmean[0]; a_mean[1] += dmean[1]; a_mean[2] += dmean[2];
     a_opac += raw_opacity ? part[8] * ((1.0f - o) * o) : part[8];
@@ -303,49 +335,40 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
     }
 }
 
+// The exchange's verdict for the host (pinned memory, polled): per view the rows it wanted, then the sequence number.  Its own
+// one-thread launch in front of the passes: the host learns it as early as it can be known, and the passes keep their
+// scalar loads (a system-scope atomic store inside them makes every later load of the kernel a vector load).
+__global__ void combine_verdict_kernel(uint32_t* __restrict__ status, uint32_t seq, const uint32_t* __restrict__ packets,
+                                       size_t packet_stride_words, int n_views, int first, int n)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t over = 0;
+    for (int v = 0; v < n_views; v++) {
+        const uint32_t* h = packets + (size_t)v * packet_stride_words;
+        const uint32_t want = h[1];
+        __hip_atomic_store(&status[2 + v], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        over |= (want > h[3] || h[5] != FRG_SUM_MAGIC || h[2] != (uint32_t)n || h[4] != (uint32_t)first) ? 1u : 0u;
+    }
+    __hip_atomic_store(&status[1], over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&status[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One workgroup per tile of CMB_TILE Gaussians.  Pass A: per block of 64 Gaussians the views' mask words -> a byte of view
 // bits per Gaussian; Gaussians without a row anywhere get their zero rows at once, the others are compacted into an LDS list.
-// Pass B: one lane per listed Gaussian walks its views in view order; 59 floats accumulated in registers, written once.
-__global__ void __launch_bounds__(CMB_THREADS)
-backward_combine_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words,
-                        const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
-                        const float* __restrict__ rotations, const float* __restrict__ opacities, RawInputs raw,
-                        float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh, uint32_t* __restrict__ status, uint32_t seq,
-                        unsigned char* __restrict__ row_live)
+// Pass B: one lane per listed Gaussian walks its views in view order; 11 floats accumulated in registers, written once.
+__global__ void __launch_bounds__(CMB_THREADS, 3)
+combine_dense_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words,
+                     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
+                     const float* __restrict__ rotations, const float* __restrict__ opacities, RawInputs raw,
+                     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+                     float* __restrict__ dL_dopacity, unsigned char* __restrict__ row_live)
 {
-    __shared__ CmbCam cams[CMB_MAX_VIEWS];
     __shared__ uint32_t list[CMB_TILE];
     __shared__ uint32_t n_list;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t bases_w = sum_packet_bases_word((size_t)n), rows_w = sum_packet_rows_word((size_t)n);
-    if (tid < n_views) {
-        const uint32_t* h = packets + (size_t)tid * packet_stride_words;
-        const float* f = reinterpret_cast<const float*>(h);
-        CmbCam& cm = cams[tid];
-        for (int i = 0; i < 16; i++) { cm.view[i] = f[8 + i]; cm.proj[i] = f[24 + i]; }
-        cm.campos[0] = f[40]; cm.campos[1] = f[41]; cm.campos[2] = f[42];
-        cm.tan_fovx = f[43]; cm.tan_fovy = f[44];
-        const int W = (int)h[45], H = (int)h[46];
-        cm.focal_y = H / (2.0f * cm.tan_fovy);     // api.hip make_view (rasterizer_impl.cu:222-223)
-        cm.focal_x = W / (2.0f * cm.tan_fovx);
-        cm.half_w = 0.5f * W; cm.half_h = 0.5f * H;
-        cm.scale_modifier = f[47]; cm.D = (int)h[48];
-    }
     if (tid == 0) n_list = 0u;
-    // the exchange's verdict for the host (pinned memory, polled): per view the rows it wanted, then the sequence number
-    if (status && blockIdx.x == 0 && tid == 0) {
-        uint32_t over = 0;
-        for (int v = 0; v < n_views; v++) {
-            const uint32_t* h = packets + (size_t)v * packet_stride_words;
-            const uint32_t want = h[1];
-            __hip_atomic_store(&status[2 + v], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            over |= (want > h[3] || h[5] != FRG_SUM_MAGIC || h[2] != (uint32_t)n || h[4] != (uint32_t)first) ? 1u : 0u;
-        }
-        __hip_atomic_store(&status[1], over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence_system();
-        __hip_atomic_store(&status[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     __syncthreads();
     const int tile0 = blockIdx.x * CMB_TILE;        // relative to `first`
     // ---- pass A ----
@@ -373,21 +396,10 @@ backward_combine_kernel(int first, int n, int n_views, const uint32_t* __restric
             *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(0.f, 0.f, 0.f, 0.f);
             dL_dopacity[gi] = 0.f;
         }
-        if (!row_live) {
-            // the SH rows of the Gaussians without a row in any view: zeros, as one float4 stream over the block
-            typedef float nt_f4 __attribute__((ext_vector_type(4)));
-            nt_f4* dst = reinterpret_cast<nt_f4*>(dL_dsh) + ((size_t)first + g0) * 12;
-            const int nvalid = min(64, n - g0);
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const int f = k * 64 + lane, gl = f / 12;
-                if (gl < nvalid && !((lm >> gl) & 1ull)) __builtin_nontemporal_store(nt_f4{0.f, 0.f, 0.f, 0.f}, dst + f);
-            }
-        }
     }
     __syncthreads();
     // ---- pass B ----
-    const uint32_t L = n_list;
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_list);
     for (uint32_t e0 = 0; e0 < L; e0 += CMB_THREADS) {
         const uint32_t ei = e0 + (uint32_t)tid;
         const bool have = ei < L;
@@ -395,9 +407,7 @@ backward_combine_kernel(int first, int n, int n_views, const uint32_t* __restric
         uint32_t vb = ent >> 16;
         const int gl = (int)(ent & 0xFFFFu), g = tile0 + gl;
         const int idx = first + g, blk = g / 64, gl64 = g & 63;
-        float a_mean[3] = {0.f, 0.f, 0.f}, a_scale[3] = {0.f, 0.f, 0.f}, a_rot[4] = {0.f, 0.f, 0.f, 0.f}, a_opac = 0.f, a_sh[48];
-#pragma unroll
-        for (int i = 0; i < 48; i++) a_sh[i] = 0.f;
+        float a_mean[3] = {0.f, 0.f, 0.f}, a_scale[3] = {0.f, 0.f, 0.f}, a_rot[4] = {0.f, 0.f, 0.f, 0.f}, a_opac = 0.f;
         float3 mean = make_float3(0.f, 0.f, 0.f), sc = make_float3(1.f, 1.f, 1.f);
         float4 q = make_float4(1.f, 0.f, 0.f, 0.f), q_raw = q;
         float o = 0.f;
@@ -409,46 +419,137 @@ backward_combine_kernel(int first, int n, int n_views, const uint32_t* __restric
             o = param_opacity(opacities, raw, idx);
             if (raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
         }
-        while (__builtin_amdgcn_ballot_w64(vb != 0u)) {          // wave-uniform trip count: the most views any lane has left
-            if (vb != 0u) {
-                const int v = __builtin_ctz(vb);
-                vb &= vb - 1u;
-                const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+        // The views in order, wave-uniformly: the camera of view v comes from its packet header by scalar loads (a per-lane view
+        // index -- every lane at its own k-th row -- kept 35 camera values per lane in vector registers: 214 VGPRs; a wave of
+        // compacted Gaussians has rows in nearly every view anyway).
+#pragma unroll 1
+        for (int v = 0; v < n_views; v++) {
+            const bool has = ((vb >> v) & 1u) != 0u;
+            if (!__builtin_amdgcn_ballot_w64(has)) continue;
+            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+            CmbCam cm;
+            load_cam(pk, cm);
+            const uint32_t cap = pk[3];
+            if (has) {
                 const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
                 const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << gl64) - 1ull));
-                if (row < pk[3]) {                                  // (beyond the capacity: the step is repeated, status says so)
+                if (row < cap) {                                    // (beyond the capacity: the step is repeated, status says so)
                     const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
                     float part[FRG_SLOT_FLOATS];
 #pragma unroll
                     for (int c2 = 0; c2 < FRG_SLOT_FLOATS; c2++) part[c2] = r[c2];
-                    combine_one_view(cams[v], mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr,
-                                     q_raw, sh_row, part, a_mean, a_scale, a_rot, a_opac, a_sh);
+                    combine_one_view(cm, mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr,
+                                     q_raw, sh_row, part, a_mean, a_scale, a_rot, a_opac);
                 }
             }
         }
         if (have) {
-            const float ds[3] = {a_scale[0], a_scale[1], a_scale[2]}, dq[4] = {a_rot[0], a_rot[1], a_rot[2], a_rot[3]};
             dL_dmean3D[3 * (size_t)idx] = a_mean[0]; dL_dmean3D[3 * (size_t)idx + 1] = a_mean[1]; dL_dmean3D[3 * (size_t)idx + 2] = a_mean[2];
-            dL_dscale[3 * (size_t)idx] = ds[0]; dL_dscale[3 * (size_t)idx + 1] = ds[1]; dL_dscale[3 * (size_t)idx + 2] = ds[2];
-            *reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            dL_dscale[3 * (size_t)idx] = a_scale[0]; dL_dscale[3 * (size_t)idx + 1] = a_scale[1]; dL_dscale[3 * (size_t)idx + 2] = a_scale[2];
+            *reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(a_rot[0], a_rot[1], a_rot[2], a_rot[3]);
             dL_dopacity[idx] = a_opac;
-            typedef float nt_f4 __attribute__((ext_vector_type(4)));
-            nt_f4* dst = reinterpret_cast<nt_f4*>(dL_dsh) + (size_t)idx * 12;
+        }
+    }
+}
+
+// dL_dsh [first, first + n) = sum over the views, in view order, of basis(dir_v) (x) dRGB_v for the views in which the Gaussian
+// has a row.  One lane per Gaussian; the view loop is wave-uniform (mask word, row base and camera centre are scalar loads);
+// the 192-byte rows leave through a wave-private LDS transpose as contiguous float4 streams (view_exchange.hip's idiom).
+#define CSH_SUB 16
+#define CSH_ROW_F4 13
+__global__ void __launch_bounds__(256)
+combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words,
+                  const float* __restrict__ means3D, RawInputs raw, float* __restrict__ dL_dsh, const unsigned char* __restrict__ row_live)
+{
+    __shared__ __attribute__((aligned(16))) float4 lds_all[4 * CSH_SUB * CSH_ROW_F4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* shbuf = lds_all + wave * CSH_SUB * CSH_ROW_F4;
+    const int blk = blockIdx.x * 4 + wave, g0 = blk * 64;
+    if (g0 >= n) return;
+    const int g = g0 + lane, idx = first + g;
+    const bool valid = g < n;
+    const size_t bases_w = sum_packet_bases_word((size_t)n), rows_w = sum_packet_rows_word((size_t)n);
+    float out[48];
+#pragma unroll
+    for (int i = 0; i < 48; i++) out[i] = 0.0f;
+    float3 mean = make_float3(0.f, 0.f, 0.f);
+    if (valid) mean = param_mean(means3D, raw, idx);
+    unsigned long long any = 0ull;
+#pragma unroll 1
+    for (int v = 0; v < n_views; v++) {
+        const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+        const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
+        if (m == 0ull) continue;                                   // wave-uniform
+        any |= m;
+        if (!((m >> lane) & 1ull)) continue;
+        const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (row >= pk[3]) continue;
+        const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
+        const float dRGB[3] = {r[0], r[1], r[2]};
+        const float* f = reinterpret_cast<const float*>(pk);
+        const int D = (int)pk[48];
+        const float dox = mean.x - f[40], doy = mean.y - f[41], doz = mean.z - f[42];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float wgt[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
+        wgt[0] = kSH0;
+        if (D > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
+        if (D > 1) {
+            wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
+            wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
+        }
+        if (D > 2) {
+            wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
+            wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
+            wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
+        }
+#pragma unroll
+        for (int i = 0; i < 48; i++) out[i] += wgt[i / 3] * dRGB[i % 3];
+    }
+    // rows to write: all of the block's -- or, with row_live, those of its Gaussians with a row somewhere
+    const unsigned long long wmask = row_live ? any : ~0ull;
+    float4* dst = reinterpret_cast<float4*>(dL_dsh) + ((size_t)first + g0) * 12;
+    const int nvalid = min(64, n - g0);
+#pragma unroll 1
+    for (int h = 0; h < 64 / CSH_SUB; h++) {
+        if (((wmask >> (h * CSH_SUB)) & ((1ull << CSH_SUB) - 1ull)) == 0ull) continue;
+        if ((lane / CSH_SUB) == h) {
 #pragma unroll
             for (int j = 0; j < 12; j++)
-                __builtin_nontemporal_store(nt_f4{a_sh[4 * j], a_sh[4 * j + 1], a_sh[4 * j + 2], a_sh[4 * j + 3]}, dst + j);
+                shbuf[(lane % CSH_SUB) * CSH_ROW_F4 + j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < CSH_SUB * 12 / 64; k++) {
+            const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
+            if (h * CSH_SUB + gl < nvalid && ((wmask >> (h * CSH_SUB + gl)) & 1ull)) {
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                const float4 v4 = shbuf[gl * CSH_ROW_F4 + j];
+                __builtin_nontemporal_store(nt_f4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<nt_f4*>(dst + (size_t)h * CSH_SUB * 12 + f));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
 hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
                                    const FwdInputs& in, const BwdOutputs& out, uint32_t* status, uint32_t seq, unsigned char* row_live,
-                                   hipStream_t s)
+                                   hipStream_t s, hipStream_t s_sh)
 {
+    const uint32_t* pk = reinterpret_cast<const uint32_t*>(packets);
     const int tiles = (n + CMB_TILE - 1) / CMB_TILE;
-    hipLaunchKernelGGL(backward_combine_kernel, dim3(tiles), dim3(CMB_THREADS), 0, s, first, n, n_views,
-                       reinterpret_cast<const uint32_t*>(packets), packet_stride_bytes / 4, in.means3D, in.shs, in.scales, in.rotations,
-                       in.opacities, in.raw, out.dL_dmean3D, out.dL_dscale, out.dL_drot, out.dL_dopacity, out.dL_dsh, status, seq, row_live);
+    if (status) hipLaunchKernelGGL(combine_verdict_kernel, dim3(1), dim3(64), 0, s, status, seq, pk, packet_stride_bytes / 4, n_views, first, n);
+    hipLaunchKernelGGL(combine_dense_kernel, dim3(tiles), dim3(CMB_THREADS), 0, s, first, n, n_views, pk, packet_stride_bytes / 4,
+                       in.means3D, in.shs, in.scales, in.rotations, in.opacities, in.raw, out.dL_dmean3D, out.dL_dscale, out.dL_drot,
+                       out.dL_dopacity, row_live);
+    const int nblk = (int)sum_packet_blocks((size_t)n);
+    // (row_live is written by the dense pass; the SH pass derives the same bits from the masks themselves)
+    hipLaunchKernelGGL(combine_sh_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s_sh, first, n, n_views, pk, packet_stride_bytes / 4,
+                       in.means3D, in.raw, out.dL_dsh, row_live);
     return hipGetLastError();
 }
 

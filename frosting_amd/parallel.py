@@ -865,6 +865,9 @@ class ViewParallelRasterizer:
         if self.out_color is None or tuple(self.out_color.shape) != (3, H, W):
             self.out_color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        # the blend arithmetic of this forward (the process option, read here) is handed to the backward explicitly: the library
+        # then launches that one instantiation instead of both behind the forward's stamp (api.hip backward_impl)
+        self._exact = int(_lib.get_option("exact_blend"))
         use_deferred = (self.deferred_counters if deferred is None else deferred) and self.capacity > 0
         if forward_only and use_deferred:
             raise RuntimeError("forward_only is not offered with deferred counters")
@@ -959,24 +962,23 @@ class ViewParallelRasterizer:
         ws = int(L.frg_backward_workspace_bytes(self.P, self.num_rendered))
         work = self.work.ensure(ws)
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        if self.raw_params or phase or self.live_rows:
-            v = lambda t: None if t is None else t.data_ptr()
-            raw = self.raw_params
-            a = _lib.BackwardArgs(
-                struct_size=C.sizeof(_lib.BackwardArgs), P=self.P, D=s.sh_degree, M=self.K, R=self.num_rendered, background=v(bg),
-                width=W, height=H, means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, scales=None if raw else v(s.scales), scale_modifier=1.0,
-                rotations=None if raw else v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix), projmatrix=v(cam.projmatrix),
-                campos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy), radii=v(self.radii),
-                geom_buffer=v(self.geom.buf), binning_buffer=v(self.binning.buf), image_buffer=v(self.img.buf),
-                dL_dpix=v(dL_dimage), dL_dmean2D=v(self.dL_dmeans2D), dL_dconic=None, dL_dopacity=v(g["opacities"]),
-                dL_dcolor=v(ex.own_drgb) if defer_sh else (v(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
-                dL_dmean3D=v(g["means3D"]), dL_dcov3D=v(self.dL_dcov3D), dL_dsh=None if defer_sh else v(g["shs"]),
-                dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), workspace=v(work), workspace_bytes=work.numel(), debug=0,
-                hip_stream=stream.value, raw_opacities=v(s.opacities) if raw else None, raw_scales=v(s.scales) if raw else None,
-                raw_rotations=v(s.rotations) if raw else None, phase=int(phase), row_live=v(self.row_live))
-            rc = L.frg_backward_ex(C.byref(a))
-        else:
-            rc = self._backward_plain(L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream)
+        # every option of the backward in one struct (frg_backward_ex), the forward's arithmetic stated
+        v = lambda t: None if t is None else t.data_ptr()
+        raw = self.raw_params
+        a = _lib.BackwardArgs(
+            struct_size=C.sizeof(_lib.BackwardArgs), P=self.P, D=s.sh_degree, M=self.K, R=self.num_rendered, background=v(bg),
+            width=W, height=H, means3D=v(s.means3D), shs=v(s.shs), colors_precomp=None, scales=None if raw else v(s.scales), scale_modifier=1.0,
+            rotations=None if raw else v(s.rotations), cov3D_precomp=None, viewmatrix=v(cam.viewmatrix), projmatrix=v(cam.projmatrix),
+            campos=v(cam.campos), tan_fovx=float(cam.tanfovx), tan_fovy=float(cam.tanfovy), radii=v(self.radii),
+            geom_buffer=v(self.geom.buf), binning_buffer=v(self.binning.buf), image_buffer=v(self.img.buf),
+            dL_dpix=v(dL_dimage), dL_dmean2D=v(self.dL_dmeans2D), dL_dconic=None, dL_dopacity=v(g["opacities"]),
+            dL_dcolor=v(ex.own_drgb) if defer_sh else (v(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
+            dL_dmean3D=v(g["means3D"]), dL_dcov3D=v(self.dL_dcov3D), dL_dsh=None if defer_sh else v(g["shs"]),
+            dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), workspace=v(work), workspace_bytes=work.numel(), debug=0,
+            hip_stream=stream.value, raw_opacities=v(s.opacities) if raw else None, raw_scales=v(s.scales) if raw else None,
+            raw_rotations=v(s.rotations) if raw else None, exact_blend=getattr(self, "_exact", -1) + 1, phase=int(phase),
+            row_live=v(self.row_live))
+        rc = L.frg_backward_ex(C.byref(a))
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
         if slot_sums:
@@ -1009,19 +1011,6 @@ class ViewParallelRasterizer:
             t[dead] = 0.0
         ex.flat._frg_rows_partial = False
         return ex.views
-
-    def _backward_plain(self, L, s, cam, bg, W, H, dL_dimage, g, ex, defer_sh, work, stream):
-        return L.frg_backward(self.P, s.sh_degree, self.K, self.num_rendered, _p(bg), W, H,
-                            _p(s.means3D), _p(s.shs), None,
-                            _p(s.scales), 1.0, _p(s.rotations), None,
-                            _p(cam.viewmatrix), _p(cam.projmatrix), _p(cam.campos),
-                            float(cam.tanfovx), float(cam.tanfovy), _p(self.radii),
-                            _p(self.geom.buf), _p(self.binning.buf), _p(self.img.buf), _p(dL_dimage),
-                            _p(self.dL_dmeans2D), None, _p(g["opacities"]),
-                            # deferred SH rows: dL_dcolor receives the masked colour gradient = the exchange payload
-                            _p(ex.own_drgb) if defer_sh else (_p(self.dL_dcolors) if (ex.factor_sh or self.write_all_outputs) else None),
-                            _p(g["means3D"]), _p(self.dL_dcov3D), None if defer_sh else _p(g["shs"]), _p(g["scales"]), _p(g["rotations"]),
-                            _p(work), work.numel(), 0, stream)
 
     def backward_overlapped(self, dL_dimage, slot: int = 0):
         """backward + the start of the exchange, factored plan: phase 1 (blend backward + slot sums: the colour-gradient

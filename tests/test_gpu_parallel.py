@@ -201,7 +201,7 @@ def test_exchange_plans_on_single_rank_rccl_group(gpu_device):
             if factored == "slotsum":    # one view: its rows, fewer than the visible Gaussians; the next step's packets are sized from them
                 st = vpr.exchanges[0].stats
                 assert 0 < st["rows_wanted_max"] <= int((vpr.radii > 0).sum()) and st["repacks"] == 0
-                assert sum(vpr.exchanges[0].capacity) < 6000
+                assert st["rows_wanted_max"] <= sum(vpr.exchanges[0].capacity) <= 6000
             if factored == "sparse":     # rows of the Gaussians with a gradient only: fewer than are visible, packed without a re-pack at this size
                 st = vpr.exchanges[0].sparse_stats
                 assert 0 < st["rows_own"] <= int((vpr.radii > 0).sum()) and st["rows_max"] == st["rows_own"]
