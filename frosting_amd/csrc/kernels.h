@@ -102,7 +102,7 @@ hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsig
 // in: means3D, shs, scales, rotations, opacities (or their raw forms); out: dL_dmean3D, dL_dscale, dL_drot, dL_dopacity, dL_dsh
 // s: the dense pass (11 floats per Gaussian); s_sh: the SH pass (48) -- the same stream, or a side stream ordered by the caller
 hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
-                                   const FwdInputs& in, const BwdOutputs& out, uint32_t* status, uint32_t seq, unsigned char* row_live,
+                                   const FwdInputs& in, const BwdOutputs& out, unsigned long long* status, uint32_t seq, unsigned char* row_live,
                                    hipStream_t s, hipStream_t s_sh);
 
 // fused Adam over the flat parameter layout (adam.hip)

@@ -39,10 +39,10 @@ __host__ __device__ inline size_t sum_packet_rows_word(size_t n) { return (sum_p
 size_t sum_packet_bytes(size_t n, size_t capacity) { return ((sum_packet_rows_word(n) + FRG_SUM_ROW_FLOATS * capacity + 3) / 4 * 4) * 4; }
 
 // One workgroup: the packet's masks (copied from the phase-1 workspace), the exclusive prefix of their popcounts, the header.
-// Rounds of 16 x 1024 blocks: a thread's sixteen mask words are requested together (coalesced across the workgroup), then
-// sixteen workgroup scans of 1024 counts (DPP wave scans + one LDS hop) carry the running total.  (Round 6's first form -- a
-// contiguous run of blocks per thread, read one after the other -- took 70 us per 23 000 blocks: a chain of dependent
-// uncoalesced loads.)
+// Rounds of 1024 x 16 blocks: a thread takes SIXTEEN CONSECUTIVE blocks -- one 128-byte line of mask words, requested at once
+// -- counts and prefixes them in registers, and one workgroup scan of the 1024 thread totals (DPP wave scans + one LDS hop)
+// carries the running total: two barriers per 16 384 blocks.  (Round 6's first form walked a thread's blocks one dependent
+// load after the other: 70 us per 23 000 blocks; a workgroup scan per 1024 blocks: 30 us.)
 #define SUM_SCAN_PER 16
 __global__ void __launch_bounds__(1024)
 sum_rows_scan_kernel(int first, int n, uint32_t capacity, const unsigned long long* __restrict__ live_masks,
@@ -50,38 +50,33 @@ sum_rows_scan_kernel(int first, int n, uint32_t capacity, const unsigned long lo
                      const float* __restrict__ projmatrix, const float* __restrict__ campos)
 {
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
     const int nblk = (int)sum_packet_blocks((size_t)n), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(packet + FRG_SUM_HDR_WORDS);
     uint32_t* bases = packet + sum_packet_bases_word((size_t)n);
     const unsigned long long* src = live_masks + first / 64;
-    if (tid == 0) carry_s = 0u;
-    __syncthreads();
+    uint32_t carry = 0;                                           // blocks before this round: the same in every thread
     for (int r0 = 0; r0 < nblk; r0 += 1024 * SUM_SCAN_PER) {
+        const int b0 = r0 + tid * SUM_SCAN_PER;
         unsigned long long m[SUM_SCAN_PER];
 #pragma unroll
-        for (int i = 0; i < SUM_SCAN_PER; i++) {
-            const int b = r0 + i * 1024 + tid;
-            m[i] = b < nblk ? src[b] : 0ull;
-        }
-#pragma unroll 1
-        for (int i = 0; i < SUM_SCAN_PER; i++) {
-            if (r0 + i * 1024 >= nblk) break;                    // workgroup-uniform
-            const int b = r0 + i * 1024 + tid;
-            const uint32_t c = (uint32_t)__popcll(m[i]);
-            const uint32_t incl = wave_incl_scan_dpp(c);
-            if (lane == 63) wave_tot[wave] = incl;
-            __syncthreads();
-            uint32_t before = carry_s;
-            for (int w = 0; w < wave; w++) before += wave_tot[w];
-            if (b < nblk) { masks[b] = m[i]; bases[b] = before + incl - c; }
-            __syncthreads();
-            if (tid == 1023) carry_s = before + incl;
-            __syncthreads();
-        }
+        for (int i = 0; i < SUM_SCAN_PER; i++) m[i] = b0 + i < nblk ? src[b0 + i] : 0ull;
+        uint32_t pre[SUM_SCAN_PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < SUM_SCAN_PER; i++) { pre[i] = sum; sum += (uint32_t)__popcll(m[i]); }
+        const uint32_t incl = wave_incl_scan_dpp(sum);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry, total = carry;
+        for (int w = 0; w < 16; w++) { const uint32_t t = wave_tot[w]; if (w < wave) before += t; total += t; }
+        before += incl - sum;
+#pragma unroll
+        for (int i = 0; i < SUM_SCAN_PER; i++)
+            if (b0 + i < nblk) { masks[b0 + i] = m[i]; bases[b0 + i] = before + pre[i]; }
+        carry = total;
+        __syncthreads();
     }
     if (tid == 0) {
-        const uint32_t want = carry_s;
+        const uint32_t want = carry;
         packet[0] = want < capacity ? want : capacity;
         packet[1] = want;
         packet[2] = (uint32_t)n; packet[3] = capacity; packet[4] = (uint32_t)first; packet[5] = FRG_SUM_MAGIC;
@@ -169,7 +164,7 @@ __device__ __forceinline__ void load_cam(const uint32_t* __restrict__ h, CmbCam&
 __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 mean, const float3 sc, const float4 q, const float o,
                                                  const bool raw_opacity, const bool raw_scale, const bool raw_rot, const float4 q_raw,
                                                  const float4* __restrict__ sh_row, float (&part)[FRG_SLOT_FLOATS],
-                                                 float (&a_mean)[3], float (&a_scale)[3], float (&a_rot)[4], float& a_opac)
+                                                 float* __restrict__ acc /* [11]: mean3D 3, scale 3, rot 4, opacity */)
 {
     // d(colour)/d(direction) from the SH row, coefficient after coefficient as the forward's SH pass adds them
     const float dox = mean.x - cm.campos[0], doy = mean.y - cm.campos[1], doz = mean.z - cm.campos[2];
@@ -288,8 +283,8 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
         dmean[1] += (-dox * doy * dd0 + (sum2 - doy * doy) * dd1 - doz * doy * dd2) * invsum32;
         dmean[2] += (-dox * doz * dd0 - doy * doz * dd1 + (sum2 - doz * doz) * dd2) * invsum32;
     }
-    a_mean[0] += dmean[0]; a_mean[1] += dmean[1]; a_mean[2] += dmean[2];
-    a_opac += raw_opacity ? part[8] * ((1.0f - o) * o) : part[8];
+    acc[0] += dmean[0]; acc[1] += dmean[1]; acc[2] += dmean[2];
+    acc[10] += raw_opacity ? part[8] * ((1.0f - o) * o) : part[8];
     // ---- cov3D -> scale, quaternion (backward.cu:278-341) ----
     {
         const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
@@ -330,33 +325,38 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
             dq[0] = (dq[0] - yn.x * d) * inv; dq[1] = (dq[1] - yn.y * d) * inv;
             dq[2] = (dq[2] - yn.z * d) * inv; dq[3] = (dq[3] - yn.w * d) * inv;
         }
-        a_scale[0] += ds[0]; a_scale[1] += ds[1]; a_scale[2] += ds[2];
-        a_rot[0] += dq[0]; a_rot[1] += dq[1]; a_rot[2] += dq[2]; a_rot[3] += dq[3];
+        acc[3] += ds[0]; acc[4] += ds[1]; acc[5] += ds[2];
+        acc[6] += dq[0]; acc[7] += dq[1]; acc[8] += dq[2]; acc[9] += dq[3];
     }
 }
 
-// The exchange's verdict for the host (pinned memory, polled): per view the rows it wanted, then the sequence number.  Its own
-// one-thread launch in front of the passes: the host learns it as early as it can be known, and the passes keep their
-// scalar loads (a system-scope atomic store inside them makes every later load of the kernel a vector load).
-__global__ void combine_verdict_kernel(uint32_t* __restrict__ status, uint32_t seq, const uint32_t* __restrict__ packets,
+// The exchange's verdict for the host (pinned memory, polled): word 0 = any packet overflowed / does not describe this range,
+// words 1 .. n_views = the rows each view wanted -- every one a 64-bit (sequence number << 32 | value) stored at once, so the
+// host knows a word is this pass's by its tag and no fence is needed (a system-scope release here writes the L2's dirty
+// lines back first: the one-thread kernel took 60 - 160 us behind a backward).  Its own launch in front of the passes: the host
+// learns the verdict as early as it can be known, and the passes keep their scalar loads.
+__global__ void combine_verdict_kernel(unsigned long long* __restrict__ status, uint32_t seq, const uint32_t* __restrict__ packets,
                                        size_t packet_stride_words, int n_views, int first, int n)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t over = 0;
-    for (int v = 0; v < n_views; v++) {
+    const int v = threadIdx.x;
+    uint32_t bad = 0;
+    if (v < n_views) {
         const uint32_t* h = packets + (size_t)v * packet_stride_words;
         const uint32_t want = h[1];
-        __hip_atomic_store(&status[2 + v], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        over |= (want > h[3] || h[5] != FRG_SUM_MAGIC || h[2] != (uint32_t)n || h[4] != (uint32_t)first) ? 1u : 0u;
+        bad = (want > h[3] || h[5] != FRG_SUM_MAGIC || h[2] != (uint32_t)n || h[4] != (uint32_t)first) ? 1u : 0u;
+        __hip_atomic_store(&status[1 + v], ((unsigned long long)seq << 32) | want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(&status[1], over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    __hip_atomic_store(&status[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(bad != 0u);
+    if (v == 0) __hip_atomic_store(&status[0], ((unsigned long long)seq << 32) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// One workgroup per tile of CMB_TILE Gaussians.  Pass A: per block of 64 Gaussians the views' mask words -> a byte of view
-// bits per Gaussian; Gaussians without a row anywhere get their zero rows at once, the others are compacted into an LDS list.
-// Pass B: one lane per listed Gaussian walks its views in view order; 11 floats accumulated in registers, written once.
+// One workgroup per tile of CMB_TILE Gaussians, the VIEWS in an outer, workgroup-uniform loop: for view v the tile's Gaussians
+// with a row in v (127 of 1024 at C3) are compacted into a list and every lane takes one -- dense lanes, and the camera of the
+// view in scalar registers.  A Gaussian's 11 sums live in LDS (one row per Gaussian of the tile), where each view adds its
+// terms; the barrier between two views keeps a Gaussian's additions in view order.  At the end every row of the tile is
+// written from the LDS rows, zeros where no view had anything.  (Round 6's first form walked each Gaussian's views in one lane,
+// accumulators in registers: a wave of 64 such Gaussians has rows in all eight views, 2.2 each -- 27 % busy lanes, 0.76 ms.)
+#define CMB_ACC 11
 __global__ void __launch_bounds__(CMB_THREADS, 3)
 combine_dense_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words,
                      const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
@@ -364,91 +364,80 @@ combine_dense_kernel(int first, int n, int n_views, const uint32_t* __restrict__
                      float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
                      float* __restrict__ dL_dopacity, unsigned char* __restrict__ row_live)
 {
-    __shared__ uint32_t list[CMB_TILE];
-    __shared__ uint32_t n_list;
+    __shared__ float acc[CMB_TILE * CMB_ACC];
+    __shared__ uint16_t vbits[CMB_TILE];
+    __shared__ uint16_t list[CMB_TILE];
+    __shared__ uint32_t n_list[CMB_MAX_VIEWS];      // one counter per view: no reset between two views' compactions
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t bases_w = sum_packet_bases_word((size_t)n), rows_w = sum_packet_rows_word((size_t)n);
-    if (tid == 0) n_list = 0u;
-    __syncthreads();
     const int tile0 = blockIdx.x * CMB_TILE;        // relative to `first`
-    // ---- pass A ----
+    if (tid < CMB_MAX_VIEWS) n_list[tid] = 0u;
+    for (int i = tid; i < CMB_TILE * CMB_ACC; i += CMB_THREADS) acc[i] = 0.0f;
+    // per Gaussian of the tile: the views in which it has a row
     for (int bb = wave; bb < CMB_TILE / 64; bb += CMB_THREADS / 64) {
         const int g0 = tile0 + bb * 64;
-        if (g0 >= n) break;
-        const int blk = g0 / 64, g = g0 + lane;
-        const bool valid = g < n;
         uint32_t vb = 0;
-        for (int v = 0; v < n_views; v++) {
-            const unsigned long long m = reinterpret_cast<const unsigned long long*>(packets + (size_t)v * packet_stride_words + FRG_SUM_HDR_WORDS)[blk];
-            vb |= (uint32_t)((m >> lane) & 1ull) << v;
+        if (g0 < n) {
+            const int blk = g0 / 64;
+            for (int v = 0; v < n_views; v++) {
+                const unsigned long long m = reinterpret_cast<const unsigned long long*>(packets + (size_t)v * packet_stride_words + FRG_SUM_HDR_WORDS)[blk];
+                vb |= (uint32_t)((m >> lane) & 1ull) << v;
+            }
+            if (g0 + lane >= n) vb = 0;
         }
-        const bool live = valid && vb != 0u;
-        const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
-        uint32_t at = 0;
-        if (lane == 0 && lm) at = atomicAdd(&n_list, (uint32_t)__popcll(lm));
-        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-        if (live) list[at + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)(bb * 64 + lane) | (vb << 16);
-        const size_t gi = (size_t)first + g;
-        if (row_live && valid) row_live[gi] = live ? 1 : 0;
-        if (valid && !live && !row_live) {
-            dL_dmean3D[3 * gi] = 0.f; dL_dmean3D[3 * gi + 1] = 0.f; dL_dmean3D[3 * gi + 2] = 0.f;
-            dL_dscale[3 * gi] = 0.f; dL_dscale[3 * gi + 1] = 0.f; dL_dscale[3 * gi + 2] = 0.f;
-            *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(0.f, 0.f, 0.f, 0.f);
-            dL_dopacity[gi] = 0.f;
-        }
+        vbits[bb * 64 + lane] = (uint16_t)vb;
     }
     __syncthreads();
-    // ---- pass B ----
-    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_list);
-    for (uint32_t e0 = 0; e0 < L; e0 += CMB_THREADS) {
-        const uint32_t ei = e0 + (uint32_t)tid;
-        const bool have = ei < L;
-        const uint32_t ent = have ? list[ei] : 0u;
-        uint32_t vb = ent >> 16;
-        const int gl = (int)(ent & 0xFFFFu), g = tile0 + gl;
-        const int idx = first + g, blk = g / 64, gl64 = g & 63;
-        float a_mean[3] = {0.f, 0.f, 0.f}, a_scale[3] = {0.f, 0.f, 0.f}, a_rot[4] = {0.f, 0.f, 0.f, 0.f}, a_opac = 0.f;
-        float3 mean = make_float3(0.f, 0.f, 0.f), sc = make_float3(1.f, 1.f, 1.f);
-        float4 q = make_float4(1.f, 0.f, 0.f, 0.f), q_raw = q;
-        float o = 0.f;
-        const float4* sh_row = reinterpret_cast<const float4*>(shs) + (size_t)idx * 12;
-        if (have) {
-            mean = param_mean(means3D, raw, idx);
-            sc = param_scale(scales, raw, idx);
-            q = param_rot(rotations, raw, idx);
-            o = param_opacity(opacities, raw, idx);
-            if (raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
-        }
-        // The views in order, wave-uniformly: the camera of view v comes from its packet header by scalar loads (a per-lane view
-        // index -- every lane at its own k-th row -- kept 35 camera values per lane in vector registers: 214 VGPRs; a wave of
-        // compacted Gaussians has rows in nearly every view anyway).
 #pragma unroll 1
-        for (int v = 0; v < n_views; v++) {
-            const bool has = ((vb >> v) & 1u) != 0u;
-            if (!__builtin_amdgcn_ballot_w64(has)) continue;
-            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-            CmbCam cm;
-            load_cam(pk, cm);
-            const uint32_t cap = pk[3];
-            if (has) {
-                const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
-                const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << gl64) - 1ull));
-                if (row < cap) {                                    // (beyond the capacity: the step is repeated, status says so)
-                    const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
-                    float part[FRG_SLOT_FLOATS];
+    for (int v = 0; v < n_views; v++) {
+        // the tile's Gaussians with a row in view v, compacted (in no particular order: each appears once)
+        for (int bb = wave; bb < CMB_TILE / 64; bb += CMB_THREADS / 64) {
+            const bool has = ((vbits[bb * 64 + lane] >> v) & 1u) != 0u;
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
+            uint32_t at = 0;
+            if (lane == 0 && hm) at = atomicAdd(&n_list[v], (uint32_t)__popcll(hm));
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (has) list[at + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint16_t)(bb * 64 + lane);
+        }
+        const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+        CmbCam cm;
+        load_cam(pk, cm);
+        const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk[3]);
+        __syncthreads();
+        const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_list[v]);
+        for (uint32_t e = (uint32_t)tid; e < L; e += CMB_THREADS) {
+            const int gl = (int)list[e], g = tile0 + gl, idx = first + g, blk = g / 64, gl64 = g & 63;
+            const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
+            const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << gl64) - 1ull));
+            if (row < cap) {                                    // (beyond the capacity: the step is repeated, the verdict says so)
+                const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
+                float part[FRG_SLOT_FLOATS];
 #pragma unroll
-                    for (int c2 = 0; c2 < FRG_SLOT_FLOATS; c2++) part[c2] = r[c2];
-                    combine_one_view(cm, mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr,
-                                     q_raw, sh_row, part, a_mean, a_scale, a_rot, a_opac);
-                }
+                for (int c2 = 0; c2 < FRG_SLOT_FLOATS; c2++) part[c2] = r[c2];
+                const float3 mean = param_mean(means3D, raw, idx);
+                const float3 sc = param_scale(scales, raw, idx);
+                const float4 q = param_rot(rotations, raw, idx);
+                const float o = param_opacity(opacities, raw, idx);
+                float4 q_raw = q;
+                if (raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
+                combine_one_view(cm, mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr, q_raw,
+                                 reinterpret_cast<const float4*>(shs) + (size_t)idx * 12, part, acc + gl * CMB_ACC);
             }
         }
-        if (have) {
-            dL_dmean3D[3 * (size_t)idx] = a_mean[0]; dL_dmean3D[3 * (size_t)idx + 1] = a_mean[1]; dL_dmean3D[3 * (size_t)idx + 2] = a_mean[2];
-            dL_dscale[3 * (size_t)idx] = a_scale[0]; dL_dscale[3 * (size_t)idx + 1] = a_scale[1]; dL_dscale[3 * (size_t)idx + 2] = a_scale[2];
-            *reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(a_rot[0], a_rot[1], a_rot[2], a_rot[3]);
-            dL_dopacity[idx] = a_opac;
-        }
+        __syncthreads();                  // the next view may add to the same rows from other lanes (and overwrites the list)
+    }
+    // every row of the tile, once
+    for (int i = tid; i < CMB_TILE; i += CMB_THREADS) {
+        const int g = tile0 + i;
+        if (g >= n) break;
+        const size_t gi = (size_t)first + g;
+        const bool live = vbits[i] != 0;
+        if (row_live) { row_live[gi] = live ? 1 : 0; if (!live) continue; }
+        const float* a = acc + i * CMB_ACC;
+        dL_dmean3D[3 * gi] = a[0]; dL_dmean3D[3 * gi + 1] = a[1]; dL_dmean3D[3 * gi + 2] = a[2];
+        dL_dscale[3 * gi] = a[3]; dL_dscale[3 * gi + 1] = a[4]; dL_dscale[3 * gi + 2] = a[5];
+        *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(a[6], a[7], a[8], a[9]);
+        dL_dopacity[gi] = a[10];
     }
 }
 
@@ -475,40 +464,67 @@ combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ pa
     float3 mean = make_float3(0.f, 0.f, 0.f);
     if (valid) mean = param_mean(means3D, raw, idx);
     unsigned long long any = 0ull;
+    // The views in groups of four: the four mask words and row offsets of the block are requested together, then the four rows'
+    // colour gradients -- two memory round trips per group instead of three per view (mask -> row index -> row) in a chain.
 #pragma unroll 1
-    for (int v = 0; v < n_views; v++) {
-        const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-        const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
-        if (m == 0ull) continue;                                   // wave-uniform
-        any |= m;
-        if (!((m >> lane) & 1ull)) continue;
-        const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (row >= pk[3]) continue;
-        const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
-        const float dRGB[3] = {r[0], r[1], r[2]};
-        const float* f = reinterpret_cast<const float*>(pk);
-        const int D = (int)pk[48];
-        const float dox = mean.x - f[40], doy = mean.y - f[41], doz = mean.z - f[42];
-        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-        const float x = dox / len, y = doy / len, z = doz / len;
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        float wgt[16];
+    for (int v0 = 0; v0 < n_views; v0 += 4) {
+        unsigned long long m[4];
+        uint32_t base[4], cap[4];
 #pragma unroll
-        for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
-        wgt[0] = kSH0;
-        if (D > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
-        if (D > 1) {
-            wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
-            wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
+        for (int u = 0; u < 4; u++) {
+            const int v = min(v0 + u, n_views - 1);
+            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+            m[u] = v0 + u < n_views ? reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk] : 0ull;
+            base[u] = (pk + bases_w)[blk];
+            cap[u] = pk[3];
         }
-        if (D > 2) {
-            wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
-            wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-            wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
-            wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
+        float dr[4][3];
+        bool has[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = min(v0 + u, n_views - 1);
+            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+            any |= m[u];
+            const uint32_t row = base[u] + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
+            has[u] = ((m[u] >> lane) & 1ull) && row < cap[u];
+            dr[u][0] = dr[u][1] = dr[u][2] = 0.0f;
+            if (has[u]) {
+                const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
+                dr[u][0] = r[0]; dr[u][1] = r[1]; dr[u][2] = r[2];
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 48; i++) out[i] += wgt[i / 3] * dRGB[i % 3];
+        for (int u = 0; u < 4; u++) {
+            if (!__builtin_amdgcn_ballot_w64(has[u])) continue;            // wave-uniform
+            const int v = min(v0 + u, n_views - 1);
+            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+            const int D = __builtin_amdgcn_readfirstlane((int)pk[48]);
+            const float cx = uniform_f(pk, 40), cy = uniform_f(pk, 41), cz = uniform_f(pk, 42);
+            if (has[u]) {
+                const float dRGB[3] = {dr[u][0], dr[u][1], dr[u][2]};
+                const float dox = mean.x - cx, doy = mean.y - cy, doz = mean.z - cz;
+                const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+                const float x = dox / len, y = doy / len, z = doz / len;
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                float wgt[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
+                wgt[0] = kSH0;
+                if (D > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
+                if (D > 1) {
+                    wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
+                    wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
+                }
+                if (D > 2) {
+                    wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
+                    wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                    wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
+                    wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
+                }
+#pragma unroll
+                for (int i = 0; i < 48; i++) out[i] += wgt[i / 3] * dRGB[i % 3];
+            }
+        }
     }
     // rows to write: all of the block's -- or, with row_live, those of its Gaussians with a row somewhere
     const unsigned long long wmask = row_live ? any : ~0ull;
@@ -537,7 +553,7 @@ combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ pa
 }
 
 hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
-                                   const FwdInputs& in, const BwdOutputs& out, uint32_t* status, uint32_t seq, unsigned char* row_live,
+                                   const FwdInputs& in, const BwdOutputs& out, unsigned long long* status, uint32_t seq, unsigned char* row_live,
                                    hipStream_t s, hipStream_t s_sh)
 {
     const uint32_t* pk = reinterpret_cast<const uint32_t*>(packets);

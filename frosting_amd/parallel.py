@@ -551,7 +551,8 @@ class SlotSumExchange(GradientExchange):
         self.packer = packer or _hip_sum_packer
         self.combiner = combiner or _hip_sum_combiner
         pin = self.device.type == "cuda"
-        self.status = [torch.zeros(2 + 16, dtype=torch.int32, pin_memory=pin) for _ in self.chunks]
+        # the combine pass's verdict per chunk: 64-bit words (sequence number << 32 | value) -- [0] overflow, [1 + v] rows view v wanted
+        self.status = [torch.zeros(1 + 16, dtype=torch.int64, pin_memory=pin) for _ in self.chunks]
         self.seq = 0
         self.packet_own = [None] * len(self.chunks)
         self.packets_all = [None] * len(self.chunks)
@@ -639,20 +640,31 @@ class SlotSumExchange(GradientExchange):
         """(overflow?, rows wanted per view) of chunk c's last combine pass: posted by the pass to pinned host memory as it
         starts (GPU), so the host polls instead of synchronising; written by the stand-in directly (CPU tests)."""
         st = self.status[c]
+        words = st[:1 + world]
+
+        def posted():
+            w = words.tolist()
+            return all((x >> 32) == self.seq for x in w), w
         if self.device.type == "cuda":
             stream = torch.cuda.current_stream(self.device)
-            spins = 0
-            while not self._no_post and int(st[0]) != self.seq:
+            spins, (ok, w) = 0, posted()
+            while not self._no_post and not ok:
                 spins += 1
-                if spins % 256 == 0 and stream.query() and int(st[0]) != self.seq:
-                    self._no_post = True        # the stream drained without the post becoming visible: read the headers instead, from now on
+                if spins % 64 == 0 and stream.query():
+                    ok, w = posted()
+                    if not ok:
+                        self._no_post = True    # the stream drained without the post becoming visible: read the headers instead, from now on
+                    break
+                ok, w = posted()
             if self._no_post:
                 hdr = self.packets_all[c][:world, :6].cpu()        # (synchronises: the plain way)
                 wants, caps = [int(x) for x in hdr[:, 1].tolist()], [int(x) for x in hdr[:, 3].tolist()]
-                return any(w > k for w, k in zip(wants, caps)), wants
-        elif int(st[0]) != self.seq:
-            raise RuntimeError("slot-sum exchange: the combine stand-in posted no verdict")
-        return bool(int(st[1])), [int(x) for x in st[2:2 + world].tolist()]
+                return any(a > k for a, k in zip(wants, caps)), wants
+        else:
+            ok, w = posted()
+            if not ok:
+                raise RuntimeError("slot-sum exchange: the combine stand-in posted no verdict")
+        return bool(w[0] & 0xffffffff), [int(x & 0xffffffff) for x in w[1:]]
 
     def finish_in_step(self):
         if not self._works:

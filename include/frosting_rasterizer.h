@@ -429,10 +429,11 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
  *                         order of additions as accumulating the per-view gradients in one process: the same bits.  M = 16
  *                         coefficients; raw opacity / scale / rotation inputs as in frg_backward_ex (their Jacobians are applied
  *                         per view, as there); shell-bound centres are not offered.
- *                         status (optional; device or pinned host memory, 2 + n_views words): word 2 + v <- the rows view v
- *                         wanted, word 1 <- 1 if any packet overflowed its capacity or does not describe this range, then
- *                         word 0 <- status_seq (system-scope release): a host polling pinned memory learns the verdict while
- *                         the pass runs, without synchronising the stream.  On overflow the outputs are incomplete. */
+ *                         status (optional; device or pinned host memory, 1 + n_views 64-bit words, each written at once as
+ *                         status_seq << 32 | value): word 0 <- 1 if any packet overflowed its capacity or does not describe
+ *                         this range, word 1 + v <- the rows view v wanted.  A host polling pinned memory until every word
+ *                         carries status_seq learns the verdict while the pass runs, without synchronising the stream (a
+ *                         one-thread launch in front of the passes posts it).  On overflow the outputs are incomplete. */
 size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows);
 int frg_pack_sum_rows(int P, int R, int first, int count, const char* workspace, size_t workspace_bytes, const float* drgb_masked,
                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
@@ -448,7 +449,7 @@ typedef struct frg_combine_args {
     const float *means3D, *shs, *scales, *rotations, *opacities;
     const float *raw_opacities, *raw_scales, *raw_rotations;
     float *dL_dmean3D, *dL_dscale, *dL_drot, *dL_dopacity, *dL_dsh;
-    unsigned int* status;
+    unsigned long long* status;
     unsigned int status_seq;
     unsigned char* row_live;
     void* hip_stream;

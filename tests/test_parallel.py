@@ -383,10 +383,9 @@ def torch_sum_combiner(ex, c, packets, n_views, seq):
             acc[k][rows] += g[k]                               # (indices are unique within a view)
     for k in PARAM_ORDER:
         ex.views[k][first:first + n] = acc[k]
-    st = ex.status[c]
-    st[1] = int(over)
-    st[2:2 + n_views] = torch.tensor(wants, dtype=torch.int32)
-    st[0] = seq
+    st = ex.status[c]              # 64-bit words, sequence number << 32 | value: [0] overflow, [1 + v] the rows view v wanted
+    st[0] = (seq << 32) | int(over)
+    st[1:1 + n_views] = torch.tensor([(seq << 32) | w_ for w_ in wants], dtype=torch.int64)
 
 
 def _slotsum_worker(rank, world, port, P, K, steps, chunks, q):

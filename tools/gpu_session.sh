@@ -21,7 +21,7 @@ ROOTD="$PWD"; O="$ROOTD/gpurun_out/$TAG"
 for w in $WHAT; do
 case $w in
 tests)
-  timeout 1800 python -m pytest tests -m gpu -q -rA --durations=15 ${PYTEST_ARGS:-} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  eval "timeout 1800 python -m pytest ${PYTEST_PATHS:-tests} -m gpu -q -rA --durations=15 ${PYTEST_ARGS:-}" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
   grep -E "passed|failed|^FAILED|^ERROR|rc=" $O/pytest_gpu.log | tail -15 ;;
 sparse)
   FROSTING_EXPERIMENTS=1 timeout 1500 python tools/sparse_grad_check.py ${SPARSE_ARGS:-} > $O/sparse_grad_check.log 2>&1; echo "sparse rc=$?" >> $O/sparse_grad_check.log
@@ -82,7 +82,12 @@ combine)
   for a in "${COMBINE_ARGS:---config c3}" ; do
     timeout 600 python tools/combine_bench.py $a 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" >> $O/combine_bench.log
   done
-  cat $O/combine_bench.log | cut -c1-1500 ;;
+  cat $O/combine_bench.log | cut -c1-1500
+  if [ -n "${COMBINE_PROF:-}" ]; then
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cprof" -- python "$ROOTD/tools/combine_bench.py" ${COMBINE_ARGS:---config c3} --no-check > /dev/null 2> "$O/cprof.err")
+    f=$(find $O/cprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/combine_kernel_stats.csv && head -14 $O/combine_kernel_stats.csv | cut -c1-60,140-230
+    rm -rf $O/cprof
+  fi ;;
 gradab)
   # the default arithmetic's distance to float64, one A/B build (tools/build_variants.sh) at a time: $GRADAB_LIBS = names under frosting_amd/lib_ab/
   : > $O/grad_ab.log
