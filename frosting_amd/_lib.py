@@ -112,6 +112,7 @@ class CombineArgs(C.Structure):
                 ("status", C.c_void_p),
                 ("status_seq", C.c_uint),
                 ("row_live", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("hip_stream", C.c_void_p)]
 
 
@@ -235,6 +236,8 @@ def lib():
     L.frg_sum_packet_bytes.argtypes = [i, C.c_longlong]
     L.frg_pack_sum_rows.restype = i
     L.frg_pack_sum_rows.argtypes = [i, i, i, i, vp, sz, vp, vp, vp, vp, f, f, i, i, f, i, vp, sz, C.c_longlong, vp]
+    L.frg_combine_workspace_bytes.restype = sz
+    L.frg_combine_workspace_bytes.argtypes = [i, C.c_longlong]
     L.frg_backward_combine.restype = i
     L.frg_backward_combine.argtypes = [C.POINTER(CombineArgs)]
     _lib = L
@@ -285,7 +288,7 @@ EXPORTED_SYMBOLS = [
     "frg_binning_bytes", "frg_geometry_layout", "frg_geometry_layout_n", "frg_image_layout", "frg_binning_layout",
     "frg_mesh_raster_workspace_bytes", "frg_mesh_rasterize", "frg_mesh_visible_faces", "frg_mesh_occlusion_workspace_bytes", "frg_mesh_occlusion_mask", "frg_sh_color_grad", "frg_sh_grad_from_views",
     "frg_pack_grad_rows", "frg_scatter_grad_rows", "frg_adam_step_rows", "frg_adam_step_shard",
-    "frg_sum_packet_bytes", "frg_pack_sum_rows", "frg_backward_combine",
+    "frg_sum_packet_bytes", "frg_pack_sum_rows", "frg_combine_workspace_bytes", "frg_backward_combine",
     "frg_forward_deferred", "frg_forward_finish", "frg_forward_ex", "frg_backward_ex", "frg_adam_step",
     "frg_photometric_workspace_bytes", "frg_photometric_loss", "frg_activate", "frg_activate_backward",
     "frg_knn_workspace_bytes", "frg_knn_mean_dist2", "frg_shell_points", "frg_shell_points_backward",

@@ -537,9 +537,14 @@ static size_t slots_bytes(int R) { return frg::align_up((size_t)(R > 0 ? R : 1) 
 static size_t sums_bytes(int P) { return frg::align_up((size_t)(P > 0 ? P : 1) * FRG_SLOT_FLOATS * sizeof(float), 256); }
 // ... + one bit per Gaussian, "its sums are not all zero", left by phase 1 for the slot-sum exchange (whole 256-Gaussian workgroups)
 static size_t live_mask_words(int P) { return (size_t)(P > 0 ? P : 1) / 64 + 8; }
+// ... + the pack's scratch: one row count per group of 256 such words
+static size_t live_mask_bytes(int P) { return frg::align_up(live_mask_words(P) * 8, 256); }
+// ... + the three view-direction terms per Gaussian that phase 1 leaves for the slot-sum packets
+static size_t dir_terms_bytes(int P) { return frg::align_up((size_t)(P > 0 ? P : 1) * 3 * sizeof(float), 256); }
+static size_t pack_scratch_bytes(int P) { return frg::align_up((live_mask_words(P) / 256 + 8) * 4, 256); }
 size_t frg_backward_workspace_bytes(int P, int R)
 {
-    return slots_bytes(R) + sums_bytes(P) + frg::align_up(live_mask_words(P) * 8, 256);
+    return slots_bytes(R) + sums_bytes(P) + live_mask_bytes(P) + pack_scratch_bytes(P) + dir_terms_bytes(P);
 }
 
 int frg_geometry_layout_n(int P, long long* out, int n)
@@ -957,6 +962,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     float* slots = reinterpret_cast<float*>(workspace);
     float* sums = reinterpret_cast<float*>(workspace + slots_bytes(R));
     unsigned long long* live_masks = phase == 1 ? reinterpret_cast<unsigned long long*>(workspace + slots_bytes(R) + sums_bytes(P)) : nullptr;
+    float* dir_terms = reinterpret_cast<float*>(workspace + slots_bytes(R) + sums_bytes(P) + live_mask_bytes(P) + pack_scratch_bytes(P));
     if (phase < 0 || phase > 2) return fail(FRG_EINVAL, "frg_backward_args: phase %d (0 whole | 1 blend + slot sums | 2 the rest)", phase);
     if (!radii) radii = g.internal_radii;   // rasterizer_impl.cu:375-377
 
@@ -1008,8 +1014,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         hipStream_t s_heavy = heavy_first ? stream : hs, s_plain = heavy_first ? hs : stream;
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(hs, g_bwd_side.fork, 0)); }
         if (!skip_heavy)
-            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy, sums, live_masks), "preprocess_bwd (long runs)");
-        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain, sums, live_masks), "preprocess_bwd");
+            FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, s_heavy, sums, live_masks, dir_terms), "preprocess_bwd (long runs)");
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | (skip_heavy ? FRG_PBW_NO_HEAVY_LAUNCH : 0), false, s_plain, sums, live_masks, dir_terms), "preprocess_bwd");
         if (side) { FRG_HIP(hipEventRecord(g_bwd_side.join, hs)); FRG_HIP(hipStreamWaitEvent(stream, g_bwd_side.join, 0)); }
     }
     return FRG_OK;
@@ -1109,38 +1115,13 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
     return FRG_OK;
 }
 
-// side stream of the combine pass's SH kernel (one per host thread, re-created when the thread's current device changes)
-namespace {
-struct CombineSide {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    int device = -1;
-    bool ensure()
-    {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (dev == device) return true;
-        if (stream) (void)hipStreamDestroy(stream);
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
-        stream = nullptr; fork = nullptr; join = nullptr; device = -1;
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
-        device = dev;
-        return true;
-    }
-};
-thread_local CombineSide g_combine_side;
-}  // namespace
-
 size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows)
 {
     if (n_gaussians < 0 || capacity_rows < 0) return 0;
     return frg::sum_packet_bytes((size_t)n_gaussians, (size_t)capacity_rows);
 }
 
-int frg_pack_sum_rows(int P, int R, int first, int count, const char* workspace, size_t workspace_bytes, const float* drgb_masked,
+int frg_pack_sum_rows(int P, int R, int first, int count, char* workspace, size_t workspace_bytes, const float* drgb_masked,
                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
                       int width, int height, float scale_modifier, int D, void* packet, size_t packet_bytes, long long capacity_rows,
                       void* hip_stream)
@@ -1155,10 +1136,18 @@ int frg_pack_sum_rows(int P, int R, int first, int count, const char* workspace,
     if (width <= 0 || height <= 0 || D < 0 || D > 3) return fail(FRG_EINVAL, "bad view: %dx%d degree %d", width, height, D);
     const float* sums = reinterpret_cast<const float*>(workspace + slots_bytes(R));
     const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(workspace + slots_bytes(R) + sums_bytes(P));
+    uint32_t* group_tot = reinterpret_cast<uint32_t*>(workspace + slots_bytes(R) + sums_bytes(P) + live_mask_bytes(P));
+    const float* dir_terms = reinterpret_cast<const float*>(workspace + slots_bytes(R) + sums_bytes(P) + live_mask_bytes(P) + pack_scratch_bytes(P));
     const frg::SumCamera cam{tan_fovx, tan_fovy, scale_modifier, width, height, D};
-    FRG_HIP(frg::launch_pack_sum_rows(first, count, (uint32_t)capacity_rows, masks, sums, drgb_masked, cam, viewmatrix, projmatrix, campos, packet,
-                                      (hipStream_t)hip_stream));
+    FRG_HIP(frg::launch_pack_sum_rows(first, count, (uint32_t)capacity_rows, masks, sums, dir_terms, drgb_masked, cam, viewmatrix, projmatrix, campos, packet,
+                                      group_tot, (hipStream_t)hip_stream));
     return FRG_OK;
+}
+
+size_t frg_combine_workspace_bytes(int n_views, long long capacity_rows)
+{
+    if (n_views < 0 || capacity_rows < 0) return 0;
+    return frg::combine_workspace_bytes(n_views, (size_t)capacity_rows);
 }
 
 int frg_backward_combine(const frg_combine_args* a)
@@ -1169,11 +1158,14 @@ int frg_backward_combine(const frg_combine_args* a)
         return fail(FRG_EINVAL, "bad range: P=%d first=%d (a multiple of 64) count=%d", a->P, a->first, a->count);
     if (a->n_views < 1 || a->n_views > 16) return fail(FRG_EINVAL, "1..16 views expected, got %d", a->n_views);
     if (a->M != 16) return fail(FRG_EINVAL, "the combine pass takes SH rows of 16 coefficients (M = %d)", a->M);
+    if (a->capacity_rows >= 65535LL * 256) return fail(FRG_EINVAL, "capacity_rows %lld: a packet holds fewer than 2^24 rows (cut the Gaussians into more ranges)", a->capacity_rows);
     if (a->count == 0) return FRG_OK;
     if (!a->packets || a->packet_stride_bytes % 16 != 0 || a->packet_stride_bytes < frg_sum_packet_bytes(a->count, a->capacity_rows))
         return fail(FRG_EINVAL, "packets: stride %zu, a packet of %d Gaussians and %lld rows has %zu bytes", a->packet_stride_bytes, a->count,
                     a->capacity_rows, frg_sum_packet_bytes(a->count, a->capacity_rows));
     if ((a->means3D == nullptr) || !a->shs) return fail(FRG_EINVAL, "means3D and shs are required (shell-bound centres are not offered here)");
+    if (!a->workspace || a->workspace_bytes < frg_combine_workspace_bytes(a->n_views, a->capacity_rows) || reinterpret_cast<uintptr_t>(a->workspace) % 16 != 0)
+        return fail(FRG_EALLOC, "workspace: need %zu bytes, 16-byte aligned", frg_combine_workspace_bytes(a->n_views, a->capacity_rows));
     if ((a->opacities == nullptr) == (a->raw_opacities == nullptr)) return fail(FRG_EINVAL, "provide exactly one of opacities / raw_opacities");
     const bool raw_sr = a->raw_scales && a->raw_rotations;
     if (raw_sr == (a->scales && a->rotations) || (a->raw_scales == nullptr) != (a->raw_rotations == nullptr) || (a->scales == nullptr) != (a->rotations == nullptr))
@@ -1185,14 +1177,8 @@ int frg_backward_combine(const frg_combine_args* a)
     frg::FwdInputs in{a->means3D, a->scales, a->rotations, a->opacities, a->shs, nullptr, nullptr, nullptr, nullptr, nullptr};
     in.raw.raw_opacity = a->raw_opacities; in.raw.raw_scale = a->raw_scales; in.raw.raw_rot = a->raw_rotations;
     frg::BwdOutputs out{nullptr, nullptr, a->dL_dopacity, nullptr, a->dL_dmean3D, nullptr, a->dL_dsh, a->dL_dscale, a->dL_drot};
-    // the dense pass (latency / instruction bound) on the caller's stream, the SH pass (708 MB of rows: HBM bound) beside it
-    hipStream_t stream = (hipStream_t)a->hip_stream;
-    const bool side = g_combine_side.ensure();
-    hipStream_t s_sh = side ? g_combine_side.stream : stream;
-    if (side) { FRG_HIP(hipEventRecord(g_combine_side.fork, stream)); FRG_HIP(hipStreamWaitEvent(s_sh, g_combine_side.fork, 0)); }
-    FRG_HIP(frg::launch_backward_combine(a->first, a->count, a->n_views, a->packets, a->packet_stride_bytes, in, out, a->status, a->status_seq,
-                                         a->row_live, stream, s_sh));
-    if (side) { FRG_HIP(hipEventRecord(g_combine_side.join, s_sh)); FRG_HIP(hipStreamWaitEvent(stream, g_combine_side.join, 0)); }
+    FRG_HIP(frg::launch_backward_combine(a->first, a->count, a->n_views, a->packets, a->packet_stride_bytes, (uint32_t)a->capacity_rows, in, out,
+                                         a->status, a->status_seq, a->row_live, a->workspace, (hipStream_t)a->hip_stream));
     return FRG_OK;
 }
 

@@ -74,7 +74,8 @@ struct BwdOutputs {
 // live_masks (phase 1, optional): one bit per Gaussian -- "its nine sums are not all zero" -- as 64-bit words per wave of 64
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s, float* sums = nullptr, unsigned long long* live_masks = nullptr);
+                                 bool heavy_only, hipStream_t s, float* sums = nullptr, unsigned long long* live_masks = nullptr,
+                                 float* view_dir_terms = nullptr /* [P][3], with live_masks: d(colour)/d(direction) . masked dRGB of the marked Gaussians */);
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);
@@ -91,19 +92,20 @@ hipError_t launch_scatter_grad_rows(unsigned int n, int P, const float* rows, fl
 // slot-sum exchange (slot_exchange.hip): rows of the nine per-Gaussian sums of phase 1, packed in index order behind a bit mask;
 // one combine pass runs the per-Gaussian chain for every view's row in view order
 #define FRG_SUM_HDR_WORDS 64
-#define FRG_SUM_ROW_FLOATS 9
+#define FRG_SUM_ROW_FLOATS 12     // masked dRGB[3], six pixel moments, three view-direction terms: 48 bytes, three aligned float4
 #define FRG_SUM_MAGIC 0x46534d36u
 struct SumCamera { float tan_fovx, tan_fovy, scale_modifier; int width, height, D; };
 size_t sum_packet_bytes(size_t n, size_t capacity);
 // live_masks: one bit per Gaussian, as phase 1 of the backward leaves them in its workspace; sums: [P][9] of the same workspace
 hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsigned long long* live_masks, const float* sums,
-                                const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, void* packet, hipStream_t s);
+                                const float* view_dir_terms, const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, void* packet, uint32_t* group_tot /* scratch: one word per 16384 Gaussians */, hipStream_t s);
 // in: means3D, shs, scales, rotations, opacities (or their raw forms); out: dL_dmean3D, dL_dscale, dL_drot, dL_dopacity, dL_dsh
-// s: the dense pass (11 floats per Gaussian); s_sh: the SH pass (48) -- the same stream, or a side stream ordered by the caller
-hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
+// workspace: combine_workspace_bytes(n_views, capacity) -- per packed row its Gaussian and its eleven staged terms;
+size_t combine_workspace_bytes(int n_views, size_t capacity);
+hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes, uint32_t capacity,
                                    const FwdInputs& in, const BwdOutputs& out, unsigned long long* status, uint32_t seq, unsigned char* row_live,
-                                   hipStream_t s, hipStream_t s_sh);
+                                   char* workspace, hipStream_t s);
 
 // fused Adam over the flat parameter layout (adam.hip)
 #ifndef FRG_ADAM_MAX_SEGMENTS

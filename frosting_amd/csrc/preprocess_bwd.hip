@@ -63,7 +63,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
                       const float* __restrict__ sh_dir, int flags, const uint32_t* __restrict__ heavy,
                       const uint32_t* __restrict__ sh_layout, float* __restrict__ sums, unsigned char* __restrict__ row_live,
-                      unsigned long long* __restrict__ live_masks)
+                      unsigned long long* __restrict__ live_masks, float* __restrict__ view_dir_terms)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -280,12 +280,49 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
     // dL_dcolor, complete after the reduction, is written: with shs given and dL_dsh == NULL it is the clamp-masked colour
     // gradient, the payload of the factored view-parallel exchange, which can travel while phase 2 computes.
     if (flags & FRG_PBW_SUMS_ONLY) {
-        if (live_masks) {      // the slot-sum exchange packs the rows of these Gaussians (slot_exchange.hip): has_grad of phase 2
+        if (live_masks) {
+            // The slot-sum exchange packs the rows of these Gaussians (slot_exchange.hip): has_grad of phase 2 -- and, beside
+            // the sums, the three view-direction terms dd = d(colour)/d(direction) . masked dRGB that section 4 below forms
+            // (the only use phase 2 makes of the forward's sh_dir / of the 192-byte SH row): with them in the packet no rank
+            // has to read another view's SH rows to run this view's chain.
             bool any = false;
 #pragma unroll
             for (int c = 0; c < FRG_SLOT_FLOATS; c++) any |= part[c] != 0.0f;
-            const uint64_t m = __ballot(any && visible);
+            any &= visible;
+            const uint64_t m = __ballot(any);
             if (lane == 0) live_masks[idx0 / 64] = m;
+            if (any && shs) {
+                float shd[9];
+                if (SH16 && (*sh_layout & 2u)) {       // the forward left no sh_dir: from the SH row, in the forward's order of additions
+#pragma unroll
+                    for (int k = 0; k < 9; k++) shd[k] = 0.0f;
+                    const float3 mm = param_mean(means3D, raw, idx);
+                    const float dox = mm.x - vmx.campos[0], doy = mm.y - vmx.campos[1], doz = mm.z - vmx.campos[2];
+                    const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+                    const ShDir sd(vp.D, dox / len, doy / len, doz / len);
+                    const int ncoef = (vp.D + 1) * (vp.D + 1);
+                    const float4* row = reinterpret_cast<const float4*>(shs) + (size_t)idx * 12;
+#pragma unroll
+                    for (int j = 0; j < 12; j++) {
+                        const float4 v = row[j];
+                        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int e = 4 * j + t, i = e / 3, ch = e % 3;
+                            if (i < ncoef) sd.feed(i, f[t], shd[ch], shd[3 + ch], shd[6 + ch]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) shd[k] = sh_dir[(size_t)sh_row * 9 + k];
+                }
+                float dRGB[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) dRGB[ch] = part[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
+                view_dir_terms[3 * (size_t)idx] = shd[0] * dRGB[0] + shd[1] * dRGB[1] + shd[2] * dRGB[2];
+                view_dir_terms[3 * (size_t)idx + 1] = shd[3] * dRGB[0] + shd[4] * dRGB[1] + shd[5] * dRGB[2];
+                view_dir_terms[3 * (size_t)idx + 2] = shd[6] * dRGB[0] + shd[7] * dRGB[1] + shd[8] * dRGB[2];
+            }
         }
         if (valid) {
 #pragma unroll
@@ -627,7 +664,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s, float* sums, unsigned long long* live_masks)
+                                 bool heavy_only, hipStream_t s, float* sums, unsigned long long* live_masks, float* view_dir_terms)
 {
     const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
@@ -638,7 +675,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums, o.row_live, live_masks)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums, o.row_live, live_masks, view_dir_terms)
     // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }

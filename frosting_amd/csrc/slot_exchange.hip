@@ -1,12 +1,13 @@
 // Slot-sum exchange of the view-parallel step (no counterpart in the single-GPU reference).
 //
 // After phase 1 of the backward (blend backward + slot reduction) everything one view contributes to the gradient of a
-// Gaussian is determined by NINE floats -- the clamp-masked colour gradient and the six pixel moments of G dL/dalpha
-// (preprocess_bwd.hip, "sums") -- together with data every rank already holds: the parameters and the view's camera.
+// Gaussian is determined by TWELVE floats -- the clamp-masked colour gradient, the six pixel moments of G dL/dalpha
+// (preprocess_bwd.hip, "sums") and the three view-direction terms d(colour)/d(direction) . dRGB (what phase 2 forms from the
+// forward's sh_dir) -- together with data every rank already holds: the parameters and the view's camera.
 // And only the Gaussians some pixel reached before its tile saturated have sums at all (one in eight at C3).  So the
 // ranks exchange those sums instead of finished gradients:
 //
-//   pack     the rows {dRGB[3], moments[6]} (36 bytes) of the Gaussians with a gradient, IN INDEX ORDER, behind a bit mask
+//   pack     the rows {dRGB[3], moments[6], dd[3]} (48 bytes) of the Gaussians with a gradient, IN INDEX ORDER, behind a bit mask
 //            (one bit per Gaussian) and one row offset per block of 64 Gaussians: Gaussian g finds its row in view v as
 //            base[v][g / 64] + popcount(mask[v][g / 64] below g).  Fixed capacity: no host wait for a count.
 //   gather   one all-gather of the packets (host side: frosting_amd/parallel.py).
@@ -17,8 +18,9 @@
 //            the dense zero fills, per-view scatters and SH rebuild of the round-5 plans.
 //
 // What a view's geometry record held for phase 2 -- conic and opacity -- is recomputed here from the parameters with the
-// forward's own functions (gauss_math.h), bit-identically; d(colour)/d(direction) is formed from the SH row as the
-// sh_dir_in_backward form of preprocess_bwd.hip does (the same bits as the forward's: tests/test_gpu_parity.py).
+// forward's own functions (gauss_math.h), bit-identically.  The view-direction terms travel in the rows because forming them
+// needs the 192-byte SH row of the Gaussian: read once per (Gaussian, view) pair by every rank, those rows were the larger
+// part of the combine pass's memory traffic (0.84 GB fetched for eight C3 views; 12 more bytes per row on the wire instead).
 #include "gauss_math.h"
 #include "kernels.h"
 
@@ -32,111 +34,103 @@ namespace frg {
 //   [45] width  [46] height  [47] scale_modifier  [48] active SH degree  [49] focal_x  [50] focal_y (api.hip make_view's)
 //   masks   uint64[nblk]  at word 64                 (nblk = blocks of 64 Gaussians)
 //   bases   uint32[nblk]  behind them, 16-byte aligned
-//   rows    float[capacity][9] behind them, 16-byte aligned
+//   rows    float[capacity][12] behind them, 16-byte aligned
 __host__ __device__ inline size_t sum_packet_blocks(size_t n) { return (n + 63) / 64; }
 __host__ __device__ inline size_t sum_packet_bases_word(size_t n) { return FRG_SUM_HDR_WORDS + 2 * sum_packet_blocks(n); }
 __host__ __device__ inline size_t sum_packet_rows_word(size_t n) { return (sum_packet_bases_word(n) + sum_packet_blocks(n) + 3) / 4 * 4; }
 size_t sum_packet_bytes(size_t n, size_t capacity) { return ((sum_packet_rows_word(n) + FRG_SUM_ROW_FLOATS * capacity + 3) / 4 * 4) * 4; }
 
-// One workgroup: the packet's masks (copied from the phase-1 workspace), the exclusive prefix of their popcounts, the header.
-// Rounds of 1024 x 16 blocks: a thread takes SIXTEEN CONSECUTIVE blocks -- one 128-byte line of mask words, requested at once
-// -- counts and prefixes them in registers, and one workgroup scan of the 1024 thread totals (DPP wave scans + one LDS hop)
-// carries the running total: two barriers per 16 384 blocks.  (Round 6's first form walked a thread's blocks one dependent
-// load after the other: 70 us per 23 000 blocks; a workgroup scan per 1024 blocks: 30 us.)
-#define SUM_SCAN_PER 16
-__global__ void __launch_bounds__(1024)
-sum_rows_scan_kernel(int first, int n, uint32_t capacity, const unsigned long long* __restrict__ live_masks,
-                     uint32_t* __restrict__ packet, SumCamera cam, const float* __restrict__ viewmatrix,
-                     const float* __restrict__ projmatrix, const float* __restrict__ campos)
+// Pack, two launches over the packet's blocks of 64 Gaussians:
+//   sum_rows_local_kernel   one thread per block, 256 blocks per workgroup: the mask word (copied from the phase-1 workspace),
+//                           its popcount, the exclusive prefix WITHIN the group of 256 blocks -> bases[], the group's total ->
+//                           group_tot[] (scratch behind the masks in the workspace);
+//   sum_rows_pack_kernel    one wave per block: the prefix of the groups before its own (a few hundred totals: three loads
+//                           per lane and a wave scan) makes bases[] global; the rows of the marked Gaussians, in index order;
+//                           the first wave writes the header (rows wanted = the sum of all totals, the camera).
+// (Round 6's first forms scanned all blocks in ONE workgroup: 70, 30 and again 70 us per packet of 47 000 blocks -- one CU's
+// load path.)
+#define SUM_GROUP 256
+__global__ void __launch_bounds__(SUM_GROUP)
+sum_rows_local_kernel(int first, int n, const unsigned long long* __restrict__ live_masks, uint32_t* __restrict__ packet,
+                      uint32_t* __restrict__ group_tot)
 {
-    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t wave_tot[SUM_GROUP / 64];
     const int nblk = (int)sum_packet_blocks((size_t)n), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(packet + FRG_SUM_HDR_WORDS);
-    uint32_t* bases = packet + sum_packet_bases_word((size_t)n);
-    const unsigned long long* src = live_masks + first / 64;
-    uint32_t carry = 0;                                           // blocks before this round: the same in every thread
-    for (int r0 = 0; r0 < nblk; r0 += 1024 * SUM_SCAN_PER) {
-        const int b0 = r0 + tid * SUM_SCAN_PER;
-        unsigned long long m[SUM_SCAN_PER];
+    const int b = blockIdx.x * SUM_GROUP + tid;
+    const unsigned long long m = b < nblk ? (live_masks + first / 64)[b] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(m), incl = wave_incl_scan_dpp(c);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int i = 0; i < SUM_SCAN_PER; i++) m[i] = b0 + i < nblk ? src[b0 + i] : 0ull;
-        uint32_t pre[SUM_SCAN_PER], sum = 0;
-#pragma unroll
-        for (int i = 0; i < SUM_SCAN_PER; i++) { pre[i] = sum; sum += (uint32_t)__popcll(m[i]); }
-        const uint32_t incl = wave_incl_scan_dpp(sum);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t before = carry, total = carry;
-        for (int w = 0; w < 16; w++) { const uint32_t t = wave_tot[w]; if (w < wave) before += t; total += t; }
-        before += incl - sum;
-#pragma unroll
-        for (int i = 0; i < SUM_SCAN_PER; i++)
-            if (b0 + i < nblk) { masks[b0 + i] = m[i]; bases[b0 + i] = before + pre[i]; }
-        carry = total;
-        __syncthreads();
+    for (int w = 0; w < SUM_GROUP / 64; w++) { const uint32_t t = wave_tot[w]; if (w < wave) before += t; total += t; }
+    if (b < nblk) {
+        reinterpret_cast<unsigned long long*>(packet + FRG_SUM_HDR_WORDS)[b] = m;
+        (packet + sum_packet_bases_word((size_t)n))[b] = before + incl - c;
     }
-    if (tid == 0) {
-        const uint32_t want = carry;
-        packet[0] = want < capacity ? want : capacity;
-        packet[1] = want;
-        packet[2] = (uint32_t)n; packet[3] = capacity; packet[4] = (uint32_t)first; packet[5] = FRG_SUM_MAGIC;
-        packet[6] = 0u; packet[7] = 0u;
-        float* f = reinterpret_cast<float*>(packet);
-        for (int i = 0; i < 16; i++) { f[8 + i] = viewmatrix[i]; f[24 + i] = projmatrix[i]; }
-        f[40] = campos[0]; f[41] = campos[1]; f[42] = campos[2];
-        f[43] = cam.tan_fovx; f[44] = cam.tan_fovy;
-        packet[45] = (uint32_t)cam.width; packet[46] = (uint32_t)cam.height;
-        f[47] = cam.scale_modifier; packet[48] = (uint32_t)cam.D;
-        f[49] = cam.width / (2.0f * cam.tan_fovx);        // rasterizer_impl.cu:222-223, as api.hip make_view forms them
-        f[50] = cam.height / (2.0f * cam.tan_fovy);
-        for (int i = 51; i < FRG_SUM_HDR_WORDS; i++) packet[i] = 0u;
-    }
+    if (tid == 0) group_tot[blockIdx.x] = total;
 }
 
-// One wave per block of 64 Gaussians: the rows of the marked ones, in index order.
 __global__ void __launch_bounds__(256)
-sum_rows_pack_kernel(int first, int n, uint32_t capacity, const float* __restrict__ sums, const float* __restrict__ drgb_masked,
-                     uint32_t* __restrict__ packet)
+sum_rows_pack_kernel(int first, int n, uint32_t capacity, const float* __restrict__ sums, const float* __restrict__ view_dir_terms,
+                     const float* __restrict__ drgb_masked, uint32_t* __restrict__ packet, const uint32_t* __restrict__ group_tot, SumCamera cam,
+                     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos)
 {
     const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= (int)sum_packet_blocks((size_t)n)) return;
+    const int nblk = (int)sum_packet_blocks((size_t)n);
+    if (blk >= nblk) return;
+    const int ngroups = (nblk + SUM_GROUP - 1) / SUM_GROUP, grp = blk / SUM_GROUP;
+    // rows before this block's group (and, for the header, of all groups)
+    uint32_t before = 0, all = 0;
+    for (int j = lane; j < ngroups; j += 64) { const uint32_t t = group_tot[j]; all += t; if (j < grp) before += t; }
+    before = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(before), 63);
+    uint32_t* bases = packet + sum_packet_bases_word((size_t)n);
+    const uint32_t base = before + bases[blk];
+    if (blk == 0) {
+        all = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(all), 63);
+        float* f = reinterpret_cast<float*>(packet);
+        if (lane < 16) { f[8 + lane] = viewmatrix[lane]; f[24 + lane] = projmatrix[lane]; }
+        if (lane < 3) f[40 + lane] = campos[lane];
+        if (lane >= 51 && lane < FRG_SUM_HDR_WORDS) packet[lane] = 0u;
+        if (lane == 0) {
+            packet[0] = all < capacity ? all : capacity;
+            packet[1] = all;
+            packet[2] = (uint32_t)n; packet[3] = capacity; packet[4] = (uint32_t)first; packet[5] = FRG_SUM_MAGIC;
+            packet[6] = 0u; packet[7] = 0u;
+            f[43] = cam.tan_fovx; f[44] = cam.tan_fovy;
+            packet[45] = (uint32_t)cam.width; packet[46] = (uint32_t)cam.height;
+            f[47] = cam.scale_modifier; packet[48] = (uint32_t)cam.D;
+            f[49] = cam.width / (2.0f * cam.tan_fovx);        // rasterizer_impl.cu:222-223, as api.hip make_view forms them
+            f[50] = cam.height / (2.0f * cam.tan_fovy);
+        }
+    }
     const unsigned long long m = reinterpret_cast<const unsigned long long*>(packet + FRG_SUM_HDR_WORDS)[blk];
+    if (lane == 0) bases[blk] = base;                   // (this wave alone reads and writes the block's entry)
     if (!((m >> lane) & 1ull)) return;
-    const uint32_t row = (packet + sum_packet_bases_word((size_t)n))[blk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t row = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (row >= capacity) return;                 // (over capacity: the header says so; the host packs again into a larger packet)
     const size_t g = (size_t)first + (size_t)blk * 64 + lane;
-    float* dst = reinterpret_cast<float*>(packet) + sum_packet_rows_word((size_t)n) + (size_t)row * FRG_SUM_ROW_FLOATS;
-    const float* s = sums + g * FRG_SLOT_FLOATS;
-    dst[0] = drgb_masked[3 * g]; dst[1] = drgb_masked[3 * g + 1]; dst[2] = drgb_masked[3 * g + 2];
-#pragma unroll
-    for (int c = 3; c < FRG_SLOT_FLOATS; c++) dst[c] = s[c];
+    float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(packet) + sum_packet_rows_word((size_t)n) + (size_t)row * FRG_SUM_ROW_FLOATS);
+    const float* sp = sums + g * FRG_SLOT_FLOATS;
+    const float* dd = view_dir_terms + 3 * g;
+    dst[0] = make_float4(drgb_masked[3 * g], drgb_masked[3 * g + 1], drgb_masked[3 * g + 2], sp[3]);
+    dst[1] = make_float4(sp[4], sp[5], sp[6], sp[7]);
+    dst[2] = make_float4(sp[8], dd[0], dd[1], dd[2]);
 }
 
 hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsigned long long* live_masks, const float* sums,
-                                const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, void* packet, hipStream_t s)
+                                const float* view_dir_terms, const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, void* packet, uint32_t* group_tot, hipStream_t s)
 {
     uint32_t* pk = reinterpret_cast<uint32_t*>(packet);
-    hipLaunchKernelGGL(sum_rows_scan_kernel, dim3(1), dim3(1024), 0, s, first, n, capacity, live_masks, pk, cam, viewmatrix, projmatrix, campos);
     const int nblk = (int)sum_packet_blocks((size_t)n);
-    hipLaunchKernelGGL(sum_rows_pack_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, first, n, capacity, sums, drgb_masked, pk);
+    hipLaunchKernelGGL(sum_rows_local_kernel, dim3((nblk + SUM_GROUP - 1) / SUM_GROUP), dim3(SUM_GROUP), 0, s, first, n, live_masks, pk, group_tot);
+    hipLaunchKernelGGL(sum_rows_pack_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, first, n, capacity, sums, view_dir_terms, drgb_masked, pk, group_tot, cam,
+                       viewmatrix, projmatrix, campos);
     return hipGetLastError();
 }
 
 // ---- combine ------------------------------------------------------------------------------------------------------------------
-// Two kernels over the same packets, independent of each other (api.hip launches them on two streams):
-//   combine_dense_kernel   dL_dmean3D, dL_dscale, dL_drot, dL_dopacity (11 floats per Gaussian): the geometric chain.  A (Gaussian,
-//                          view) pair costs ~700 vector instructions and only one Gaussian in eight has a row in a given view
-//                          (their union over eight ring views: 45 % of the Gaussians), so the Gaussians with a row anywhere are
-//                          COMPACTED over a tile of 1024 and one lane per such Gaussian walks its views in view order.
-//   combine_sh_kernel      dL_dsh (48 floats per Gaussian): sum over the views of basis(dir_v) (x) dRGB_v -- cheap per pair (the
-//                          basis and 48 products), dominated by its 192-byte rows: one lane per Gaussian, the views in a
-//                          wave-uniform loop, the rows leave as one float4 stream through an LDS transpose (the form of
-//                          view_exchange.hip's rebuild, with the colour gradients looked up in the packets instead of dense planes).
-// (One kernel holding all 59 accumulators, the camera and the chain's temporaries took 334 VGPRs -- one wave per SIMD -- and
-// 1.0 ms for eight C3 views.)
-#define CMB_THREADS 256
-#define CMB_TILE 1024                   // Gaussians per workgroup of the dense pass
 #define CMB_MAX_VIEWS 16
 
 struct CmbCam { float view[16], proj[16], campos[3], tan_fovx, tan_fovy, focal_x, focal_y, half_w, half_h, scale_modifier; int D; };
@@ -157,49 +151,15 @@ __device__ __forceinline__ void load_cam(const uint32_t* __restrict__ h, CmbCam&
 }
 
 // sections 2, 3 and 5 of preprocess_bwd_kernel, and the view-direction term of section 4, for ONE (Gaussian, view): `part` = the
-// view's nine slot sums of the Gaussian, the colour part already clamp-masked.  Adds the view's terms to the accumulators.
-// Expression for expression the chain of preprocess_bwd.hip (has_grad branch; d(colour)/d(direction) formed from the SH row
-// as its sh_dir_in_backward form does); tests pin the two bit for bit.  Raw-parameter mode (raw_params.h): the activations'
-// Jacobians are applied per view, as phase 2 applies them.
+// view's nine slot sums of the Gaussian (the colour part clamp-masked), dd = its three view-direction terms.  Adds the view's
+// terms to acc[11].  Expression for expression the chain of preprocess_bwd.hip (has_grad branch); tests pin the two bit for
+// bit.  Raw-parameter mode (raw_params.h): the activations' Jacobians are applied per view, as phase 2 applies them.
 __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 mean, const float3 sc, const float4 q, const float o,
                                                  const bool raw_opacity, const bool raw_scale, const bool raw_rot, const float4 q_raw,
-                                                 const float4* __restrict__ sh_row, float (&part)[FRG_SLOT_FLOATS],
+                                                 float (&part)[FRG_SLOT_FLOATS], const float dd0, const float dd1, const float dd2,
                                                  float* __restrict__ acc /* [11]: mean3D 3, scale 3, rot 4, opacity */)
 {
-    // d(colour)/d(direction) from the SH row, coefficient after coefficient as the forward's SH pass adds them
     const float dox = mean.x - cm.campos[0], doy = mean.y - cm.campos[1], doz = mean.z - cm.campos[2];
-    float dd0, dd1, dd2;
-    {
-        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-        const float x = dox / len, y = doy / len, z = doz / len;
-        float shd[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) shd[k] = 0.0f;
-        const ShDir sd(cm.D, x, y, z);
-        const int ncoef = (cm.D + 1) * (cm.D + 1);
-        // three groups of four float4: the next group's loads are not issued before this group is consumed (twelve requests in
-        // flight would hold 48 registers through the whole chain's register peak)
-#pragma unroll
-        for (int jg = 0; jg < 3; jg++) {
-            float4 v4[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) v4[jj] = sh_row[4 * jg + jj];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const float f[4] = {v4[jj].x, v4[jj].y, v4[jj].z, v4[jj].w};
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int ee = 4 * (4 * jg + jj) + t, i = ee / 3, ch = ee % 3;
-                    if (i < ncoef) sd.feed(i, f[t], shd[ch], shd[3 + ch], shd[6 + ch]);
-                }
-            }
-            __asm__ volatile("" ::: "memory");
-        }
-        dd0 = shd[0] * part[0] + shd[1] * part[1] + shd[2] * part[2];
-        dd1 = shd[3] * part[0] + shd[4] * part[1] + shd[5] * part[2];
-        dd2 = shd[6] * part[0] + shd[7] * part[1] + shd[8] * part[2];
-    }
-    __asm__ volatile("" ::: "memory");
     // the forward's conic (preprocess.hip preprocess_one): cov3D -> EWA cov2D -> + 0.3 -> inverse
     float cov[6];
     cov3d_from_scale_rot(sc, cm.scale_modifier, q, cov);
@@ -350,104 +310,142 @@ __global__ void combine_verdict_kernel(unsigned long long* __restrict__ status, 
     if (v == 0) __hip_atomic_store(&status[0], ((unsigned long long)seq << 32) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// One workgroup per tile of CMB_TILE Gaussians, the VIEWS in an outer, workgroup-uniform loop: for view v the tile's Gaussians
-// with a row in v (127 of 1024 at C3) are compacted into a list and every lane takes one -- dense lanes, and the camera of the
-// view in scalar registers.  A Gaussian's 11 sums live in LDS (one row per Gaussian of the tile), where each view adds its
-// terms; the barrier between two views keeps a Gaussian's additions in view order.  At the end every row of the tile is
-// written from the LDS rows, zeros where no view had anything.  (Round 6's first form walked each Gaussian's views in one lane,
-// accumulators in registers: a wave of 64 such Gaussians has rows in all eight views, 2.2 each -- 27 % busy lanes, 0.76 ms.)
+// The dense part in three launches over a scratch of 48 bytes per packed row (n_views x capacity_rows rows):
+//   combine_index_kernel   one lane per Gaussian, its views in a wave-uniform loop: gidx[v][row] <- the Gaussian of row `row` of
+//                          view v (the packets give Gaussian -> row; the chain wants row -> Gaussian);
+//   combine_chain_kernel   grid (views, rows / 256): ONE LANE PER PACKED ROW -- every lane busy, the view uniform per workgroup
+//                          (its camera in scalar registers), every load of a pair in flight at once, no barrier anywhere;
+//                          the pair's eleven terms go to stage[v][row];
+//   combine_sum_kernel     one lane per Gaussian: the staged terms of its views added IN VIEW ORDER, every row written once
+//                          (zeros where no view has a row).
+// Forms of round 6 that were measured and replaced (eight C3 views, 3 M Gaussians, 3 M pairs): one lane per Gaussian walking
+// its views, accumulators in registers -- 27 % busy lanes: 0.76 ms; tiles of 1024 / 512 Gaussians with the views in an outer
+// loop and the sums in LDS -- dense lanes, but a tile's eight view steps are a chain of barriers with one or two waves at
+// work: 0.41 / 0.44 ms.
 #define CMB_ACC 11
-__global__ void __launch_bounds__(CMB_THREADS, 3)
-combine_dense_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words,
-                     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
-                     const float* __restrict__ rotations, const float* __restrict__ opacities, RawInputs raw,
-                     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-                     float* __restrict__ dL_dopacity, unsigned char* __restrict__ row_live)
+#define CMB_STAGE 12                    // floats per staged row (48 bytes: three aligned float4)
+__global__ void __launch_bounds__(256)
+combine_index_kernel(int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
+                     uint32_t* __restrict__ gidx)
 {
-    __shared__ float acc[CMB_TILE * CMB_ACC];
-    __shared__ uint16_t vbits[CMB_TILE];
-    __shared__ uint16_t list[CMB_TILE];
-    __shared__ uint32_t n_list[CMB_MAX_VIEWS];      // one counter per view: no reset between two views' compactions
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t bases_w = sum_packet_bases_word((size_t)n), rows_w = sum_packet_rows_word((size_t)n);
-    const int tile0 = blockIdx.x * CMB_TILE;        // relative to `first`
-    if (tid < CMB_MAX_VIEWS) n_list[tid] = 0u;
-    for (int i = tid; i < CMB_TILE * CMB_ACC; i += CMB_THREADS) acc[i] = 0.0f;
-    // per Gaussian of the tile: the views in which it has a row
-    for (int bb = wave; bb < CMB_TILE / 64; bb += CMB_THREADS / 64) {
-        const int g0 = tile0 + bb * 64;
-        uint32_t vb = 0;
-        if (g0 < n) {
-            const int blk = g0 / 64;
-            for (int v = 0; v < n_views; v++) {
-                const unsigned long long m = reinterpret_cast<const unsigned long long*>(packets + (size_t)v * packet_stride_words + FRG_SUM_HDR_WORDS)[blk];
-                vb |= (uint32_t)((m >> lane) & 1ull) << v;
-            }
-            if (g0 + lane >= n) vb = 0;
-        }
-        vbits[bb * 64 + lane] = (uint16_t)vb;
-    }
-    __syncthreads();
-#pragma unroll 1
+    const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= (int)sum_packet_blocks((size_t)n)) return;
+    const size_t bases_w = sum_packet_bases_word((size_t)n);
     for (int v = 0; v < n_views; v++) {
-        // the tile's Gaussians with a row in view v, compacted (in no particular order: each appears once)
-        for (int bb = wave; bb < CMB_TILE / 64; bb += CMB_THREADS / 64) {
-            const bool has = ((vbits[bb * 64 + lane] >> v) & 1u) != 0u;
-            const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
-            uint32_t at = 0;
-            if (lane == 0 && hm) at = atomicAdd(&n_list[v], (uint32_t)__popcll(hm));
-            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-            if (has) list[at + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (uint16_t)(bb * 64 + lane);
-        }
         const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-        CmbCam cm;
-        load_cam(pk, cm);
-        const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk[3]);
-        __syncthreads();
-        const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_list[v]);
-        for (uint32_t e = (uint32_t)tid; e < L; e += CMB_THREADS) {
-            const int gl = (int)list[e], g = tile0 + gl, idx = first + g, blk = g / 64, gl64 = g & 63;
-            const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
-            const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << gl64) - 1ull));
-            if (row < cap) {                                    // (beyond the capacity: the step is repeated, the verdict says so)
-                const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
-                float part[FRG_SLOT_FLOATS];
-#pragma unroll
-                for (int c2 = 0; c2 < FRG_SLOT_FLOATS; c2++) part[c2] = r[c2];
-                const float3 mean = param_mean(means3D, raw, idx);
-                const float3 sc = param_scale(scales, raw, idx);
-                const float4 q = param_rot(rotations, raw, idx);
-                const float o = param_opacity(opacities, raw, idx);
-                float4 q_raw = q;
-                if (raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
-                combine_one_view(cm, mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr, q_raw,
-                                 reinterpret_cast<const float4*>(shs) + (size_t)idx * 12, part, acc + gl * CMB_ACC);
-            }
-        }
-        __syncthreads();                  // the next view may add to the same rows from other lanes (and overwrites the list)
-    }
-    // every row of the tile, once
-    for (int i = tid; i < CMB_TILE; i += CMB_THREADS) {
-        const int g = tile0 + i;
-        if (g >= n) break;
-        const size_t gi = (size_t)first + g;
-        const bool live = vbits[i] != 0;
-        if (row_live) { row_live[gi] = live ? 1 : 0; if (!live) continue; }
-        const float* a = acc + i * CMB_ACC;
-        dL_dmean3D[3 * gi] = a[0]; dL_dmean3D[3 * gi + 1] = a[1]; dL_dmean3D[3 * gi + 2] = a[2];
-        dL_dscale[3 * gi] = a[3]; dL_dscale[3 * gi + 1] = a[4]; dL_dscale[3 * gi + 2] = a[5];
-        *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(a[6], a[7], a[8], a[9]);
-        dL_dopacity[gi] = a[10];
+        const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
+        if (!((m >> lane) & 1ull)) continue;
+        const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (row < capacity) gidx[(size_t)v * capacity + row] = (uint32_t)(blk * 64 + lane);
     }
 }
 
-// dL_dsh [first, first + n) = sum over the views, in view order, of basis(dir_v) (x) dRGB_v for the views in which the Gaussian
-// has a row.  One lane per Gaussian; the view loop is wave-uniform (mask word, row base and camera centre are scalar loads);
-// the 192-byte rows leave through a wave-private LDS transpose as contiguous float4 streams (view_exchange.hip's idiom).
+__global__ void __launch_bounds__(256)
+combine_chain_kernel(int first, int n, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
+                     const uint32_t* __restrict__ gidx, float* __restrict__ stage,
+                     const float* __restrict__ means3D, const float* __restrict__ scales,
+                     const float* __restrict__ rotations, const float* __restrict__ opacities, RawInputs raw)
+{
+    // the VIEW is the fast grid dimension: the workgroups of one row block in all views are dispatched together, and row block k
+    // of every view covers about the same Gaussians (the rows are index-ordered, the views' densities alike) -- their
+    // parameter lines and SH rows are then found in the L2 by all but the first view
+    const int v = blockIdx.x;
+    const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+    const uint32_t rows = min((uint32_t)__builtin_amdgcn_readfirstlane((int)pk[1]), capacity);
+    if (blockIdx.y * 256u >= rows) return;                    // workgroup-uniform
+    CmbCam cm;
+    load_cam(pk, cm);
+    const uint32_t row = blockIdx.y * 256u + threadIdx.x;
+    if (row >= rows) return;
+    const int idx = first + (int)gidx[(size_t)v * capacity + row];
+    const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(pk) + sum_packet_rows_word((size_t)n) + (size_t)row * FRG_SUM_ROW_FLOATS);
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    float part[FRG_SLOT_FLOATS] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+    const float3 mean = param_mean(means3D, raw, idx);
+    const float3 sc = param_scale(scales, raw, idx);
+    const float4 q = param_rot(rotations, raw, idx);
+    const float o = param_opacity(opacities, raw, idx);
+    float4 q_raw = q;
+    if (raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
+    float out[CMB_ACC];
+#pragma unroll
+    for (int k = 0; k < CMB_ACC; k++) out[k] = 0.0f;
+    combine_one_view(cm, mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr, q_raw,
+                     part, r2.y, r2.z, r2.w, out);
+    float4* dst = reinterpret_cast<float4*>(stage + ((size_t)v * capacity + row) * CMB_STAGE);
+    dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+    dst[2] = make_float4(out[8], out[9], out[10], 0.0f);
+}
+
+// The two gather passes, one lane per Gaussian each, over the views in which it has a row, IN VIEW ORDER:
+//   combine_sum_kernel   the 11 dense sums: the terms the chain pass staged for (view, row), added one after the other;
+//   combine_sh_kernel    dL_dsh: basis(dir_v) (x) dRGB_v, 48 products per view added into 48 accumulators; the 192-byte rows
+//                        leave through a wave-private LDS transpose as contiguous float4 streams (view_exchange.hip's idiom);
+// every row of the five outputs written once, zeros where no view has a row (with row_live: those are skipped and the byte
+// says so).  The view loops are wave-uniform (mask word, row base and camera centre are uniform loads), in groups of four
+// views whose look-ups are requested together.  (As ONE kernel the 59 accumulators and the staged rows of a group took 180
+// VGPRs, two waves per SIMD: 0.36 ms for eight C3 views against 0.10 + 0.19 of the two.)
+__global__ void __launch_bounds__(256)
+combine_sum_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
+                   const float* __restrict__ stage, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale,
+                   float* __restrict__ dL_drot, float* __restrict__ dL_dopacity, unsigned char* __restrict__ row_live)
+{
+    const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= (int)sum_packet_blocks((size_t)n)) return;
+    const int g = blk * 64 + lane;
+    const size_t bases_w = sum_packet_bases_word((size_t)n);
+    float a[CMB_ACC];
+#pragma unroll
+    for (int k = 0; k < CMB_ACC; k++) a[k] = 0.0f;
+    bool live = false;
+#pragma unroll 1
+    for (int v0 = 0; v0 < n_views; v0 += 4) {
+        unsigned long long m[4];
+        uint32_t base[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = min(v0 + u, n_views - 1);
+            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+            m[u] = v0 + u < n_views ? reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk] : 0ull;
+            base[u] = (pk + bases_w)[blk];
+        }
+        float4 st[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = min(v0 + u, n_views - 1);
+            const bool bit = ((m[u] >> lane) & 1ull) != 0ull;
+            live |= bit;
+            const uint32_t row = base[u] + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
+            st[u][0] = st[u][1] = st[u][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            m[u] = (bit && row < capacity) ? 1ull : 0ull;
+            if (m[u]) {
+                const float4* sp = reinterpret_cast<const float4*>(stage + ((size_t)v * capacity + row) * CMB_STAGE);
+                st[u][0] = sp[0]; st[u][1] = sp[1]; st[u][2] = sp[2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                          // view order
+            if (m[u]) {
+                a[0] += st[u][0].x; a[1] += st[u][0].y; a[2] += st[u][0].z; a[3] += st[u][0].w;
+                a[4] += st[u][1].x; a[5] += st[u][1].y; a[6] += st[u][1].z; a[7] += st[u][1].w;
+                a[8] += st[u][2].x; a[9] += st[u][2].y; a[10] += st[u][2].z;
+            }
+        }
+    }
+    if (g >= n) return;
+    const size_t gi = (size_t)first + g;
+    if (row_live) { row_live[gi] = live ? 1 : 0; if (!live) return; }
+    dL_dmean3D[3 * gi] = a[0]; dL_dmean3D[3 * gi + 1] = a[1]; dL_dmean3D[3 * gi + 2] = a[2];
+    dL_dscale[3 * gi] = a[3]; dL_dscale[3 * gi + 1] = a[4]; dL_dscale[3 * gi + 2] = a[5];
+    *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(a[6], a[7], a[8], a[9]);
+    dL_dopacity[gi] = a[10];
+}
+
 #define CSH_SUB 16
 #define CSH_ROW_F4 13
 __global__ void __launch_bounds__(256)
-combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words,
+combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
                   const float* __restrict__ means3D, RawInputs raw, float* __restrict__ dL_dsh, const unsigned char* __restrict__ row_live)
 {
     __shared__ __attribute__((aligned(16))) float4 lds_all[4 * CSH_SUB * CSH_ROW_F4];
@@ -464,19 +462,16 @@ combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ pa
     float3 mean = make_float3(0.f, 0.f, 0.f);
     if (valid) mean = param_mean(means3D, raw, idx);
     unsigned long long any = 0ull;
-    // The views in groups of four: the four mask words and row offsets of the block are requested together, then the four rows'
-    // colour gradients -- two memory round trips per group instead of three per view (mask -> row index -> row) in a chain.
 #pragma unroll 1
     for (int v0 = 0; v0 < n_views; v0 += 4) {
         unsigned long long m[4];
-        uint32_t base[4], cap[4];
+        uint32_t base[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int v = min(v0 + u, n_views - 1);
             const uint32_t* pk = packets + (size_t)v * packet_stride_words;
             m[u] = v0 + u < n_views ? reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk] : 0ull;
             base[u] = (pk + bases_w)[blk];
-            cap[u] = pk[3];
         }
         float dr[4][3];
         bool has[4];
@@ -486,7 +481,7 @@ combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ pa
             const uint32_t* pk = packets + (size_t)v * packet_stride_words;
             any |= m[u];
             const uint32_t row = base[u] + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
-            has[u] = ((m[u] >> lane) & 1ull) && row < cap[u];
+            has[u] = ((m[u] >> lane) & 1ull) && row < capacity;
             dr[u][0] = dr[u][1] = dr[u][2] = 0.0f;
             if (has[u]) {
                 const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
@@ -526,7 +521,7 @@ combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ pa
             }
         }
     }
-    // rows to write: all of the block's -- or, with row_live, those of its Gaussians with a row somewhere
+    // SH rows to write: all of the block's -- or, with row_live, those of its Gaussians with a row somewhere
     const unsigned long long wmask = row_live ? any : ~0ull;
     float4* dst = reinterpret_cast<float4*>(dL_dsh) + ((size_t)first + g0) * 12;
     const int nvalid = min(64, n - g0);
@@ -552,20 +547,32 @@ combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ pa
     }
 }
 
-hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes,
+size_t combine_workspace_bytes(int n_views, size_t capacity)
+{
+    const size_t rows = (size_t)(n_views > 0 ? n_views : 1) * (capacity > 0 ? capacity : 1);
+    return align_up(rows * 4, 256) + align_up(rows * CMB_STAGE * 4, 256);
+}
+
+hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes, uint32_t capacity,
                                    const FwdInputs& in, const BwdOutputs& out, unsigned long long* status, uint32_t seq, unsigned char* row_live,
-                                   hipStream_t s, hipStream_t s_sh)
+                                   char* workspace, hipStream_t s)
 {
     const uint32_t* pk = reinterpret_cast<const uint32_t*>(packets);
-    const int tiles = (n + CMB_TILE - 1) / CMB_TILE;
-    if (status) hipLaunchKernelGGL(combine_verdict_kernel, dim3(1), dim3(64), 0, s, status, seq, pk, packet_stride_bytes / 4, n_views, first, n);
-    hipLaunchKernelGGL(combine_dense_kernel, dim3(tiles), dim3(CMB_THREADS), 0, s, first, n, n_views, pk, packet_stride_bytes / 4,
-                       in.means3D, in.shs, in.scales, in.rotations, in.opacities, in.raw, out.dL_dmean3D, out.dL_dscale, out.dL_drot,
-                       out.dL_dopacity, row_live);
+    const size_t stride_w = packet_stride_bytes / 4;
     const int nblk = (int)sum_packet_blocks((size_t)n);
-    // (row_live is written by the dense pass; the SH pass derives the same bits from the masks themselves)
-    hipLaunchKernelGGL(combine_sh_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s_sh, first, n, n_views, pk, packet_stride_bytes / 4,
-                       in.means3D, in.raw, out.dL_dsh, row_live);
+    const size_t rows = (size_t)n_views * (capacity > 0 ? capacity : 1);
+    uint32_t* gidx = reinterpret_cast<uint32_t*>(workspace);
+    float* stage = reinterpret_cast<float*>(workspace + align_up(rows * 4, 256));
+    if (status) hipLaunchKernelGGL(combine_verdict_kernel, dim3(1), dim3(64), 0, s, status, seq, pk, stride_w, n_views, first, n);
+    hipLaunchKernelGGL(combine_index_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, n, n_views, pk, stride_w, capacity, gidx);
+    if (capacity > 0)
+        hipLaunchKernelGGL(combine_chain_kernel, dim3(n_views, (capacity + 255) / 256), dim3(256), 0, s, first, n, pk, stride_w, capacity, gidx, stage,
+                           in.means3D, in.scales, in.rotations, in.opacities, in.raw);
+    hipLaunchKernelGGL(combine_sum_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, first, n, n_views, pk, stride_w, capacity, stage,
+                       out.dL_dmean3D, out.dL_dscale, out.dL_drot, out.dL_dopacity, row_live);
+    // (row_live is written by the sum pass; the SH pass derives the same bits from the masks themselves)
+    hipLaunchKernelGGL(combine_sh_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, first, n, n_views, pk, stride_w, capacity, in.means3D, in.raw,
+                       out.dL_dsh, row_live);
     return hipGetLastError();
 }
 

@@ -462,7 +462,7 @@ class GradientExchange:
 
 # ---- slot-sum exchange (round 6) ---------------------------------------------------------------------------------------------
 SUM_HDR_WORDS = 64      # frosting_amd/csrc/slot_exchange.hip: the packet's header ...
-SUM_ROW_FLOATS = 9      # ... and its rows {masked dRGB[3], six pixel moments}
+SUM_ROW_FLOATS = 12     # ... and its rows {masked dRGB[3], six pixel moments, three view-direction terms}
 SUM_TILE = 1024         # chunk boundaries fall on the combine pass's tiles
 
 
@@ -498,6 +498,9 @@ def _hip_sum_combiner(ex: "SlotSumExchange", chunk: int, packets: torch.Tensor, 
     g, pr = ex.views, ex.params
     raw = ex.raw_params
     v = lambda t: None if t is None else t.data_ptr()
+    ws = int(_lib.lib().frg_combine_workspace_bytes(int(n_views), int(ex.capacity[chunk])))
+    if ex.combine_work is None or ex.combine_work.numel() < ws:
+        ex.combine_work = torch.empty(int(ws * 1.25) + 256, dtype=torch.uint8, device=packets.device)
     a = _lib.CombineArgs(struct_size=C.sizeof(_lib.CombineArgs), P=ex.P, first=first, count=count, n_views=int(n_views),
                          packets=v(packets), packet_stride_bytes=packets.shape[1] * 4, capacity_rows=int(ex.capacity[chunk]),
                          M=int(ex.shapes["shs"][1]), means3D=v(pr["means3D"]), shs=v(pr["shs"]),
@@ -506,7 +509,7 @@ def _hip_sum_combiner(ex: "SlotSumExchange", chunk: int, packets: torch.Tensor, 
                          raw_scales=v(pr["scales"]) if raw else None, raw_rotations=v(pr["rotations"]) if raw else None,
                          dL_dmean3D=v(g["means3D"]), dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), dL_dopacity=v(g["opacities"]),
                          dL_dsh=v(g["shs"]), status=v(ex.status[chunk]), status_seq=int(seq), row_live=None,
-                         hip_stream=torch.cuda.current_stream(packets.device).cuda_stream)
+                         workspace=v(ex.combine_work), workspace_bytes=ex.combine_work.numel(), hip_stream=torch.cuda.current_stream(packets.device).cuda_stream)
     rc = _lib.lib().frg_backward_combine(C.byref(a))
     if rc < 0:
         raise RuntimeError(f"frg_backward_combine failed ({rc}): {_lib.last_error()}")
@@ -532,7 +535,7 @@ class SlotSumExchange(GradientExchange):
 
     slotsum = True
 
-    def __init__(self, shapes: dict, device, process_group=None, average: bool = False, chunks: int = 2, slack: float = 1.25,
+    def __init__(self, shapes: dict, device, process_group=None, average: bool = False, chunks: int = 2, slack: float = 1.125,
                  packer=None, combiner=None, raw_params: bool = False):
         super().__init__(shapes, device, process_group, average)
         if "shs" not in self.shapes:
@@ -560,6 +563,7 @@ class SlotSumExchange(GradientExchange):
         self.params = None
         self.stats = {"rows_wanted_max": 0, "repacks": 0, "packet_bytes": 0}
         self._no_post = False
+        self.combine_work = None      # the combine pass's scratch (48 bytes per packed row), grown on demand
 
     def set_params(self, params: dict):
         """The replicated parameters the combine pass reads: {'means3D','shs','scales','rotations','opacities'} (raw forms

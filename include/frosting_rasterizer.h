@@ -435,7 +435,7 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
  *                         carries status_seq learns the verdict while the pass runs, without synchronising the stream (a
  *                         one-thread launch in front of the passes posts it).  On overflow the outputs are incomplete. */
 size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows);
-int frg_pack_sum_rows(int P, int R, int first, int count, const char* workspace, size_t workspace_bytes, const float* drgb_masked,
+int frg_pack_sum_rows(int P, int R, int first, int count, char* workspace, size_t workspace_bytes, const float* drgb_masked,
                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
                       int width, int height, float scale_modifier, int D, void* packet, size_t packet_bytes, long long capacity_rows,
                       void* hip_stream);
@@ -452,8 +452,11 @@ typedef struct frg_combine_args {
     unsigned long long* status;
     unsigned int status_seq;
     unsigned char* row_live;
+    char* workspace;              /* frg_combine_workspace_bytes(n_views, capacity_rows): 48 bytes per packed row (its Gaussian, its staged terms) */
+    size_t workspace_bytes;
     void* hip_stream;
 } frg_combine_args;
+size_t frg_combine_workspace_bytes(int n_views, long long capacity_rows);
 int frg_backward_combine(const frg_combine_args* args);
 
 /* ---- fused Adam over the flat per-Gaussian parameter layout ---------------------------

@@ -236,9 +236,9 @@ def test_ctypes_structs_have_the_headers_layout(tmp_path):
 
 def test_sum_packet_size_formula():
     """frosting_amd.parallel.sum_packet_words (what the Python layer sizes its all-gather buffers with, on any backend) is the
-    library's frg_sum_packet_bytes: header, one bit per Gaussian, one row offset per 64 Gaussians, 36-byte rows."""
+    library's frg_sum_packet_bytes: header, one bit per Gaussian, one row offset per 64 Gaussians, 48-byte rows."""
     from frosting_amd.parallel import sum_packet_words
     L = _lib.lib()
     for n, cap in ((1, 0), (64, 64), (65, 7), (1000, 1000), (1_500_000, 204_800), (3_000_000, 3_000_000)):
         assert 4 * sum_packet_words(n, cap) == L.frg_sum_packet_bytes(n, cap), (n, cap)
-    assert sum_packet_words(1_500_000, 204_800) * 4 < 0.15 * 1_500_000 * 36 + 400_000
+    assert sum_packet_words(1_500_000, 204_800) * 4 < 0.15 * 1_500_000 * 48 + 400_000

@@ -302,12 +302,12 @@ def test_exchange_then_adam_then_next_forward_equals_single_process_accumulation
 
 def _sum_chain(params, rows, campos, S):
     """A deterministic stand-in for the per-Gaussian backward chain: the 59 gradient floats of the Gaussians `rows` in one view
-    from their nine sums S [k, 9], the parameters and the view's camera centre.  Multiplications and additions only (the same
-    bits whatever the batch shape); zero sums give a zero row."""
+    from their twelve sums S [k, 12] (the packet's row), the parameters and the view's camera centre.  Multiplications and
+    additions only (the same bits whatever the batch shape); zero sums give a zero row."""
     m, sc, q, o, sh = (params[k][rows] for k in ("means3D", "scales", "rotations", "opacities", "shs"))
     d = m - campos
     w = S[:, 3:6] * d + S[:, 6:9]
-    return dict(means3D=w * sc + S[:, 0:3] * d,
+    return dict(means3D=w * sc + S[:, 0:3] * d + S[:, 9:12],
                 scales=S[:, 3:6] * sc * sc + S[:, 6:9] * d,
                 rotations=q * (S[:, 3:4] * d[:, 0:1] + S[:, 8:9]) + S[:, 4:5] * o,
                 opacities=S[:, 8:9] * o + S[:, 5:6] * d[:, 1:2],
@@ -315,10 +315,10 @@ def _sum_chain(params, rows, campos, S):
 
 
 def _view_sums(params, view, it, P):
-    """Phase 1 of view `view` at iteration `it`: nine sums per Gaussian, zero rows for the Gaussians no pixel reached -- one in
+    """Phase 1 of view `view` at iteration `it`: twelve sums per Gaussian, zero rows for the Gaussians no pixel reached -- one in
     four in the first two iterations, three in four from the third (the packets sized from the earlier steps then overflow)."""
     campos = torch.tensor([1.0 + view, 0.5 - view, 2.0]) * 0.5
-    base = torch.cat([params["means3D"], params["scales"], params["rotations"][:, :3]], 1)     # [P, 9]
+    base = torch.cat([params["means3D"], params["scales"], params["rotations"][:, :3], params["shs"][:, 1, :]], 1)     # [P, 12]
     S = base * (0.25 + 0.125 * view) + 0.0625 * (1 + it)
     reached = (torch.arange(P) * 7 + 3 * view) % 4 == 0 if it < 2 else (torch.arange(P) * 7 + 3 * view) % 4 != 0
     S[~reached] = 0.0

@@ -27,8 +27,13 @@ def main():
     ap.add_argument("--chunks", type=int, default=2)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--option", action="append", default=[], help="name=value for frg_set_option")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    from frosting_amd import _lib
+    for kv in a.option:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     cfg = scenes.CONFIGS[a.config]
     P = a.points or cfg["P"]
     scene, _, bg = scenes.config_scene(a.config, 0, P=P)

@@ -79,12 +79,13 @@ cmd)
 combine)
   # the local terms of the slot-sum exchange: phase 1, pack, the combine pass over eight views' packets (tools/combine_bench.py)
   : > $O/combine_bench.log
-  for a in "${COMBINE_ARGS:---config c3}" ; do
+  IFS='|' read -ra CARGS <<< "${COMBINE_ARGS:---config c3}"
+  for a in "${CARGS[@]}" ; do
     timeout 600 python tools/combine_bench.py $a 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" >> $O/combine_bench.log
   done
   cat $O/combine_bench.log | cut -c1-1500
   if [ -n "${COMBINE_PROF:-}" ]; then
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cprof" -- python "$ROOTD/tools/combine_bench.py" ${COMBINE_ARGS:---config c3} --no-check > /dev/null 2> "$O/cprof.err")
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cprof" -- python "$ROOTD/tools/combine_bench.py" ${COMBINE_PROF_ARGS:---config c3} --no-check > /dev/null 2> "$O/cprof.err")
     f=$(find $O/cprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/combine_kernel_stats.csv && head -14 $O/combine_kernel_stats.csv | cut -c1-60,140-230
     rm -rf $O/cprof
   fi ;;
