@@ -75,7 +75,7 @@ def parse_args():
                          "which like the reference blocks on a read-back of num_rendered")
     ap.add_argument("--exchange", default="slotsum", choices=["slotsum", "auto", "sparse", "factored", "allreduce"],
                     help="N>1: 'slotsum' (default, round 6) = the ranks all-gather the nine per-Gaussian SLOT SUMS of their view's "
-                         "backward (36-byte rows of the Gaussians with a gradient, index-ordered behind a bit mask, fixed-capacity "
+                         "backward (48-byte rows of the Gaussians with a gradient, index-ordered behind a bit mask, fixed-capacity "
                          "packets: no host wait for a count) and every rank runs the per-Gaussian chain for every view's rows in "
                          "view order in ONE pass that writes each gradient row once (csrc/slot_exchange.hip) -- the plan the "
                          "arithmetic of DESIGN.md section 5 puts first at every bus bandwidth, and ONE kind of collective "
@@ -86,7 +86,7 @@ def parse_args():
                          "SH rebuild (frosting_amd/parallel.py); 'auto' = an explicit PROBE: N>1 on RCCL, 'slotsum', 'factored' and "
                          "'sparse' are each timed for a few steps before the warm-up and the fastest one runs (never the default: "
                          "the first multi-rank run of a build should execute as few never-executed collectives as possible)")
-    ap.add_argument("--chunks", type=int, default=2,
+    ap.add_argument("--chunks", type=int, default=4,
                     help="slotsum: index ranges of Gaussians with a packet and a collective each -- the combine pass of one range "
                          "runs while the next range's packets travel")
     ap.add_argument("--reduce", default="allreduce", choices=["auto", "allreduce", "direct"],
@@ -786,7 +786,7 @@ def main():
                        "tile_list_mean": float(tile_len.mean()), "tile_list_max": int(tile_len.max()),
                        "parallelism": f"view-parallel x{world}", "ranks": world, "backend": (args.backend if dist else "none"),
                        "exchange": ("none" if not exchanging else
-                                    ("slot sums: 36-byte rows {masked dRGB, six pixel moments} of the Gaussians with a gradient, index-ordered "
+                                    ("slot sums: 48-byte rows {masked dRGB, six pixel moments, three view-direction terms} of the Gaussians with a gradient, index-ordered "
                                      f"behind a bit mask, all-gathered in {len(vpr.exchange.chunks)} fixed-capacity packets per view; every rank "
                                      "runs the per-Gaussian chain for every view's rows in view order in one pass (frg_backward_combine)"
                                      if args.exchange == "slotsum" else
@@ -827,21 +827,25 @@ def main():
             render_ms = compute_only if compute_only is not None else ms_per_step
             sched = "in-step" if schedule[0] == "in-step" else "sync"
             rows_frac = (vpr.exchange.sparse_stats["rows_max"] / P) if (exchanging and args.exchange == "sparse" and vpr.exchange.sparse_stats["rows_max"]) else 0.124
+            if exchanging and args.exchange == "slotsum" and vpr.exchange.stats["rows_wanted_max"]:
+                rows_frac = vpr.exchange.stats["rows_wanted_max"] / P
             plans = [("allreduce", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync",)] + \
-                    [("factored", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync", "in-step")] + [("sparse", "allgather", "sync")]
+                    [("factored", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync", "in-step")] + [("sparse", "allgather", "sync"), ("slotsum", "allgather", "in-step")]
             out["predicted"] = {
                 "render_ms": render_ms, "rows_fraction": rows_frac,
-                "this_plan": {str(n): predict_exchange(P, 16, n, render_ms, args.exchange, args.reduce, sched, rows_fraction=rows_frac) for n in (2, 4, 8)},
-                "at_8_gpus": {f"{pl}/{rd}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, rd, sc, rows_fraction=rows_frac)["scaling_vs_1gpu"], 2)
+                "this_plan": {str(n): predict_exchange(P, 16, n, render_ms, args.exchange, args.reduce, sched, rows_fraction=rows_frac, chunks=args.chunks) for n in (2, 4, 8)},
+                "at_8_gpus": {f"{pl}/{rd}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, rd, sc, rows_fraction=rows_frac, chunks=args.chunks)["scaling_vs_1gpu"], 2)
                               for pl, rd, sc in plans},
                 # the same with every collective priced at ONE bus bandwidth per GPU, whatever its algorithm: the sum of the
                 # seven links, what RCCL usually reaches of it, and a pessimistic figure
-                "at_8_gpus_by_bus_GBps": {str(bw): {f"{pl}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, "direct", sc, bus_GBps=bw, rows_fraction=rows_frac)["scaling_vs_1gpu"], 2)
-                                                    for pl, sc in (("allreduce", "sync"), ("factored", "in-step"), ("sparse", "sync"))}
+                "at_8_gpus_by_bus_GBps": {str(bw): {f"{pl}/{sc}": round(predict_exchange(P, 16, 8, render_ms, pl, "direct", sc, bus_GBps=bw, rows_fraction=rows_frac, chunks=args.chunks)["scaling_vs_1gpu"], 2)
+                                                    for pl, sc in (("allreduce", "sync"), ("factored", "in-step"), ("sparse", "sync"), ("slotsum", "in-step"))}
                                           for bw in (1071, 450, 300)},
                 "note": "scaling = N x render / (render + exposed exchange); link arithmetic: RCCL's all-reduce priced as a ring "
                         "bound by one xGMI link (pessimistic), 'direct' = reduce-scatter + all-gather over all seven links; bus "
-                        "arithmetic: incoming bytes / bus bandwidth; see DESIGN.md section 5"}
+                        "arithmetic: incoming bytes / bus bandwidth; slotsum: the packets' all-gather pipelined with the combine pass over "
+                        "--chunks ranges, local terms (pack, combine pass, the chain phase 1 leaves out) measured on one MI355X "
+                        "(frosting_amd.parallel.SLOTSUM_LOCAL_MS); see DESIGN.md section 5"}
         if compute_only is not None:
             out["exchange_timing"] = {"schedule": schedule[0], "ms_per_step_without_exchange": compute_only,
                                       "exposed_ms_per_step": ms_per_step - compute_only, "other_schedule": other_schedule,

@@ -478,6 +478,8 @@ int frg_set_option(const char* name, int value)
         const int old = frg::g_rows_grid; frg::g_rows_grid = value <= 0 ? 0 : value < 8 ? 8 : value; return old;
     }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
+    // tuning: blocks of 64 Gaussians per tile of the combine pass (3, 6, 12 or 24; 0 = chosen from the number of views); same results
+    if (name && strcmp(name, "combine_blocks") == 0) { const int old = frg::g_combine_blocks; frg::g_combine_blocks = value < 0 ? 0 : value; return old; }
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 

@@ -101,8 +101,9 @@ hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsig
                                 const float* view_dir_terms, const float* drgb_masked, const SumCamera& cam, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, void* packet, uint32_t* group_tot /* scratch: one word per 16384 Gaussians */, hipStream_t s);
 // in: means3D, shs, scales, rotations, opacities (or their raw forms); out: dL_dmean3D, dL_dscale, dL_drot, dL_dopacity, dL_dsh
-// workspace: combine_workspace_bytes(n_views, capacity) -- per packed row its Gaussian and its eleven staged terms;
+// workspace: combine_workspace_bytes(n_views, capacity) (256 bytes since the pass became one kernel that stages nothing in HBM);
 size_t combine_workspace_bytes(int n_views, size_t capacity);
+extern int g_combine_blocks;   // tuning: blocks of 64 Gaussians per combine tile (0: by the number of views)
 hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes, uint32_t capacity,
                                    const FwdInputs& in, const BwdOutputs& out, unsigned long long* status, uint32_t seq, unsigned char* row_live,
                                    char* workspace, hipStream_t s);

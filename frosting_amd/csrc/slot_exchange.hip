@@ -132,38 +132,45 @@ hipError_t launch_pack_sum_rows(int first, int n, uint32_t capacity, const unsig
 
 // ---- combine ------------------------------------------------------------------------------------------------------------------
 #define CMB_MAX_VIEWS 16
+#define CMB_ACC 11
 
-struct CmbCam { float view[16], proj[16], campos[3], tan_fovx, tan_fovy, focal_x, focal_y, half_w, half_h, scale_modifier; int D; };
-
-// A view's camera from its packet header.  The address is wave-uniform, but behind the passes' stores the compiler does not
-// prove these loads unclobbered and issues vector loads: every value is moved to a scalar register by hand (v_readfirstlane),
-// so that the camera costs no vector registers across the chain.
-__device__ __forceinline__ float uniform_f(const uint32_t* __restrict__ h, int i) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)h[i])); }
-__device__ __forceinline__ void load_cam(const uint32_t* __restrict__ h, CmbCam& cm)
-{
-#pragma unroll
-    for (int i = 0; i < 16; i++) { cm.view[i] = uniform_f(h, 8 + i); cm.proj[i] = uniform_f(h, 24 + i); }
-    cm.campos[0] = uniform_f(h, 40); cm.campos[1] = uniform_f(h, 41); cm.campos[2] = uniform_f(h, 42);
-    cm.tan_fovx = uniform_f(h, 43); cm.tan_fovy = uniform_f(h, 44);
-    cm.focal_x = uniform_f(h, 49); cm.focal_y = uniform_f(h, 50);
-    cm.half_w = 0.5f * (float)__builtin_amdgcn_readfirstlane((int)h[45]); cm.half_h = 0.5f * (float)__builtin_amdgcn_readfirstlane((int)h[46]);
-    cm.scale_modifier = uniform_f(h, 47); cm.D = __builtin_amdgcn_readfirstlane((int)h[48]);
-}
+// A view's camera = words 8 .. 50 of its packet header, copied to LDS once per workgroup (CAM_WORDS floats per view at an odd
+// stride: lanes that look at different views hit different banks).  Offsets inside a view's camera:
+#define CAM_WORDS 43
+#define CAM_STRIDE 45
+#define CAM_VIEW 0
+#define CAM_PROJ 16
+#define CAM_POS 32
+#define CAM_TANX 35
+#define CAM_TANY 36
+#define CAM_W 37
+#define CAM_H 38
+#define CAM_SCALE 39
+#define CAM_D 40
+#define CAM_FX 41
+#define CAM_FY 42
 
 // sections 2, 3 and 5 of preprocess_bwd_kernel, and the view-direction term of section 4, for ONE (Gaussian, view): `part` = the
-// view's nine slot sums of the Gaussian (the colour part clamp-masked), dd = its three view-direction terms.  Adds the view's
-// terms to acc[11].  Expression for expression the chain of preprocess_bwd.hip (has_grad branch); tests pin the two bit for
-// bit.  Raw-parameter mode (raw_params.h): the activations' Jacobians are applied per view, as phase 2 applies them.
-__device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 mean, const float3 sc, const float4 q, const float o,
+// view's nine slot sums of the Gaussian (the colour part clamp-masked), dd = its three view-direction terms.  Writes the view's
+// eleven terms to out[11].  Expression for expression the chain of preprocess_bwd.hip (has_grad branch); tests pin the two bit
+// for bit.  Raw-parameter mode (raw_params.h): the activations' Jacobians are applied per view, as phase 2 applies them.
+// cam: the view's camera in LDS (per lane: the lanes of a wave work on different views).
+// (cam_at(): the camera's LDS offset made opaque anew in front of every section, so that its ~45 values are read where they are
+// used instead of being loaded -- and held in 45 vector registers -- ahead of the whole chain)
+__device__ __forceinline__ const float* cam_at(const float* __restrict__ cams, int off) { asm volatile("" : "+v"(off)); return cams + off; }
+__device__ __forceinline__ void combine_one_view(const float* __restrict__ cams, const int cam_off, const float3 mean, const float3 sc, const float4 q, const float o,
                                                  const bool raw_opacity, const bool raw_scale, const bool raw_rot, const float4 q_raw,
                                                  float (&part)[FRG_SLOT_FLOATS], const float dd0, const float dd1, const float dd2,
-                                                 float* __restrict__ acc /* [11]: mean3D 3, scale 3, rot 4, opacity */)
+                                                 float* __restrict__ out /* [11]: mean3D 3, scale 3, rot 4, opacity */)
 {
-    const float dox = mean.x - cm.campos[0], doy = mean.y - cm.campos[1], doz = mean.z - cm.campos[2];
+    const float* cam = cam_at(cams, cam_off);
+    const float* vmat = cam + CAM_VIEW;
+    const float scale_modifier = cam[CAM_SCALE], focal_x = cam[CAM_FX], focal_y = cam[CAM_FY];
+    const float half_w = 0.5f * (float)__float_as_int(cam[CAM_W]), half_h = 0.5f * (float)__float_as_int(cam[CAM_H]);
     // the forward's conic (preprocess.hip preprocess_one): cov3D -> EWA cov2D -> + 0.3 -> inverse
     float cov[6];
-    cov3d_from_scale_rot(sc, cm.scale_modifier, q, cov);
-    const Ewa e = ewa_setup(mean, cm.focal_x, cm.focal_y, cm.tan_fovx, cm.tan_fovy, cm.view);
+    cov3d_from_scale_rot(sc, scale_modifier, q, cov);
+    const Ewa e = ewa_setup(mean, focal_x, focal_y, cam[CAM_TANX], cam[CAM_TANY], vmat);
     float a, b, c;
     ewa_cov2d(e, cov, a, b, c);
     a += 0.3f; c += 0.3f;
@@ -173,8 +180,8 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
     // pixel moments -> the reference's terms (backward.cu:536-554), once per Gaussian
     {
         const float m3 = part[3], m4 = part[4];
-        part[3] = -o * (kc.x * m3 + kc.y * m4) * cm.half_w;
-        part[4] = -o * (kc.z * m4 + kc.y * m3) * cm.half_h;
+        part[3] = -o * (kc.x * m3 + kc.y * m4) * half_w;
+        part[4] = -o * (kc.z * m4 + kc.y * m3) * half_h;
         part[5] = -0.5f * o * part[5];
         part[6] = -0.5f * o * part[6];
         part[7] = -0.5f * o * part[7];
@@ -207,25 +214,26 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
         const float dL_dT12 = 2 * TV_(1, 2) * dL_dc + TV_(0, 2) * dL_db;
 #undef TV_
 #undef T_
-#define W_(k, rr) cm.view[4 * (rr) + (k)]
+        const float* vmat2 = cam_at(cams, cam_off) + CAM_VIEW;
+#define W_(k, rr) vmat2[4 * (rr) + (k)]
         const float dL_dJ00 = W_(0, 0) * dL_dT00 + W_(0, 1) * dL_dT01 + W_(0, 2) * dL_dT02;
         const float dL_dJ02 = W_(2, 0) * dL_dT00 + W_(2, 1) * dL_dT01 + W_(2, 2) * dL_dT02;
         const float dL_dJ11 = W_(1, 0) * dL_dT10 + W_(1, 1) * dL_dT11 + W_(1, 2) * dL_dT12;
         const float dL_dJ12 = W_(2, 0) * dL_dT10 + W_(2, 1) * dL_dT11 + W_(2, 2) * dL_dT12;
 #undef W_
-        const float h_x = cm.focal_x, h_y = cm.focal_y;
+        const float h_x = focal_x, h_y = focal_y;
         const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
         const float dL_dtx = e.xmul * -h_x * tz2 * dL_dJ02;
         const float dL_dty = e.ymul * -h_y * tz2 * dL_dJ12;
         const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * e.t[0]) * tz3 * dL_dJ02 + (2 * h_y * e.t[1]) * tz3 * dL_dJ12;
-        const float* vm = cm.view;
+        const float* vm = cam_at(cams, cam_off) + CAM_VIEW;
         dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
         dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
         dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
     }
     // ---- projection path (backward.cu:367-387) ----
     {
-        const float* proj = cm.proj;
+        const float* proj = cam_at(cams, cam_off) + CAM_PROJ;
         const float4 m_hom = xform44(mean, proj);
         const float m_w = 1.0f / (m_hom.w + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
@@ -237,19 +245,22 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
     }
     // ---- view-direction term of the SH path (backward.cu:130-138; auxiliary.h:107-117 dnormvdv) ----
     {
+        const float* cp = cam_at(cams, cam_off) + CAM_POS;
+        const float dox = mean.x - cp[0], doy = mean.y - cp[1], doz = mean.z - cp[2];
         const float sum2 = dox * dox + doy * doy + doz * doz;
         const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
         dmean[0] += ((+sum2 - dox * dox) * dd0 - doy * dox * dd1 - doz * dox * dd2) * invsum32;
         dmean[1] += (-dox * doy * dd0 + (sum2 - doy * doy) * dd1 - doz * doy * dd2) * invsum32;
         dmean[2] += (-dox * doz * dd0 - doy * doz * dd1 + (sum2 - doz * doz) * dd2) * invsum32;
     }
-    acc[0] += dmean[0]; acc[1] += dmean[1]; acc[2] += dmean[2];
-    acc[10] += raw_opacity ? part[8] * ((1.0f - o) * o) : part[8];
+    out[0] = dmean[0]; out[1] = dmean[1]; out[2] = dmean[2];
+    out[10] = raw_opacity ? part[8] * ((1.0f - o) * o) : part[8];
     // ---- cov3D -> scale, quaternion (backward.cu:278-341) ----
     {
         const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
         const Rot3 R = quat_to_rot(q);
-        const float s[3] = {cm.scale_modifier * sc.x, cm.scale_modifier * sc.y, cm.scale_modifier * sc.z};
+        const float scale_mod2 = cam_at(cams, cam_off)[CAM_SCALE];
+        const float s[3] = {scale_mod2 * sc.x, scale_mod2 * sc.y, scale_mod2 * sc.z};
         float Mm[3][3];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
@@ -285,20 +296,20 @@ __device__ __forceinline__ void combine_one_view(const CmbCam& cm, const float3 
             dq[0] = (dq[0] - yn.x * d) * inv; dq[1] = (dq[1] - yn.y * d) * inv;
             dq[2] = (dq[2] - yn.z * d) * inv; dq[3] = (dq[3] - yn.w * d) * inv;
         }
-        acc[3] += ds[0]; acc[4] += ds[1]; acc[5] += ds[2];
-        acc[6] += dq[0]; acc[7] += dq[1]; acc[8] += dq[2]; acc[9] += dq[3];
+        out[3] = ds[0]; out[4] = ds[1]; out[5] = ds[2];
+        out[6] = dq[0]; out[7] = dq[1]; out[8] = dq[2]; out[9] = dq[3];
     }
 }
 
 // The exchange's verdict for the host (pinned memory, polled): word 0 = any packet overflowed / does not describe this range,
 // words 1 .. n_views = the rows each view wanted -- every one a 64-bit (sequence number << 32 | value) stored at once, so the
 // host knows a word is this pass's by its tag and no fence is needed (a system-scope release here writes the L2's dirty
-// lines back first: the one-thread kernel took 60 - 160 us behind a backward).  Its own launch in front of the passes: the host
-// learns the verdict as early as it can be known, and the passes keep their scalar loads.
-__global__ void combine_verdict_kernel(unsigned long long* __restrict__ status, uint32_t seq, const uint32_t* __restrict__ packets,
-                                       size_t packet_stride_words, int n_views, int first, int n)
+// lines back first: a one-thread kernel doing that took 60 - 160 us behind a backward).  Posted by the first wave of the
+// combine pass's first workgroup as it starts: the host learns the verdict while the pass runs.
+__device__ __forceinline__ void post_verdict(unsigned long long* __restrict__ status, uint32_t seq, const uint32_t* __restrict__ packets,
+                                             size_t packet_stride_words, int n_views, int first, int n, int lane)
 {
-    const int v = threadIdx.x;
+    const int v = lane;
     uint32_t bad = 0;
     if (v < n_views) {
         const uint32_t* h = packets + (size_t)v * packet_stride_words;
@@ -310,269 +321,276 @@ __global__ void combine_verdict_kernel(unsigned long long* __restrict__ status, 
     if (v == 0) __hip_atomic_store(&status[0], ((unsigned long long)seq << 32) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// The dense part in three launches over a scratch of 48 bytes per packed row (n_views x capacity_rows rows):
-//   combine_index_kernel   one lane per Gaussian, its views in a wave-uniform loop: gidx[v][row] <- the Gaussian of row `row` of
-//                          view v (the packets give Gaussian -> row; the chain wants row -> Gaussian);
-//   combine_chain_kernel   grid (views, rows / 256): ONE LANE PER PACKED ROW -- every lane busy, the view uniform per workgroup
-//                          (its camera in scalar registers), every load of a pair in flight at once, no barrier anywhere;
-//                          the pair's eleven terms go to stage[v][row];
-//   combine_sum_kernel     one lane per Gaussian: the staged terms of its views added IN VIEW ORDER, every row written once
-//                          (zeros where no view has a row).
+// ONE launch: a workgroup of 256 threads takes a TILE of B blocks of 64 Gaussians.  B is chosen by the host from the number of
+// views so that a tile holds a few hundred (Gaussian, view) PAIRS at C3's density (one Gaussian in eight has a row per view):
+// B = 3 for eight views (192 +- 21 pairs: one balanced pass of the four waves), 24 for a single view.
+//   set-up    the views' cameras, mask words and row offsets of the tile's blocks -> LDS; per Gaussian the views it has a row in
+//             (one bit each) and an exclusive prefix of the pair counts over the tile: the pairs are ordered by (Gaussian, view);
+//   pairs     in passes of at most 256, dealt evenly to as few of the four waves as hold them, ONE LANE PER PAIR: its packed
+//             row (48 bytes), the Gaussian's parameters, the view's camera read from LDS by the lane; the per-Gaussian chain of
+//             phase 2 (combine_one_view) and the sixteen SH basis weights of the view's direction -> 30 floats per pair in LDS;
+//   sums      dense part: one thread per Gaussian adds the eleven terms of its pairs IN VIEW ORDER; SH part in the OUTPUT's
+//             mapping: thread t < 252 owns float4 t % 12 of the SH rows of Gaussians t / 12 + 21 k = four consecutive
+//             (coefficient, channel) products, and adds, for each pair of that Gaussian in view order, weight x dRGB read
+//             from the staged pair (a wave covers 5.3 Gaussians: the view loop runs to THEIR longest list, ~2.5 steps, not
+//             to the wave's eight; which operands a thread reads of a pair is fixed by t % 12 for the whole tile);
+//   stores    every row once, in the pass that holds its Gaussian's last pair (the first pass for a Gaussian without pairs:
+//             zeros -- or, row_live, nothing but the byte): the SH rows as contiguous non-temporal float4 streams straight from
+//             the accumulators (no LDS transpose: the mapping is the output's), the dense rows by their Gaussian's thread.
+//             Only a Gaussian whose pairs straddle two passes (at most one per pass boundary) leaves a partial sum in its
+//             output row and reads it back in the next pass (the same threads; L2) -- so no accumulator lives across the pair
+//             phase: 128 vector registers, four waves per SIMD.  No staging through HBM, no row -> Gaussian index pass.
 // Forms of round 6 that were measured and replaced (eight C3 views, 3 M Gaussians, 3 M pairs): one lane per Gaussian walking
-// its views, accumulators in registers -- 27 % busy lanes: 0.76 ms; tiles of 1024 / 512 Gaussians with the views in an outer
-// loop and the sums in LDS -- dense lanes, but a tile's eight view steps are a chain of barriers with one or two waves at
-// work: 0.41 / 0.44 ms.
-#define CMB_ACC 11
-#define CMB_STAGE 12                    // floats per staged row (48 bytes: three aligned float4)
+// its views with 59 accumulators -- 27 % busy lanes: 0.76 ms; tiles of 1024 / 512 Gaussians with the views in an outer loop and
+// the sums in LDS -- a chain of barriers with one or two waves at work: 0.41 / 0.44 ms; four launches (row -> Gaussian index
+// 0.037, one lane per packed row with the camera in scalar registers and the terms staged in HBM 0.146, ordered sum 0.089, SH
+// rows with one lane per Gaussian and a wave-uniform view loop at one busy lane in eight 0.191): 0.476 ms.  This form: 0.256.
+#define CT_PC 256
+#define CT_STRIDE 31                  // 11 chain terms, 16 basis weights, 3 dRGB; odd: lane-consecutive pairs hit different banks
+#define CT_SH_THREADS 252             // 21 Gaussians x 12 float4 of their SH rows per step of the SH sums
+#define CT_W 11                       // first basis weight in a staged pair
+#define CT_RGB 27                     // first dRGB component
+// RAW: some parameter arrives in its raw form (the activations and their Jacobians cost 50 vector registers: the plain
+// instantiation keeps four waves per SIMD)
+template <int B, bool RAW>
 __global__ void __launch_bounds__(256)
-combine_index_kernel(int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
-                     uint32_t* __restrict__ gidx)
+combine_tile_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
+                    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+                    const float* __restrict__ opacities, RawInputs raw_in, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale,
+                    float* __restrict__ dL_drot, float* __restrict__ dL_dopacity, float* __restrict__ dL_dsh,
+                    unsigned char* __restrict__ row_live, unsigned long long* __restrict__ status, uint32_t seq)
 {
-    const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= (int)sum_packet_blocks((size_t)n)) return;
-    const size_t bases_w = sum_packet_bases_word((size_t)n);
-    for (int v = 0; v < n_views; v++) {
-        const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-        const unsigned long long m = reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk];
-        if (!((m >> lane) & 1ull)) continue;
-        const uint32_t row = (pk + bases_w)[blk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (row < capacity) gidx[(size_t)v * capacity + row] = (uint32_t)(blk * 64 + lane);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-combine_chain_kernel(int first, int n, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
-                     const uint32_t* __restrict__ gidx, float* __restrict__ stage,
-                     const float* __restrict__ means3D, const float* __restrict__ scales,
-                     const float* __restrict__ rotations, const float* __restrict__ opacities, RawInputs raw)
-{
-    // the VIEW is the fast grid dimension: the workgroups of one row block in all views are dispatched together, and row block k
-    // of every view covers about the same Gaussians (the rows are index-ordered, the views' densities alike) -- their
-    // parameter lines and SH rows are then found in the L2 by all but the first view
-    const int v = blockIdx.x;
-    const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-    const uint32_t rows = min((uint32_t)__builtin_amdgcn_readfirstlane((int)pk[1]), capacity);
-    if (blockIdx.y * 256u >= rows) return;                    // workgroup-uniform
-    CmbCam cm;
-    load_cam(pk, cm);
-    const uint32_t row = blockIdx.y * 256u + threadIdx.x;
-    if (row >= rows) return;
-    const int idx = first + (int)gidx[(size_t)v * capacity + row];
-    const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(pk) + sum_packet_rows_word((size_t)n) + (size_t)row * FRG_SUM_ROW_FLOATS);
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-    float part[FRG_SLOT_FLOATS] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-    const float3 mean = param_mean(means3D, raw, idx);
-    const float3 sc = param_scale(scales, raw, idx);
-    const float4 q = param_rot(rotations, raw, idx);
-    const float o = param_opacity(opacities, raw, idx);
-    float4 q_raw = q;
-    if (raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
-    float out[CMB_ACC];
-#pragma unroll
-    for (int k = 0; k < CMB_ACC; k++) out[k] = 0.0f;
-    combine_one_view(cm, mean, sc, q, o, raw.raw_opacity != nullptr, raw.raw_scale != nullptr, raw.raw_rot != nullptr, q_raw,
-                     part, r2.y, r2.z, r2.w, out);
-    float4* dst = reinterpret_cast<float4*>(stage + ((size_t)v * capacity + row) * CMB_STAGE);
-    dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-    dst[1] = make_float4(out[4], out[5], out[6], out[7]);
-    dst[2] = make_float4(out[8], out[9], out[10], 0.0f);
-}
-
-// The two gather passes, one lane per Gaussian each, over the views in which it has a row, IN VIEW ORDER:
-//   combine_sum_kernel   the 11 dense sums: the terms the chain pass staged for (view, row), added one after the other;
-//   combine_sh_kernel    dL_dsh: basis(dir_v) (x) dRGB_v, 48 products per view added into 48 accumulators; the 192-byte rows
-//                        leave through a wave-private LDS transpose as contiguous float4 streams (view_exchange.hip's idiom);
-// every row of the five outputs written once, zeros where no view has a row (with row_live: those are skipped and the byte
-// says so).  The view loops are wave-uniform (mask word, row base and camera centre are uniform loads), in groups of four
-// views whose look-ups are requested together.  (As ONE kernel the 59 accumulators and the staged rows of a group took 180
-// VGPRs, two waves per SIMD: 0.36 ms for eight C3 views against 0.10 + 0.19 of the two.)
-__global__ void __launch_bounds__(256)
-combine_sum_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
-                   const float* __restrict__ stage, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dscale,
-                   float* __restrict__ dL_drot, float* __restrict__ dL_dopacity, unsigned char* __restrict__ row_live)
-{
-    const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= (int)sum_packet_blocks((size_t)n)) return;
-    const int g = blk * 64 + lane;
-    const size_t bases_w = sum_packet_bases_word((size_t)n);
-    float a[CMB_ACC];
-#pragma unroll
-    for (int k = 0; k < CMB_ACC; k++) a[k] = 0.0f;
-    bool live = false;
-#pragma unroll 1
-    for (int v0 = 0; v0 < n_views; v0 += 4) {
-        unsigned long long m[4];
-        uint32_t base[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = min(v0 + u, n_views - 1);
-            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-            m[u] = v0 + u < n_views ? reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk] : 0ull;
-            base[u] = (pk + bases_w)[blk];
-        }
-        float4 st[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = min(v0 + u, n_views - 1);
-            const bool bit = ((m[u] >> lane) & 1ull) != 0ull;
-            live |= bit;
-            const uint32_t row = base[u] + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
-            st[u][0] = st[u][1] = st[u][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            m[u] = (bit && row < capacity) ? 1ull : 0ull;
-            if (m[u]) {
-                const float4* sp = reinterpret_cast<const float4*>(stage + ((size_t)v * capacity + row) * CMB_STAGE);
-                st[u][0] = sp[0]; st[u][1] = sp[1]; st[u][2] = sp[2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {                          // view order
-            if (m[u]) {
-                a[0] += st[u][0].x; a[1] += st[u][0].y; a[2] += st[u][0].z; a[3] += st[u][0].w;
-                a[4] += st[u][1].x; a[5] += st[u][1].y; a[6] += st[u][1].z; a[7] += st[u][1].w;
-                a[8] += st[u][2].x; a[9] += st[u][2].y; a[10] += st[u][2].z;
-            }
-        }
-    }
-    if (g >= n) return;
-    const size_t gi = (size_t)first + g;
-    if (row_live) { row_live[gi] = live ? 1 : 0; if (!live) return; }
-    dL_dmean3D[3 * gi] = a[0]; dL_dmean3D[3 * gi + 1] = a[1]; dL_dmean3D[3 * gi + 2] = a[2];
-    dL_dscale[3 * gi] = a[3]; dL_dscale[3 * gi + 1] = a[4]; dL_dscale[3 * gi + 2] = a[5];
-    *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(a[6], a[7], a[8], a[9]);
-    dL_dopacity[gi] = a[10];
-}
-
-#define CSH_SUB 16
-#define CSH_ROW_F4 13
-__global__ void __launch_bounds__(256)
-combine_sh_kernel(int first, int n, int n_views, const uint32_t* __restrict__ packets, size_t packet_stride_words, uint32_t capacity,
-                  const float* __restrict__ means3D, RawInputs raw, float* __restrict__ dL_dsh, const unsigned char* __restrict__ row_live)
-{
-    __shared__ __attribute__((aligned(16))) float4 lds_all[4 * CSH_SUB * CSH_ROW_F4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4* shbuf = lds_all + wave * CSH_SUB * CSH_ROW_F4;
-    const int blk = blockIdx.x * 4 + wave, g0 = blk * 64;
-    if (g0 >= n) return;
-    const int g = g0 + lane, idx = first + g;
-    const bool valid = g < n;
+    constexpr int G = 64 * B, GI = (G + 255) / 256;        // Gaussians of a tile; per thread
+    static_assert(G <= 2048, "a pair is (Gaussian of the tile: 11 bits, view: 4 bits)");
+    __shared__ float s_stage[CT_PC * CT_STRIDE];
+    __shared__ float s_cam[CMB_MAX_VIEWS * CAM_STRIDE];
+    __shared__ unsigned long long s_mask[CMB_MAX_VIEWS * B];
+    __shared__ uint32_t s_base[CMB_MAX_VIEWS * B];
+    __shared__ uint32_t s_start[G + 1];                    // exclusive prefix of the pair counts
+    __shared__ uint16_t s_views[G];                        // the views a Gaussian has a row in
+    __shared__ uint16_t s_pair[CT_PC];
+    __shared__ uint32_t s_wtot[4];
+    const RawInputs raw = RAW ? raw_in : RawInputs{};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (int)sum_packet_blocks((size_t)n), blk0 = blockIdx.x * B, g0 = blk0 * 64;
     const size_t bases_w = sum_packet_bases_word((size_t)n), rows_w = sum_packet_rows_word((size_t)n);
-    float out[48];
-#pragma unroll
-    for (int i = 0; i < 48; i++) out[i] = 0.0f;
-    float3 mean = make_float3(0.f, 0.f, 0.f);
-    if (valid) mean = param_mean(means3D, raw, idx);
-    unsigned long long any = 0ull;
-#pragma unroll 1
-    for (int v0 = 0; v0 < n_views; v0 += 4) {
-        unsigned long long m[4];
-        uint32_t base[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = min(v0 + u, n_views - 1);
-            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-            m[u] = v0 + u < n_views ? reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk] : 0ull;
-            base[u] = (pk + bases_w)[blk];
-        }
-        float dr[4][3];
-        bool has[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = min(v0 + u, n_views - 1);
-            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-            any |= m[u];
-            const uint32_t row = base[u] + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
-            has[u] = ((m[u] >> lane) & 1ull) && row < capacity;
-            dr[u][0] = dr[u][1] = dr[u][2] = 0.0f;
-            if (has[u]) {
-                const float* r = reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS;
-                dr[u][0] = r[0]; dr[u][1] = r[1]; dr[u][2] = r[2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!__builtin_amdgcn_ballot_w64(has[u])) continue;            // wave-uniform
-            const int v = min(v0 + u, n_views - 1);
-            const uint32_t* pk = packets + (size_t)v * packet_stride_words;
-            const int D = __builtin_amdgcn_readfirstlane((int)pk[48]);
-            const float cx = uniform_f(pk, 40), cy = uniform_f(pk, 41), cz = uniform_f(pk, 42);
-            if (has[u]) {
-                const float dRGB[3] = {dr[u][0], dr[u][1], dr[u][2]};
-                const float dox = mean.x - cx, doy = mean.y - cy, doz = mean.z - cz;
-                const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-                const float x = dox / len, y = doy / len, z = doz / len;
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                float wgt[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
-                wgt[0] = kSH0;
-                if (D > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
-                if (D > 1) {
-                    wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
-                    wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
-                }
-                if (D > 2) {
-                    wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
-                    wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                    wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
-                    wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
-                }
-#pragma unroll
-                for (int i = 0; i < 48; i++) out[i] += wgt[i / 3] * dRGB[i % 3];
-            }
-        }
+    if (status && blockIdx.x == 0 && wave == 0) post_verdict(status, seq, packets, packet_stride_words, n_views, first, n, lane);
+    // ---- set-up ----
+    for (int v = wave; v < n_views; v += 4)
+        if (lane < CAM_WORDS) s_cam[v * CAM_STRIDE + lane] = __uint_as_float(packets[(size_t)v * packet_stride_words + 8 + lane]);
+    for (int i = tid; i < n_views * B; i += 256) {
+        const int v = i / B, b = i - v * B, blk = blk0 + b;
+        const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+        s_mask[i] = blk < nblk ? reinterpret_cast<const unsigned long long*>(pk + FRG_SUM_HDR_WORDS)[blk] : 0ull;
+        s_base[i] = blk < nblk ? (pk + bases_w)[blk] : 0u;
     }
-    // SH rows to write: all of the block's -- or, with row_live, those of its Gaussians with a row somewhere
-    const unsigned long long wmask = row_live ? any : ~0ull;
-    float4* dst = reinterpret_cast<float4*>(dL_dsh) + ((size_t)first + g0) * 12;
-    const int nvalid = min(64, n - g0);
-#pragma unroll 1
-    for (int h = 0; h < 64 / CSH_SUB; h++) {
-        if (((wmask >> (h * CSH_SUB)) & ((1ull << CSH_SUB) - 1ull)) == 0ull) continue;
-        if ((lane / CSH_SUB) == h) {
+    __syncthreads();
+    uint32_t T = 0;
 #pragma unroll
-            for (int j = 0; j < 12; j++)
-                shbuf[(lane % CSH_SUB) * CSH_ROW_F4 + j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+    for (int it = 0; it < GI; it++) {
+        const int g = it * 256 + tid;
+        uint32_t views_of = 0;
+        if (g < G && g0 + g < n)
+            for (int v = 0; v < n_views; v++) views_of |= (uint32_t)((s_mask[v * B + (g >> 6)] >> lane) & 1ull) << v;
+        const uint32_t cnt = (uint32_t)__popc(views_of), incl = wave_incl_scan_dpp(cnt);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t t = s_wtot[w]; if (w < wave) before += t; tot += t; }
+        if (g < G) { s_start[g] = T + before + incl - cnt; s_views[g] = (uint16_t)views_of; }
+        T += tot;
+        if (it + 1 < GI) __syncthreads();
+    }
+    if (tid == 0) s_start[G] = T;
+    __syncthreads();
+
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    float4* const sh_dst = reinterpret_cast<float4*>(dL_dsh) + ((size_t)first + g0) * 12;
+    const int gmax = min(G, n - g0);                       // Gaussians of this tile
+    if (T == 0) {                                          // no view has a row in this tile: zeros (or, row_live, nothing but the bytes)
+        if (!row_live)
+            for (int f = tid; f < gmax * 12; f += 256) __builtin_nontemporal_store(nt_f4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<nt_f4*>(sh_dst + f));
+        for (int g = tid; g < gmax; g += 256) {
+            const size_t gi = (size_t)first + g0 + g;
+            if (row_live) { row_live[gi] = 0; continue; }
+            dL_dmean3D[3 * gi] = 0.f; dL_dmean3D[3 * gi + 1] = 0.f; dL_dmean3D[3 * gi + 2] = 0.f;
+            dL_dscale[3 * gi] = 0.f; dL_dscale[3 * gi + 1] = 0.f; dL_dscale[3 * gi + 2] = 0.f;
+            *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(0.f, 0.f, 0.f, 0.f);
+            dL_dopacity[gi] = 0.f;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int k = 0; k < CSH_SUB * 12 / 64; k++) {
-            const int f = k * 64 + lane, gl = f / 12, j = f - gl * 12;
-            if (h * CSH_SUB + gl < nvalid && ((wmask >> (h * CSH_SUB + gl)) & 1ull)) {
-                typedef float nt_f4 __attribute__((ext_vector_type(4)));
-                const float4 v4 = shbuf[gl * CSH_ROW_F4 + j];
-                __builtin_nontemporal_store(nt_f4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<nt_f4*>(dst + (size_t)h * CSH_SUB * 12 + f));
+        return;
+    }
+
+#pragma unroll 1
+    for (uint32_t p0 = 0; p0 < T; p0 += CT_PC) {
+        const uint32_t npass = min(T - p0, (uint32_t)CT_PC), p1 = p0 + npass;
+        const bool first_pass = p0 == 0;
+        // ---- the pass's pairs, ordered by (Gaussian, view) ----
+        for (int g = tid; g < gmax; g += 256) {
+            const uint32_t s0 = s_start[g];
+            uint32_t vs = s_views[g];
+            if (!vs || s0 >= p1 || s_start[g + 1] <= p0) continue;
+            uint32_t s = s0 - p0;                            // (unsigned: pairs before the pass compare as huge)
+            while (vs) {
+                const int v = __ffs((int)vs) - 1;
+                vs &= vs - 1;
+                if (s < (uint32_t)CT_PC) s_pair[s] = (uint16_t)(g | (v << 11));
+                s++;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __syncthreads();
+        // ---- one lane per pair ----
+        {
+            const uint32_t nw = (npass + 63) >> 6, q = (npass + nw - 1) / nw, sl = wave * q + lane;     // the fewest waves, evenly filled
+            if ((uint32_t)wave < nw && (uint32_t)lane < q && sl < npass) {
+                const uint32_t info = s_pair[sl];
+                const int gl = (int)(info & 2047u), v = (int)(info >> 11), b = gl >> 6, gln = gl & 63;
+                const unsigned long long m = s_mask[v * B + b];
+                const uint32_t row = s_base[v * B + b] + (uint32_t)__popcll(m & ((1ull << gln) - 1ull));
+                float* st = s_stage + sl * CT_STRIDE;
+                if (row < capacity) {
+                    const uint32_t* pk = packets + (size_t)v * packet_stride_words;
+                    const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(pk) + rows_w + (size_t)row * FRG_SUM_ROW_FLOATS);
+                    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                    const int idx = first + g0 + gl;
+                    const float3 mean = param_mean(means3D, raw, idx);
+                    const float3 sc = param_scale(scales, raw, idx);
+                    const float4 qt = param_rot(rotations, raw, idx);
+                    const float o = param_opacity(opacities, raw, idx);
+                    float4 q_raw = qt;
+                    if (RAW && raw.raw_rot) q_raw = make_float4(raw.raw_rot[4 * idx], raw.raw_rot[4 * idx + 1], raw.raw_rot[4 * idx + 2], raw.raw_rot[4 * idx + 3]);
+                    const float* cam = cam_at(s_cam, v * CAM_STRIDE);
+                    st[CT_RGB] = r0.x; st[CT_RGB + 1] = r0.y; st[CT_RGB + 2] = r0.z;
+                    {   // the SH basis of the view's direction (forward.cu:20-71 in weight form; view_exchange.hip's expressions)
+                        const int D = __float_as_int(cam[CAM_D]);
+                        const float dox = mean.x - cam[CAM_POS], doy = mean.y - cam[CAM_POS + 1], doz = mean.z - cam[CAM_POS + 2];
+                        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+                        const float x = dox / len, y = doy / len, z = doz / len;
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        float wgt[16];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) wgt[i] = 0.0f;
+                        wgt[0] = kSH0;
+                        if (D > 0) { wgt[1] = -kSH1 * y; wgt[2] = kSH1 * z; wgt[3] = -kSH1 * x; }
+                        if (D > 1) {
+                            wgt[4] = kSH2[0] * xy; wgt[5] = kSH2[1] * yz; wgt[6] = kSH2[2] * (2.f * zz - xx - yy);
+                            wgt[7] = kSH2[3] * xz; wgt[8] = kSH2[4] * (xx - yy);
+                        }
+                        if (D > 2) {
+                            wgt[9] = kSH3[0] * y * (3.f * xx - yy); wgt[10] = kSH3[1] * xy * z;
+                            wgt[11] = kSH3[2] * y * (4.f * zz - xx - yy); wgt[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                            wgt[13] = kSH3[4] * x * (4.f * zz - xx - yy); wgt[14] = kSH3[5] * z * (xx - yy);
+                            wgt[15] = kSH3[6] * x * (xx - 3.f * yy);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; i++) st[CT_W + i] = wgt[i];
+                    }
+                    float part[FRG_SLOT_FLOATS] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+                    float out[CMB_ACC];
+                    combine_one_view(s_cam, v * CAM_STRIDE, mean, sc, qt, o, RAW && raw.raw_opacity != nullptr, RAW && raw.raw_scale != nullptr,
+                                     RAW && raw.raw_rot != nullptr, q_raw,
+                                     part, r2.y, r2.z, r2.w, out);
+#pragma unroll
+                    for (int k = 0; k < CMB_ACC; k++) st[k] = out[k];
+                } else {                                   // beyond the packet's capacity (the verdict says so): contributes nothing
+#pragma unroll
+                    for (int k = 0; k < CT_STRIDE - 1; k++) st[k] = 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- ordered sums; a row leaves in the pass that holds its Gaussian's last pair ----
+        for (int g = tid; g < gmax; g += 256) {
+            const uint32_t s0 = s_start[g], s1 = s_start[g + 1];
+            const size_t gi = (size_t)first + g0 + g;
+            if (first_pass && row_live) row_live[gi] = s1 > s0 ? 1 : 0;
+            const uint32_t lo = max(s0, p0), hi = min(s1, p1);
+            if (s0 == s1 ? !(first_pass && !row_live) : lo >= hi) continue;
+            float acc[CMB_ACC];
+#pragma unroll
+            for (int k = 0; k < CMB_ACC; k++) acc[k] = 0.0f;
+            if (s0 < p0 && s0 != s1) {                     // pairs in an earlier pass: the partial sums are in the row
+                acc[0] = dL_dmean3D[3 * gi]; acc[1] = dL_dmean3D[3 * gi + 1]; acc[2] = dL_dmean3D[3 * gi + 2];
+                acc[3] = dL_dscale[3 * gi]; acc[4] = dL_dscale[3 * gi + 1]; acc[5] = dL_dscale[3 * gi + 2];
+                const float4 rq = *reinterpret_cast<const float4*>(dL_drot + 4 * gi);
+                acc[6] = rq.x; acc[7] = rq.y; acc[8] = rq.z; acc[9] = rq.w;
+                acc[10] = dL_dopacity[gi];
+            }
+            for (uint32_t s = lo; s < hi; s++) {
+                const float* st = s_stage + (s - p0) * CT_STRIDE;
+#pragma unroll
+                for (int k = 0; k < CMB_ACC; k++) acc[k] += st[k];
+            }
+            dL_dmean3D[3 * gi] = acc[0]; dL_dmean3D[3 * gi + 1] = acc[1]; dL_dmean3D[3 * gi + 2] = acc[2];
+            dL_dscale[3 * gi] = acc[3]; dL_dscale[3 * gi + 1] = acc[4]; dL_dscale[3 * gi + 2] = acc[5];
+            *reinterpret_cast<float4*>(dL_drot + 4 * gi) = make_float4(acc[6], acc[7], acc[8], acc[9]);
+            dL_dopacity[gi] = acc[10];
+        }
+        if (tid < CT_SH_THREADS) {
+            // thread t: float4 j = t % 12 of the rows of Gaussians t / 12 + 21 k -- elements i = 4 j + e (e < 4): coefficient i / 3,
+            // channel i % 3; the staged pair's offsets of the four (weight, dRGB) operands are the thread's own for the whole tile
+            int tc = tid;
+            asm volatile("" : "+v"(tc));                   // (opaque: formed per pass, not held across the pair phase)
+            const int tg = tc / 12, j = tc - 12 * tg, c0 = (4 * j) / 3, r = j - 3 * (j / 3);
+            int wo[4], co[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int t = r + e; wo[e] = CT_W + c0 + (t >= 3 ? 1 : 0); co[e] = CT_RGB + (t >= 3 ? t - 3 : t); }
+#pragma unroll 1
+            for (int gl = tg; gl < gmax; gl += CT_SH_THREADS / 12) {
+                const uint32_t s0 = s_start[gl], s1 = s_start[gl + 1];
+                const uint32_t lo = max(s0, p0), hi = min(s1, p1);
+                if (s0 == s1 ? !(first_pass && !row_live) : lo >= hi) continue;      // not this pass's / nothing to write
+                const int f = gl * 12 + j;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s0 < p0 && s0 != s1) acc = sh_dst[f];
+                for (uint32_t s = lo; s < hi; s++) {
+                    const float* st = s_stage + (s - p0) * CT_STRIDE;
+                    acc.x += st[wo[0]] * st[co[0]];
+                    acc.y += st[wo[1]] * st[co[1]];
+                    acc.z += st[wo[2]] * st[co[2]];
+                    acc.w += st[wo[3]] * st[co[3]];
+                }
+                if (s1 <= p1) __builtin_nontemporal_store(nt_f4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<nt_f4*>(sh_dst + f));
+                else sh_dst[f] = acc;
+            }
+        }
+        if (p1 < T) __syncthreads();
     }
 }
 
 size_t combine_workspace_bytes(int n_views, size_t capacity)
 {
-    const size_t rows = (size_t)(n_views > 0 ? n_views : 1) * (capacity > 0 ? capacity : 1);
-    return align_up(rows * 4, 256) + align_up(rows * CMB_STAGE * 4, 256);
+    (void)n_views; (void)capacity;
+    return 256;                 // the pass stages nothing in HBM any more; the argument stays in the ABI
+}
+
+int g_combine_blocks = 0;       // tuning (frg_set_option("combine_blocks")): blocks of 64 Gaussians per tile, 0 = by the number of views
+
+template <bool RAW>
+static void launch_tile(int B, int nblk, hipStream_t s, int first, int n, int n_views, const uint32_t* pk, size_t stride_w, uint32_t capacity,
+                        const FwdInputs& in, const BwdOutputs& out, unsigned char* row_live, unsigned long long* status, uint32_t seq)
+{
+#define FRG_TILE_LAUNCH(BB) hipLaunchKernelGGL((combine_tile_kernel<BB, RAW>), dim3((nblk + BB - 1) / BB), dim3(256), 0, s, first, n, n_views, pk, stride_w, \
+        capacity, in.means3D, in.scales, in.rotations, in.opacities, in.raw, out.dL_dmean3D, out.dL_dscale, out.dL_drot, out.dL_dopacity, out.dL_dsh,       \
+        row_live, status, seq)
+    if (B >= 24) FRG_TILE_LAUNCH(24); else if (B >= 12) FRG_TILE_LAUNCH(12); else if (B >= 6) FRG_TILE_LAUNCH(6); else FRG_TILE_LAUNCH(3);
+#undef FRG_TILE_LAUNCH
 }
 
 hipError_t launch_backward_combine(int first, int n, int n_views, const void* packets, size_t packet_stride_bytes, uint32_t capacity,
                                    const FwdInputs& in, const BwdOutputs& out, unsigned long long* status, uint32_t seq, unsigned char* row_live,
                                    char* workspace, hipStream_t s)
 {
+    (void)workspace;
     const uint32_t* pk = reinterpret_cast<const uint32_t*>(packets);
     const size_t stride_w = packet_stride_bytes / 4;
     const int nblk = (int)sum_packet_blocks((size_t)n);
-    const size_t rows = (size_t)n_views * (capacity > 0 ? capacity : 1);
-    uint32_t* gidx = reinterpret_cast<uint32_t*>(workspace);
-    float* stage = reinterpret_cast<float*>(workspace + align_up(rows * 4, 256));
-    if (status) hipLaunchKernelGGL(combine_verdict_kernel, dim3(1), dim3(64), 0, s, status, seq, pk, stride_w, n_views, first, n);
-    hipLaunchKernelGGL(combine_index_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, n, n_views, pk, stride_w, capacity, gidx);
-    if (capacity > 0)
-        hipLaunchKernelGGL(combine_chain_kernel, dim3(n_views, (capacity + 255) / 256), dim3(256), 0, s, first, n, pk, stride_w, capacity, gidx, stage,
-                           in.means3D, in.scales, in.rotations, in.opacities, in.raw);
-    hipLaunchKernelGGL(combine_sum_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, first, n, n_views, pk, stride_w, capacity, stage,
-                       out.dL_dmean3D, out.dL_dscale, out.dL_drot, out.dL_dopacity, row_live);
-    // (row_live is written by the sum pass; the SH pass derives the same bits from the masks themselves)
-    hipLaunchKernelGGL(combine_sh_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, first, n, n_views, pk, stride_w, capacity, in.means3D, in.raw,
-                       out.dL_dsh, row_live);
+    // a tile of a few hundred pairs where one Gaussian in eight has a row per view (C3); any density is handled (more passes)
+    const int B = g_combine_blocks > 0 ? g_combine_blocks : n_views >= 6 ? 3 : n_views >= 3 ? 6 : n_views == 2 ? 12 : 24;
+    const bool raw = in.raw.raw_opacity || in.raw.raw_scale || in.raw.raw_rot;
+    if (raw) launch_tile<true>(B, nblk, s, first, n, n_views, pk, stride_w, capacity, in, out, row_live, status, seq);
+    else launch_tile<false>(B, nblk, s, first, n, n_views, pk, stride_w, capacity, in, out, row_live, status, seq);
     return hipGetLastError();
 }
 

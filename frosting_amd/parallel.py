@@ -87,10 +87,19 @@ XGMI_LINKS = 7                 # one node: every MI355X talks to each of the oth
 XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task statement and SURVEY 8(e) give)
 
 
+# The slot-sum plan's local terms at C3 (3 M Gaussians, 0.127 P rows per view), measured on ONE MI355X with HIP events
+# (tools/combine_bench.py: profiles/r06_combine_bench.log): pack = mask scan + rows; combine_ms[N] = frg_backward_combine over
+# N views' packets in one chunk; per_chunk_ms = what every further chunk adds (launch + tail); phase2_ms = one-call backward -
+# phase 1.  overlap_slowdown and slack are assumptions / settings, not measurements.
+SLOTSUM_LOCAL_MS = {"pack_ms": 0.036, "pack_per_chunk_ms": 0.005, "combine_ms": {1: 0.172, 2: 0.190, 4: 0.210, 8: 0.293},
+                    "per_chunk_ms": 0.011, "phase2_ms": 0.115, "overlap_slowdown": 1.15, "slack": 1.125}
+
+
 def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "factored", reduce: str = "allreduce",
                      schedule: str = "in-step", link_efficiency: float = 0.8, rebuild_ms_per_view: float = 0.019,
                      split_overhead_ms: float = 0.08, per_gaussian_bwd_ms: float = 0.29, bus_GBps: float = None,
-                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0, adam_ms: float = 0.8):
+                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0, adam_ms: float = 0.8, chunks: int = 4,
+                     slotsum_local: dict = None):
     """Predicted step time and scaling of the view-parallel step on ONE node of `world` MI355X: arithmetic, not a
     measurement (no 8-GPU run is available to this repository; bench.py prints it as `predicted`).
 
@@ -111,6 +120,15 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
     (rebuild_ms_per_view x N, measured 0.15 ms at 8 views) runs beside the dense sum; "sync" hides nothing.  Sparse plan
     (one-call backward, nothing hidden but the zero fills, which run under the wire): pack (one read of the 56 P bytes) +
     the host's wait for the counts and its serial section behind it (0.16 ms, measured on one rank) + the row all-gather + one scatter launch per view + the SH rebuild.
+    Slot-sum plan (round 6, plan="slotsum"): per rank and step one all-gather per chunk of fixed-capacity packets -- 48-byte rows
+    for rows_fraction x P x slack Gaussians, one bit per Gaussian, one word per 64 -- and LOCAL terms that were measured on one
+    MI355X (slotsum_local, defaults = SLOTSUM_LOCAL_MS: tools/combine_bench.py, profiles/r06_combine_bench.log): pack_ms, the
+    combine pass over `world` views' packets (combine_ms[world], total over the chunks), and phase2_ms = what the per-view
+    backward no longer does (the per-Gaussian chain and the dense rows of ONE view: one-call backward - phase 1).  The chunks
+    pipeline: chunk k's combine pass runs while chunk k + 1 is on the wire, so gather + combine complete after
+    W + c (c = one chunk's pass, when c <= w = one chunk's wire time) or w + C (combine-bound); the pass is priced
+    overlap_slowdown x its stand-alone time while collectives run beside it (RCCL's kernels hold some CUs: an assumption,
+    1.15).  exposed = pack + that - phase2.
     link_efficiency: achieved / nominal link rate.  Returns a dict."""
     rate = XGMI_LINK_GBPS * 1e9 * link_efficiency
     links = max(1, min(world - 1, XGMI_LINKS))
@@ -138,8 +156,31 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
         zero_ms = 1e3 * (44.0 * P + 12.0 * P * world) / (hbm_GBps * 1e9)      # the dense part and the dense dRGB of every view
         # one scatter launch per view: 0.047 ms for the 372 000 rows of a C3 view (rocprofv3, profiles/r05_trace_c3_sparse_exchange.log)
         scatter_ms = world * 0.047 * rows / 372000.0
+    slot = None
+    if plan == "slotsum" and world > 1:
+        loc = dict(SLOTSUM_LOCAL_MS)
+        loc.update(slotsum_local or {})
+        K = max(1, int(chunks))
+        cap = min(P, (int(rows_fraction * P * loc["slack"]) // 256 + 1) * 256)
+        packet_bytes = 4.0 * sum_packet_words(P, cap) + 256.0 * (K - 1)
+        wire = 1e3 * (packet_bytes * (world - 1) / bus if bus else packet_bytes / rate)
+        table = loc["combine_ms"]                               # {views: ms of one pass over everything}, interpolated
+        ks = sorted(table)
+        lo_k = max([k for k in ks if k <= world] or ks[:1]); hi_k = min([k for k in ks if k >= world] or ks[-1:])
+        c_all = table[lo_k] if hi_k == lo_k else table[lo_k] + (table[hi_k] - table[lo_k]) * (world - lo_k) / (hi_k - lo_k)
+        c_all = (c_all + loc["per_chunk_ms"] * (K - 1)) * loc["overlap_slowdown"]
+        w1, c1 = wire / K, c_all / K
+        done = wire + c1 if c1 <= w1 else w1 + c_all
+        pack = loc["pack_ms"] + loc["pack_per_chunk_ms"] * (K - 1)
+        slot = {"chunks": K, "capacity_rows": cap, "packet_MB": packet_bytes / 1e6, "wire_ms": wire, "combine_ms": c_all, "pack_ms": pack,
+                "phase2_saved_ms": loc["phase2_ms"], "gather_and_combine_ms": done, "bound": "wire" if c1 <= w1 else "combine",
+                "local_terms": loc}
+        dense_ms = gather_ms = rebuild_ms = 0.0
+        dense_bytes = 0
     if world == 1:
         exposed = 0.0
+    elif slot is not None:
+        exposed = slot["pack_ms"] + slot["gather_and_combine_ms"] - slot["phase2_saved_ms"]
     elif sparse:
         exposed = pack_ms + counts_ms + max(rows_ms, zero_ms) + scatter_ms + rebuild_ms
     elif not factored:
@@ -155,6 +196,8 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
            "scaling_vs_1gpu": world * render_ms / step, "link_GBps": XGMI_LINK_GBPS, "link_efficiency": link_efficiency,
            "bus_GBps": bus_GBps,
            "note": "arithmetic from bytes and the nominal xGMI link rate (or the given bus bandwidth), not a measurement"}
+    if slot is not None:
+        out["slotsum"] = slot
     if sparse:
         out.update(rows_per_rank=rows, rows_MB_in=4.0 * ROW_FLOATS * rows * max(world - 1, 0) / 1e6, rows_wire_ms=rows_ms,
                    pack_ms=pack_ms, counts_wait_ms=counts_ms, zero_fill_ms=zero_ms, scatter_ms=scatter_ms)
@@ -463,7 +506,7 @@ class GradientExchange:
 # ---- slot-sum exchange (round 6) ---------------------------------------------------------------------------------------------
 SUM_HDR_WORDS = 64      # frosting_amd/csrc/slot_exchange.hip: the packet's header ...
 SUM_ROW_FLOATS = 12     # ... and its rows {masked dRGB[3], six pixel moments, three view-direction terms}
-SUM_TILE = 1024         # chunk boundaries fall on the combine pass's tiles
+SUM_TILE = 1536         # chunk boundaries fall on whole tiles of the combine pass, whichever tile size it picks (3 .. 24 blocks of 64)
 
 
 def sum_packet_words(n: int, capacity: int) -> int:
@@ -517,7 +560,7 @@ def _hip_sum_combiner(ex: "SlotSumExchange", chunk: int, packets: torch.Tensor, 
 
 class SlotSumExchange(GradientExchange):
     """The exchange plan of round 6: ranks all-gather the nine per-Gaussian SLOT SUMS of their view's backward (phase 1) for
-    the Gaussians that have any -- 36-byte rows in index order behind a bit mask, a fixed-capacity packet per chunk of
+    the Gaussians that have any -- 48-byte rows {masked dRGB, six moments, three view-direction terms} in index order behind a bit mask, a fixed-capacity packet per chunk of
     Gaussians -- and every rank runs the per-Gaussian chain (phase 2) for EVERY view's rows itself, in view order, in one pass
     that writes each of the 59 gradient floats of a Gaussian once (csrc/slot_exchange.hip).  Bit-identical to accumulating the
     per-view gradients in one process.  Against the factored plan: a quarter of the wire bytes, no dense zero fills, no
@@ -563,7 +606,7 @@ class SlotSumExchange(GradientExchange):
         self.params = None
         self.stats = {"rows_wanted_max": 0, "repacks": 0, "packet_bytes": 0}
         self._no_post = False
-        self.combine_work = None      # the combine pass's scratch (48 bytes per packed row), grown on demand
+        self.combine_work = None      # the combine pass's scratch (256 bytes since the pass is one kernel; the ABI keeps the argument)
 
     def set_params(self, params: dict):
         """The replicated parameters the combine pass reads: {'means3D','shs','scales','rotations','opacities'} (raw forms

@@ -417,7 +417,7 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
  *   frg_pack_sum_rows     (after phase 1, same P / R / workspace; drgb_masked = the dL_dcolor that call wrote with shs given
  *                         and dL_dsh == NULL) writes the packet of Gaussians [first, first + count), first a multiple of 64:
  *                         a 256-byte header (rows wanted / packed, the camera), one bit per Gaussian, one row offset per 64
- *                         Gaussians, and the 36-byte rows {dRGB[3], moments[6]} of the marked Gaussians IN INDEX ORDER, at
+ *                         Gaussians, and the 48-byte rows {dRGB[3], moments[6], view-direction terms[3]} of the marked Gaussians IN INDEX ORDER, at
  *                         most capacity_rows of them.  Fixed size frg_sum_packet_bytes(count, capacity_rows): it can be
  *                         all-gathered without any host knowing a count.  Header word 1 > capacity_rows: overflow, the
  *                         packet is incomplete (pack again with a larger capacity; the workspace is untouched).
@@ -432,8 +432,8 @@ int frg_scatter_grad_rows(long long n_rows, int P, const float* rows, float* dL_
  *                         status (optional; device or pinned host memory, 1 + n_views 64-bit words, each written at once as
  *                         status_seq << 32 | value): word 0 <- 1 if any packet overflowed its capacity or does not describe
  *                         this range, word 1 + v <- the rows view v wanted.  A host polling pinned memory until every word
- *                         carries status_seq learns the verdict while the pass runs, without synchronising the stream (a
- *                         one-thread launch in front of the passes posts it).  On overflow the outputs are incomplete. */
+ *                         carries status_seq learns the verdict while the pass runs, without synchronising the stream (the
+ *                         pass's first workgroup posts it as it starts).  On overflow the outputs are incomplete. */
 size_t frg_sum_packet_bytes(int n_gaussians, long long capacity_rows);
 int frg_pack_sum_rows(int P, int R, int first, int count, char* workspace, size_t workspace_bytes, const float* drgb_masked,
                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
@@ -452,7 +452,7 @@ typedef struct frg_combine_args {
     unsigned long long* status;
     unsigned int status_seq;
     unsigned char* row_live;
-    char* workspace;              /* frg_combine_workspace_bytes(n_views, capacity_rows): 48 bytes per packed row (its Gaussian, its staged terms) */
+    char* workspace;              /* frg_combine_workspace_bytes(n_views, capacity_rows): 256 bytes (the pass is one kernel and stages nothing in HBM) */
     size_t workspace_bytes;
     void* hip_stream;
 } frg_combine_args;

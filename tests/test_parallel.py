@@ -298,7 +298,7 @@ def test_exchange_then_adam_then_next_forward_equals_single_process_accumulation
 
 # ---- slot-sum exchange (round 6): the nine per-Gaussian sums of phase 1 travel, every rank runs the chain for every view ----------
 # Stand-ins for csrc/slot_exchange.hip (the product kernels are HIP-only) that write and read the SAME packet layout: header, one
-# bit per Gaussian, one row offset per 64 Gaussians, 36-byte rows in index order.
+# bit per Gaussian, one row offset per 64 Gaussians, 48-byte rows in index order.
 
 def _sum_chain(params, rows, campos, S):
     """A deterministic stand-in for the per-Gaussian backward chain: the 59 gradient floats of the Gaussians `rows` in one view

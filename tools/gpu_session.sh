@@ -40,14 +40,15 @@ trace)
   # kernel timeline of one step of each of ${TRACE_CFGS:-c2} (gaps between launches): rocprofv3 kernel trace, no counters
   for tc in ${TRACE_CFGS:-${TRACE_CFG:-c2}}; do
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace" -- python "$ROOTD/bench.py" --config $tc --steps 30 --warmup 5 --spinup-steps 50 --views 1 --no-cpu-baseline --no-extras --no-stage-timers ${TRACE_ARGS:-} > "$O/trace_bench.json" 2> "$O/trace.err")
-    f=$(find $O/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py "$f" > $O/trace_$tc.log 2>&1; cat $O/trace_$tc.log | tail -40
+    f=$(find $O/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py "$f" ${TRACE_PICK:-} > $O/trace_$tc.log 2>&1; cat $O/trace_$tc.log | tail -40
     rm -rf $O/trace
   done ;;
 train)
   timeout 600 python tools/train_step.py > $O/train_step.log 2>&1; tail -6 $O/train_step.log ;;
 exchange)
   : > $O/exchange_1rank.log
-  for mode in "--exchange slotsum" "--exchange slotsum --chunks 1" "--exchange slotsum --chunks 4" "--exchange factored" "--exchange factored --sync-exchange" "--exchange factored --reduce direct" "--exchange allreduce" "--exchange sparse"; do
+  IFS='|' read -ra EMODES <<< "${EXCHANGE_MODES:---exchange slotsum|--exchange slotsum --chunks 1|--exchange slotsum --chunks 4|--exchange factored|--exchange factored --sync-exchange|--exchange factored --reduce direct|--exchange allreduce|--exchange sparse}"
+  for mode in "${EMODES[@]}"; do
     echo "== bench.py --force-exchange $mode" >> $O/exchange_1rank.log
     timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --force-exchange $mode 2>&1 | grep -v "^Librccl\|^RCCL\|^HIP\|^ROCm\|^Hostname\|amdgpu.ids" | tail -2 >> $O/exchange_1rank.log
   done

@@ -1,4 +1,4 @@
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOTD="$PWD"; O="$ROOTD/gpurun_out/r06i"; mkdir -p $O; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOTD="$PWD"; O="$ROOTD/gpurun_out/${TAG:-r06pmc}"; mkdir -p $O; export TMPDIR=/tmp
 run() { local name="$1"; shift
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$O/$name" -- python "$ROOTD/tools/combine_bench.py" --config c3 --chunks 1 --no-check --iters 3 > /dev/null 2> "$O/$name.err")
   f=$(find $O/$name -name "*counter_collection.csv" | head -1)
