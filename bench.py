@@ -827,8 +827,8 @@ def main():
             render_ms = compute_only if compute_only is not None else ms_per_step
             sched = "in-step" if schedule[0] == "in-step" else "sync"
             rows_frac = (vpr.exchange.sparse_stats["rows_max"] / P) if (exchanging and args.exchange == "sparse" and vpr.exchange.sparse_stats["rows_max"]) else 0.124
-            if exchanging and args.exchange == "slotsum" and vpr.exchange.stats["rows_wanted_max"]:
-                rows_frac = vpr.exchange.stats["rows_wanted_max"] / P
+            if exchanging and args.exchange == "slotsum" and vpr.exchange.stats["rows_per_view_max"]:
+                rows_frac = vpr.exchange.stats["rows_per_view_max"] / P
             plans = [("allreduce", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync",)] + \
                     [("factored", rd, sc) for rd in ("allreduce", "direct") for sc in ("sync", "in-step")] + [("sparse", "allgather", "sync"), ("slotsum", "allgather", "in-step")]
             out["predicted"] = {

@@ -574,7 +574,7 @@ static void launch_tile(int B, int nblk, hipStream_t s, int first, int n, int n_
 #define FRG_TILE_LAUNCH(BB) hipLaunchKernelGGL((combine_tile_kernel<BB, RAW>), dim3((nblk + BB - 1) / BB), dim3(256), 0, s, first, n, n_views, pk, stride_w, \
         capacity, in.means3D, in.scales, in.rotations, in.opacities, in.raw, out.dL_dmean3D, out.dL_dscale, out.dL_drot, out.dL_dopacity, out.dL_dsh,       \
         row_live, status, seq)
-    if (B >= 24) FRG_TILE_LAUNCH(24); else if (B >= 12) FRG_TILE_LAUNCH(12); else if (B >= 6) FRG_TILE_LAUNCH(6); else FRG_TILE_LAUNCH(3);
+    if (B >= 24) FRG_TILE_LAUNCH(24); else if (B >= 12) FRG_TILE_LAUNCH(12); else if (B >= 6) FRG_TILE_LAUNCH(6); else if (B >= 3) FRG_TILE_LAUNCH(3); else FRG_TILE_LAUNCH(2);
 #undef FRG_TILE_LAUNCH
 }
 

@@ -604,7 +604,7 @@ class SlotSumExchange(GradientExchange):
         self.packets_all = [None] * len(self.chunks)
         self.view_ctx = None
         self.params = None
-        self.stats = {"rows_wanted_max": 0, "repacks": 0, "packet_bytes": 0}
+        self.stats = {"rows_wanted_max": 0, "rows_per_view_max": 0, "repacks": 0, "packet_bytes": 0}
         self._no_post = False
         self.combine_work = None      # the combine pass's scratch (256 bytes since the pass is one kernel; the ABI keeps the argument)
 
@@ -680,6 +680,9 @@ class SlotSumExchange(GradientExchange):
                 if want < 0.8 * self.capacity[c] or want > self.capacity[c]:
                     self.capacity[c] = want
             self.stats["rows_wanted_max"] = max(self.stats["rows_wanted_max"], max(counts))
+            wanted[c] = (False, counts)
+        # rows per view over ALL chunks of this step (the largest view's): what the packets' capacity follows
+        self.stats["rows_per_view_max"] = max(sum(cs[v] for _, cs in wanted) for v in range(world))
         if self.average:
             self.flat.mul_(1.0 / dist.get_world_size(self.group))
 
