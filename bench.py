@@ -98,6 +98,11 @@ def parse_args():
                     help="run the 'auto' probe of --exchange on any backend (it is skipped on gloo otherwise: functional tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only for functional tests of the multi-rank path on one GPU")
+    ap.add_argument("--dry-run-plumbing", action="store_true",
+                    help="no GPU: the launch path only -- self-launch under torch.distributed.run, rank environment, gloo group, the "
+                         "slot-sum exchange's collectives (all_gather_into_tensor per chunk, verdict, capacity update) on toy packets, "
+                         "barrier + max-over-ranks timing, rank 0's JSON line (marked dry_run; its value is NOT a measurement).  "
+                         "tests/test_parallel.py runs it at world 8")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange path on a single-rank RCCL group when launched without torch.distributed.run")
     ap.add_argument("--sync-exchange", action="store_true",
@@ -126,6 +131,86 @@ def self_launch_if_needed(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     os.execv(sys.executable, cmd)
+
+
+def dry_run_plumbing(args, world, rank):
+    """bench.py's multi-rank path without a GPU (see --dry-run-plumbing): toy packets in the real layout through the real
+    SlotSumExchange on gloo.  Every Gaussian has a row in every view; row of view v = v + 1 in all twelve floats; the toy combine
+    pass adds the views' rows in view order into the opacity gradient, so every rank must end with world (world + 1) / 2."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from frosting_amd.parallel import SUM_HDR_WORDS, SUM_ROW_FLOATS, SlotSumExchange, sum_packet_words
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = args.points or 20000
+    shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1), "shs": (P, 16, 3)}
+
+    def layout(n):
+        nblk = (n + 63) // 64
+        b_at = SUM_HDR_WORDS + 2 * nblk
+        return nblk, b_at, (b_at + nblk + 3) // 4 * 4
+
+    def packer(ex, c, dest):
+        first, n = ex.chunks[c]
+        cap = ex.capacity[c]
+        nblk, b_at, r_at = layout(n)
+        w = np.zeros(sum_packet_words(n, cap), dtype=np.int32)
+        w[0:6] = [min(n, cap), n, n, cap, first, 0x46534d36]
+        bits = np.zeros(nblk * 64, dtype=bool)
+        bits[:n] = True
+        w[SUM_HDR_WORDS:b_at] = np.packbits(bits.reshape(nblk, 64), axis=1, bitorder="little").view(np.int32).reshape(-1)
+        w[b_at:b_at + nblk] = 64 * np.arange(nblk, dtype=np.int32)
+        w[r_at:r_at + SUM_ROW_FLOATS * min(n, cap)] = np.full(SUM_ROW_FLOATS * min(n, cap), rank + 1, dtype=np.float32).view(np.int32)
+        dest.copy_(torch.from_numpy(w))
+
+    def combiner(ex, c, packets, n_views, seq):
+        first, n = ex.chunks[c]
+        _, _, r_at = layout(n)
+        acc = torch.zeros(n)
+        wants, over = [], False
+        for v in range(n_views):
+            w = packets[v].numpy()
+            assert int(w[2]) == n and int(w[4]) == first and int(w[5]) == 0x46534d36
+            wants.append(int(w[1]))
+            over |= int(w[1]) > int(w[3])
+            k = min(n, int(w[3]))
+            acc[:k] += torch.from_numpy(w[r_at:r_at + SUM_ROW_FLOATS * k].view(np.float32).reshape(k, SUM_ROW_FLOATS)[:, 0].copy())
+        ex.views["opacities"][first:first + n, 0] = acc
+        st = ex.status[c]
+        st[0] = (seq << 32) | int(over)
+        st[1:1 + n_views] = torch.tensor([(seq << 32) | x for x in wants], dtype=torch.int64)
+
+    ex = SlotSumExchange(shapes, "cpu", dist.group.WORLD, chunks=args.chunks, packer=packer, combiner=combiner)
+    ex.set_params({})
+
+    def step():
+        ex.note_view(dry=True)
+        ex.start()
+        ex.finish_in_step()
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    good = torch.tensor([1.0 if bool((ex.views["opacities"] == world * (world + 1) / 2).all()) else 0.0])
+    dist.all_reduce(good, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "train views/sec (fwd+bwd raster)", "value": world * args.steps / float(dt), "unit": "views/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(dt) / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry_run": True, "dry_run_note": "launch path and collectives only, toy packets on the CPU: NOT a measurement",
+                          "all_ranks_agree": bool(good.item() == 1.0),
+                          "config": {"workload": "dry run of the multi-rank plumbing", "P": P, "ranks": world, "backend": "gloo",
+                                     "exchange": "slotsum", "chunks": len(ex.chunks), "capacity_rows": list(ex.capacity),
+                                     "repacks": ex.stats["repacks"], "parallelism": f"view-parallel x{world}"}}))
+    dist.destroy_process_group()
 
 
 def stage_bytes(P, V, R, N, T):
@@ -394,6 +479,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("FRG_BENCH_ONE_GPU"):   # functional test: every rank on GPU 0
         local_rank = 0
+    if args.dry_run_plumbing:
+        if args.backend != "gloo":
+            raise SystemExit("--dry-run-plumbing runs on the CPU: add --backend gloo")
+        return dry_run_plumbing(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the rasterizer has no CPU path")
     dev = torch.device("cuda", local_rank)
@@ -551,6 +640,34 @@ def main():
         return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(nsteps)]
 
     timers = not args.no_stage_timers
+    # N > 1: the first steps of a plan are a TRIAL -- the slot-sum path's multi-rank collectives have only ever run on one GPU
+    # (single-rank RCCL, two ranks sharing a GPU over gloo).  A rank on which they raise tells the others (one MAX all-reduce),
+    # and every rank falls back to the next plan down: slotsum -> factored -> allreduce.  (A collective that HANGS cannot be
+    # caught here.)  The plan that ran is in config.exchange, a fallback in config.exchange_fallback.
+    exchange_fallback = None
+    if exchanging and world > 1:
+        for nxt in ("factored", "allreduce", None):
+            failed, err = 0.0, None
+            try:
+                for _ in range(2):
+                    step()
+                drain()
+            except Exception as ex:      # noqa: BLE001
+                failed, err = 1.0, repr(ex)
+            try:
+                flag = torch.tensor([failed], dtype=torch.float64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                failed = float(flag.item())
+            except Exception as ex:      # noqa: BLE001
+                raise SystemExit(f"bench.py: the process group itself fails: {ex!r}")
+            if not failed:
+                break
+            if nxt is None or args.exchange == "allreduce":
+                raise SystemExit(f"bench.py: every exchange plan failed; last error: {err}")
+            exchange_fallback = {"from": args.exchange, "to": nxt if args.exchange != nxt else "allreduce", "error": err}
+            args.exchange = exchange_fallback["to"]
+            torch.cuda.synchronize(dev)
+            vpr.set_exchange_plan(args.exchange, reduce=args.reduce)
     for _ in range(max(0, args.spinup_steps)):
         step()
     drain()
@@ -805,7 +922,7 @@ def main():
                                               "buffers; one-step-stale gradients only)"}[schedule[0]] +
                                     (", + densification statistics (radii MAX, grad-norm / count SUM)" if dstats is not None else "")),
                        "exchange_bytes_per_rank": (4 * vpr.exchange.wire_floats_per_rank if exchanging else 0),
-                       "reduce_probe_ms": reduce_probe, "exchange_probe_ms_per_step": exchange_probe,
+                       "reduce_probe_ms": reduce_probe, "exchange_probe_ms_per_step": exchange_probe, "exchange_fallback": exchange_fallback,
                        "blend_arithmetic": "exact" if args.exact else "fast", "seed": cfg["seed"],
                        "outputs_written": "all nine gradient tensors of SURVEY 8(d)'s 284 B / Gaussian except dL_dconic (an "
                                           "intermediate the reference's binding never returns, rasterize_points.cu:195): "

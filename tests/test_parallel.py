@@ -548,6 +548,57 @@ def test_predicted_exchange_budget_arithmetic():
         assert 0 < r["scaling_vs_1gpu"] < n
 
 
+def test_predicted_slot_sum_plan_from_measured_local_terms():
+    """The slot-sum plan in predict_exchange: the packets' bytes, the two-stage pipeline of gather and combine
+    pass over the chunks, local terms = the single-GPU measurements (SLOTSUM_LOCAL_MS: profiles/r06_combine_bench.log) -- and what
+    the arithmetic then says at 450 GB/s of bus bandwidth."""
+    from frosting_amd.parallel import SLOTSUM_LOCAL_MS, predict_exchange, sum_packet_words
+    P, render = 3_000_000, 1.35
+    loc = SLOTSUM_LOCAL_MS
+    for bw in (1071.0, 450.0, 300.0):
+        for K in (1, 2, 4):
+            r = predict_exchange(P, 16, 8, render, "slotsum", "allgather", "in-step", bus_GBps=bw, rows_fraction=0.1267, chunks=K)
+            s = r["slotsum"]
+            cap = (int(0.1267 * P * loc["slack"]) // 256 + 1) * 256
+            assert s["capacity_rows"] == cap and abs(s["packet_MB"] * 1e6 - (4.0 * sum_packet_words(P, cap) + 256.0 * (K - 1))) < 1.0
+            assert abs(s["wire_ms"] - 7 * s["packet_MB"] * 1e6 / (bw * 1e9) * 1e3) < 1e-9
+            c_all = (loc["combine_ms"][8] + loc["per_chunk_ms"] * (K - 1)) * loc["overlap_slowdown"]
+            assert abs(s["combine_ms"] - c_all) < 1e-12
+            done = s["wire_ms"] + c_all / K if c_all <= s["wire_ms"] else s["wire_ms"] / K + c_all
+            assert abs(s["gather_and_combine_ms"] - done) < 1e-12
+            assert abs(r["exposed_ms"] - (s["pack_ms"] + done - loc["phase2_ms"])) < 1e-12
+            assert r["dense_MB"] == 0.0
+    at = lambda bw, K: predict_exchange(P, 16, 8, render, "slotsum", "allgather", "in-step", bus_GBps=bw, rows_fraction=0.1267, chunks=K)["scaling_vs_1gpu"]
+    assert at(450.0, 4) >= 6.0 and at(450.0, 2) >= 6.0 > at(450.0, 1)        # the chunks' overlap is what carries it past 6 x
+    assert at(450.0, 4) > predict_exchange(P, 16, 8, render, "factored", "direct", "in-step", bus_GBps=450.0)["scaling_vs_1gpu"]
+    assert at(1071.0, 4) >= 6.0 > at(300.0, 4)                               # 300 GB/s: wire-bound, below the target
+    for n in (2, 4, 8):
+        assert 0 < predict_exchange(P, 16, n, render, "slotsum", "allgather", "in-step", bus_GBps=450.0, rows_fraction=0.1267)["scaling_vs_1gpu"] < n
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_at_world_8_dry_run():
+    """`python bench.py --gpus 8` from a bare shell: the self-launch under torch.distributed.run, eight ranks'
+    environment, the group, the slot-sum exchange's collectives on toy packets in the real layout, the barrier + max-over-ranks
+    timing and rank 0's one JSON line -- without a GPU (--dry-run-plumbing; the line is marked dry_run, its value is no measurement)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run-plumbing",
+                        "--steps", "3", "--warmup", "1", "--points", "20000"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]             # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["dry_run"] is True and d["all_ranks_agree"] is True
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["exchange"] == "slotsum"
+    assert d["config"]["chunks"] == 4 and d["config"]["repacks"] == 0
+    assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
 def _probe_worker(rank, world, port, q):
     import torch.distributed as dist
     from frosting_amd.parallel import probe_reduce_plan
