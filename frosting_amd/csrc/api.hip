@@ -526,6 +526,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.load();
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
+    if (name && strcmp(name, "combine_blocks") == 0) return frg::g_combine_blocks;
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
 
