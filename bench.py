@@ -89,6 +89,9 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=4,
                     help="slotsum: index ranges of Gaussians with a packet and a collective each -- the combine pass of one range "
                          "runs while the next range's packets travel")
+    ap.add_argument("--phase1-in-pieces", action="store_true",
+                    help="slotsum with several chunks: the backward's phase 1 chunk by chunk, every chunk's packet leaving as soon as its "
+                         "sums exist (frg_backward_args::range_first / range_count) instead of one phase-1 call followed by all the packets")
     ap.add_argument("--reduce", default="allreduce", choices=["auto", "allreduce", "direct"],
                     help="N>1: how the summed part travels: 'allreduce' = one RCCL all-reduce; 'direct' = one RCCL reduce-scatter "
                          "of 1/N shards + one all-gather (every GPU talks to every other over its own xGMI link: SURVEY 8(e)); "
@@ -531,7 +534,7 @@ def main():
     vpr = ViewParallelRasterizer(scene_d, dev, process_group=dist.group.WORLD if dist else None,
                                  factor_sh=(args.exchange in ("factored", "sparse")), deferred_counters=args.deferred_counters,
                                  reduce=args.reduce, sparse=(args.exchange == "sparse"), slotsum=(args.exchange == "slotsum"),
-                                 chunks=args.chunks)
+                                 chunks=args.chunks, phase1_in_pieces=args.phase1_in_pieces)
     if auto_reduce and dist is not None and world > 1 and args.backend == "nccl" and args.exchange in ("factored", "allreduce"):
         # the sum of the dense part timed both ways on this run's buffers, max over ranks; the faster plan is used
         from frosting_amd.parallel import probe_reduce_plan

@@ -94,7 +94,9 @@ class BackwardArgs(C.Structure):
                 # the backward in two calls: 1 = blend + slot sums (dL_dcolor complete), 2 = the rest; 0 = one call
                 ("phase", C.c_int),
                 # optional [P] bytes: 1 = the Gaussian has a gradient; the rows of the others are then not written
-                ("row_live", C.c_void_p)]
+                ("row_live", C.c_void_p),
+                # phase 1 in pieces: Gaussians [range_first, + range_count) (range_count 0: the whole phase)
+                ("range_first", C.c_int), ("range_count", C.c_int)]
 
 
 class CombineArgs(C.Structure):

@@ -900,7 +900,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  char* workspace, size_t workspace_bytes, int debug, void* hip_stream,
                  const frg::RawInputs& rw, float* dL_dshell_logits, float* dL_dshell_verts, int exact_mode = 0, int phase = 0,
-                 unsigned char* row_live = nullptr)
+                 unsigned char* row_live = nullptr, int range_first = 0, int range_count = 0)
 {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(FRG_EINVAL, "bad sizes");
@@ -984,6 +984,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         return FRG_OK;
     }
     if (phase == 1) note_phase1(workspace, geom_buffer, image_buffer, P, R);
+    const bool ranged = range_count > 0;
+    if (ranged) {
+        if (phase != 1) return fail(FRG_EINVAL, "frg_backward_args: a range is offered with phase 1 only (phase %d)", phase);
+        if (range_first < 0 || range_first % 256 != 0 || (long long)range_first + range_count > P)
+            return fail(FRG_EINVAL, "frg_backward_args: range [%d, +%d) of %d Gaussians (range_first: a multiple of 256)", range_first, range_count, P);
+    }
     const bool probe_bwd = (g_probe.load() & 2) && g_probe_side.ensure();
     if (probe_bwd) {   // timing experiment: the per-Gaussian backward beside the blend (it reads the previous frame's slots)
         FRG_HIP(hipEventRecord(g_probe_side.fork, stream));
@@ -992,7 +998,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         FRG_HIP(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags, true, g_probe_side.stream, sums));
         FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
     }
-    {
+    if (!ranged || range_first == 0) {
         StageScope sc_(ST_BLEND_BWD, stream);
         if (exact != 0)
             FRG_STAGE(frg::launch_blend_bwd_exact(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream, exact < 0), "blend_bwd");
@@ -1000,6 +1006,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
             FRG_STAGE(frg::launch_blend_bwd_fast(vp, g, img, b, background, dL_dpix, slots, (uint32_t)R, g_bwd_batch.load(), stream, exact < 0), "blend_bwd");
     }
     if (probe_bwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return FRG_OK; }
+    if (ranged) {      // phase 1 in pieces: the plain kernel over this range, whatever its waves own (no 16-wave side launch)
+        StageScope sc_(ST_PREPROCESS_BWD, stream);
+        FRG_STAGE(frg::launch_preprocess_bwd(P, vp, in, radii, g, img, slots, out, g_ablate.load(), pbw_flags | FRG_PBW_NO_HEAVY_LAUNCH, false, stream, sums,
+                                             live_masks, dir_terms, range_first, range_count), "preprocess_bwd (phase 1, range)");
+        return FRG_OK;
+    }
     {
         // the 16-wave form for the Gaussians that own thousands of slots runs on a side stream beside the plain kernel
         // (usually its workgroups find an empty list and leave)
@@ -1044,17 +1056,19 @@ int frg_backward(int P, int D, int M, int R, const float* background, int width,
 
 int frg_backward_ex(const frg_backward_args* a)
 {
-    // four generations of the struct: up to shell_*, + exact_blend / shell_bary_mode, + phase, + row_live
-    const size_t b1 = offsetof(frg_backward_args, exact_blend), b2 = offsetof(frg_backward_args, phase), b3 = offsetof(frg_backward_args, row_live);
-    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1 && a->struct_size != b2 && a->struct_size != b3))
-        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu, %zu, %zu)", a ? a->struct_size : (size_t)0,
-                    sizeof(frg_backward_args), b3, b2, b1);
+    // five generations of the struct: up to shell_*, + exact_blend / shell_bary_mode, + phase, + row_live, + range_first / range_count
+    const size_t b1 = offsetof(frg_backward_args, exact_blend), b2 = offsetof(frg_backward_args, phase), b3 = offsetof(frg_backward_args, row_live),
+                 b4 = offsetof(frg_backward_args, range_first);
+    if (!a || (a->struct_size != sizeof(frg_backward_args) && a->struct_size != b1 && a->struct_size != b2 && a->struct_size != b3 && a->struct_size != b4))
+        return fail(FRG_EINVAL, "frg_backward_args: struct_size %zu, this library expects %zu (or %zu, %zu, %zu, %zu)", a ? a->struct_size : (size_t)0,
+                    sizeof(frg_backward_args), b4, b3, b2, b1);
     frg::RawInputs rw;
     rw.raw_opacity = a->raw_opacities; rw.raw_scale = a->raw_scales; rw.raw_rot = a->raw_rotations;
     rw.shell_logits = a->shell_logits; rw.shell_verts = a->shell_cell_verts; rw.shell_cells = a->shell_cells;
     int exact_mode = 0;
     const int phase = a->struct_size >= b3 ? a->phase : 0;
-    unsigned char* row_live = a->struct_size == sizeof(frg_backward_args) ? a->row_live : nullptr;
+    unsigned char* row_live = a->struct_size >= b4 ? a->row_live : nullptr;
+    const bool has_range = a->struct_size == sizeof(frg_backward_args);
     if (a->struct_size >= b2) {
         if (a->exact_blend < 0 || a->exact_blend > 2 || a->shell_bary_mode < 0 || a->shell_bary_mode > 1)
             return fail(FRG_EINVAL, "frg_backward_args: mode out of range (exact_blend %d, shell_bary_mode %d)", a->exact_blend, a->shell_bary_mode);
@@ -1066,7 +1080,8 @@ int frg_backward_ex(const frg_backward_args* a)
                          a->tan_fovx, a->tan_fovy, a->radii, a->geom_buffer, a->binning_buffer, a->image_buffer, a->dL_dpix,
                          a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh,
                          a->dL_dscale, a->dL_drot, a->workspace, a->workspace_bytes, a->debug, a->hip_stream, rw,
-                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode, phase, row_live);
+                         a->dL_dshell_logits, a->dL_dshell_cell_verts, exact_mode, phase, row_live, has_range ? a->range_first : 0,
+                         has_range ? a->range_count : 0);
 }
 
 int frg_sh_color_grad(int P, const char* geom_buffer, const int* radii, const float* dL_dcolors,

@@ -75,7 +75,8 @@ struct BwdOutputs {
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& out, int ablate, int flags,
                                  bool heavy_only, hipStream_t s, float* sums = nullptr, unsigned long long* live_masks = nullptr,
-                                 float* view_dir_terms = nullptr /* [P][3], with live_masks: d(colour)/d(direction) . masked dRGB of the marked Gaussians */);
+                                 float* view_dir_terms = nullptr /* [P][3], with live_masks: d(colour)/d(direction) . masked dRGB of the marked Gaussians */,
+                                 int range_first = 0, int range_count = 0 /* > 0 (plain kernel only): Gaussians [range_first, + range_count), range_first a multiple of 256 */);
 
 // view-parallel exchange helpers (view_exchange.hip)
 hipError_t launch_sh_color_grad(int P, const GeomState& g, const int* radii, const float* dL_dcolor, float* out, hipStream_t s);

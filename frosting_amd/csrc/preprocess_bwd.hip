@@ -63,7 +63,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
                       RawInputs raw, float* __restrict__ dL_dshell_logits, float* __restrict__ dL_dshell_verts,
                       const float* __restrict__ sh_dir, int flags, const uint32_t* __restrict__ heavy,
                       const uint32_t* __restrict__ sh_layout, float* __restrict__ sums, unsigned char* __restrict__ row_live,
-                      unsigned long long* __restrict__ live_masks, float* __restrict__ view_dir_terms)
+                      unsigned long long* __restrict__ live_masks, float* __restrict__ view_dir_terms, int first_block)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(HEAVY ? BWD_HEAVY_WAVES : BWD_THREADS / 64) * BWD_LDS_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,7 +79,7 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
   if (HEAVY && heavy_item >= heavy[0]) return;                  // (usually: nothing was handed over)
   do {   // HEAVY: the workgroup strides over the handed-over waves; otherwise once
     if (HEAVY && heavy_item != blockIdx.x) __syncthreads();     // the previous item's LDS contents are dead
-    const int idx0 = HEAVY ? (int)heavy[1 + heavy_item] * 64 : (int)blockIdx.x * BWD_THREADS + wave * 64;       // first Gaussian of this wave
+    const int idx0 = HEAVY ? (int)heavy[1 + heavy_item] * 64 : ((int)blockIdx.x + first_block) * BWD_THREADS + wave * 64;       // first Gaussian of this wave
     const int idx = idx0 + lane;
     const bool valid = idx < P;
     ViewMats vmx;
@@ -664,9 +664,12 @@ preprocess_bwd_kernel(int P, ViewParams vp, const float* __restrict__ viewmatrix
 
 hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& in, const int* radii, const GeomState& g,
                                  const ImageState& img, const float* slots, const BwdOutputs& o, int ablate, int flags,
-                                 bool heavy_only, hipStream_t s, float* sums, unsigned long long* live_masks, float* view_dir_terms)
+                                 bool heavy_only, hipStream_t s, float* sums, unsigned long long* live_masks, float* view_dir_terms,
+                                 int range_first, int range_count)
 {
-    const dim3 grid((P + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
+    // (range: the plain kernel over Gaussians [range_first, range_first + range_count) only, range_first a multiple of 256)
+    const int first_block = range_count > 0 ? range_first / BWD_THREADS : 0;
+    const dim3 grid(((range_count > 0 ? range_count : P) + BWD_THREADS - 1) / BWD_THREADS), block(BWD_THREADS);
     // float4-streamed SH needs the reference's usual layout: 16 coefficients, 16-byte aligned rows
     const bool sh16 = in.shs && vp.M == 16 && (reinterpret_cast<uintptr_t>(in.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(o.dL_dsh) % 16 == 0);
@@ -675,7 +678,7 @@ hipError_t launch_preprocess_bwd(int P, const ViewParams& vp, const FwdInputs& i
                        in.cam_pos, in.means3D, radii, in.shs, in.scales, in.rotations, in.cov3D_precomp, g.xydr,          \
                        g.rgb_clamped, g.conic_opacity, g.point_offsets, img.cutoff, img.counters, slots, o.dL_dmean2D,     \
                        o.dL_dconic, o.dL_dopacity, o.dL_dcolor, o.dL_dmean3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscale, o.dL_drot, ablate,       \
-                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums, o.row_live, live_masks, view_dir_terms)
+                       in.raw, o.dL_dshell_logits, o.dL_dshell_verts, g.sh_dir, flags, g.heavy_waves, g.sh_layout, sums, o.row_live, live_masks, view_dir_terms, first_block)
     // the listed waves (usually none: the workgroups read the count and leave)
     const dim3 hgrid(256), hblock(BWD_HEAVY_WAVES * 64);
     if (heavy_only) { if (sh16) FRG_PBW(true, true, hgrid, hblock); else FRG_PBW(false, true, hgrid, hblock); }

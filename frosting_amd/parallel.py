@@ -650,6 +650,19 @@ class SlotSumExchange(GradientExchange):
         self.stats["packet_bytes"] = 4 * self.wire_floats_per_rank
         return self._works
 
+    def start_chunk(self, c: int):
+        """Pack chunk c of this view and enqueue its all-gather behind the work on the current stream -- for a backward whose
+        phase 1 comes in pieces (ViewParallelRasterizer.backward_overlapped): in chunk order, _works cleared by the caller first."""
+        if not self._active():
+            return None
+        if self.view_ctx is None:
+            raise RuntimeError("slot-sum exchange: note_view() after the backward's phase 1 first")
+        if len(self._works) != c:
+            raise RuntimeError(f"slot-sum exchange: chunk {c} started out of order ({len(self._works)} in flight)")
+        self._works.append(self._gather(c, self._world(), True))
+        self.stats["packet_bytes"] = 4 * self.wire_floats_per_rank
+        return self._works[-1]
+
     def _finish_on_current_stream(self):
         import torch.distributed as dist
         if self.params is None:
@@ -846,7 +859,7 @@ class ViewParallelRasterizer:
     def __init__(self, scene, device, process_group=None, average: bool = False, factor_sh: bool = False,
                  deferred_counters: bool = False, capacity_slack: float = 1.25, reduce: str = "allreduce",
                  write_all_outputs: bool = True, raw_params: bool = False, sparse: bool = False, live_rows: bool = False,
-                 slotsum: bool = False, chunks: int = 2):
+                 slotsum: bool = False, chunks: int = 2, phase1_in_pieces: bool = False):
         """deferred_counters: after the first (synchronous) view, forwards run through
         frg_forward_deferred -- no host synchronisation inside the step; finish() then reports the
         true instance count and whether the view has to be repeated (capacity exceeded)."""
@@ -859,6 +872,9 @@ class ViewParallelRasterizer:
         # rows of the others (frg_backward_args::row_live) -- for a consumer that takes an unmarked row as zero without
         # reading it (FlatAdam.step(row_live=...)).  Single-GPU training steps; not with an exchange (it sums whole buffers).
         self.live_rows = live_rows
+        # slot-sum plan, several chunks: the backward's phase 1 runs chunk by chunk and every chunk's packet leaves as soon as
+        # its sums exist (backward_overlapped): the wire starts ~0.1 ms earlier at C3
+        self.phase1_in_pieces = phase1_in_pieces
         self.deferred_counters = deferred_counters
         self.capacity_slack = capacity_slack
         self.capacity = 0            # instances the binning arena is sized for (deferred forwards)
@@ -988,7 +1004,8 @@ class ViewParallelRasterizer:
         self.true_num_rendered = n.value
         return True
 
-    def backward(self, dL_dimage, slot: int = 0, payload=None, phase: int = 0, slot_sums: bool = False, local: bool = False):
+    def backward(self, dL_dimage, slot: int = 0, payload=None, phase: int = 0, slot_sums: bool = False, local: bool = False,
+                 sum_range=None):
         """Gradients of the last forward, written in place into exchange buffer `slot`.  In the
         factored plan under a process group, views["shs"] is only valid after wait_exchange(slot).
         payload: also fill this view's share of the factored exchange (masked colour gradient and
@@ -998,6 +1015,8 @@ class ViewParallelRasterizer:
         consumer that may take the buffer as it is is FlatAdam.step(flat, row_live=self.row_live) (it rejects the buffer
         without the mask); anything else -- densification statistics, gradient norms, a plain optimizer -- calls
         zero_dead_rows(slot) first.
+        sum_range = (first, count), slot-sum plan only: phase 1 in pieces (frg_backward_args::range_first / range_count) -- the
+        call with first == 0 runs the blend backward, every call reduces its range's slots.
         phase (frg_backward_args::phase): 1 = the backward blend + the per-Gaussian slot sums -- the payload of the
         factored exchange is complete when this call's kernels are, so its all-gather can be started before phase 2
         (backward_overlapped does that); 2 = the rest; 0 = both in one call."""
@@ -1011,7 +1030,10 @@ class ViewParallelRasterizer:
         # (slot_sums=True: one process playing every rank -- tests, tools; local=True: no exchange follows this backward --
         # the whole backward of the own view, as without a process group)
         slot_sums = ex.slotsum and not local and (ex._active() or slot_sums)
-        self._bwd_gen = getattr(self, "_bwd_gen", 0) + 1            # (the workspace now holds THIS backward's sums)
+        if sum_range is not None and not slot_sums:
+            raise RuntimeError("sum_range: pieces of phase 1 exist on the slot-sum path only")
+        if sum_range is None or sum_range[0] == 0:
+            self._bwd_gen = getattr(self, "_bwd_gen", 0) + 1        # (the workspace now holds THIS backward's sums)
         if slot_sums:
             # slot-sum plan with live collectives: only phase 1 runs here -- the blend backward and the per-Gaussian slot sums;
             # the sums travel, and the per-Gaussian chain runs for every view's rows in the exchange's combine pass
@@ -1039,7 +1061,8 @@ class ViewParallelRasterizer:
             dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), workspace=v(work), workspace_bytes=work.numel(), debug=0,
             hip_stream=stream.value, raw_opacities=v(s.opacities) if raw else None, raw_scales=v(s.scales) if raw else None,
             raw_rotations=v(s.rotations) if raw else None, exact_blend=getattr(self, "_exact", -1) + 1, phase=int(phase),
-            row_live=v(self.row_live))
+            row_live=v(self.row_live), range_first=0 if sum_range is None else int(sum_range[0]),
+            range_count=0 if sum_range is None else int(sum_range[1]))
         rc = L.frg_backward_ex(C.byref(a))
         if rc < 0:
             raise RuntimeError(f"frg_backward failed ({rc}): {_lib.last_error()}")
@@ -1081,6 +1104,16 @@ class ViewParallelRasterizer:
         exchanges[slot].finish_in_step() (or exchange_in_step(slot, started=True)).  Without a live factored exchange:
         a plain backward + start_exchange."""
         ex = self.exchanges[slot]
+        if ex.slotsum and ex._active() and len(ex.chunks) > 1 and self.phase1_in_pieces:
+            # slot-sum plan: phase 1 in pieces -- the blend backward, then per chunk of Gaussians: its slot sums, its packet, its
+            # all-gather: chunk k travels while chunk k + 1 is still being reduced (and, in finish_in_step, while chunk k - 1
+            # is being combined)
+            self.exchange = ex
+            ex._works = []
+            for c, (first, n) in enumerate(ex.chunks):
+                g = self.backward(dL_dimage, slot, sum_range=(first, n))
+                ex.start_chunk(c)
+            return g
         if not (ex.factor_sh and ex._active()) or ex.sparse:      # (sparse: one call -- its rows are packed from the finished gradients; slotsum: backward() runs phase 1 only)
             g = self.backward(dL_dimage, slot)
             ex.start()

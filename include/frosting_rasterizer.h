@@ -251,6 +251,12 @@ typedef struct frg_backward_args {
      * NOT written (at 3 M Gaussians six rows in seven are zeros: 0.74 of the 0.85 GB the backward writes).  A consumer that
      * treats an unmarked row as zero without reading it (frg_adam_step_rows) gets exactly what the dense form gives. */
     unsigned char* row_live;
+    /* fifth generation: phase 1 IN PIECES (range_count > 0, with phase == 1 only; 0 = the whole phase in one call).  Every call
+     * reduces the slots of Gaussians [range_first, range_first + range_count) -- range_first a multiple of 256 -- to their sums;
+     * the call with range_first == 0 comes first and runs the backward blend in front of it.  The ranges together must cover
+     * [0, P); each call's share of the sums (and of what frg_pack_sum_rows packs from them) is complete when that call's work
+     * is, so a slot-sum exchange can pack and send range k while range k + 1 is still being reduced.  Same bits as one call. */
+    int range_first, range_count;
 } frg_backward_args;
 int frg_backward_ex(const frg_backward_args* args);
 

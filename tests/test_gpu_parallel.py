@@ -70,7 +70,7 @@ def test_rebuild_lower_degree_and_zero_views(gpu_device):
     assert float(ex.views["shs"].abs().max()) == 0.0
 
 
-def _slot_sum_views(vpr, name, views, dev, P, world=None, seed0=555):
+def _slot_sum_views(vpr, name, views, dev, P, world=None, seed0=555, pieces=False):
     """One process playing every rank of the slot-sum exchange: per view the one-call backward (the reference gradient of that
     view) and, from the same forward, phase 1 + the view's packets where an all-gather would have put them."""
     ex = vpr.exchange
@@ -84,18 +84,24 @@ def _slot_sum_views(vpr, name, views, dev, P, world=None, seed0=555):
         g = vpr.backward(gpix, 0)                               # every gradient of this view, one call
         for n in PARAM_ORDER:
             acc[n] += g[n]                                      # the single-process accumulation, in view order
-        vpr.backward(gpix, 0, slot_sums=True)                   # phase 1 only: the nine sums + their bit mask in the workspace
+        if pieces:                                              # phase 1 in pieces (frg_backward_args::range_first / range_count): the blend
+            for first, n in ex.chunks:                              # backward with the first range, every range's sums by its own call
+                vpr.backward(gpix, 0, slot_sums=True, sum_range=(first, n))
+        else:
+            vpr.backward(gpix, 0, slot_sums=True)               # phase 1 only: the nine sums + their bit mask in the workspace
         ex.pack_local_view(slot_v, world)
     return acc
 
 
-@pytest.mark.parametrize("name,P,views,chunks,degree,raw", [("mini", 5000, [0, 3, 5, 6], 1, 3, False), ("mini", 4807, [1, 2], 3, 1, False),
-                                                           ("c2", 80_000, list(range(8)), 2, 3, False), ("c2", 50_000, [0, 1, 2, 4], 2, 3, True)])
-def test_slot_sum_combine_is_the_accumulation_of_the_view_gradients_bit_for_bit(gpu_device, name, P, views, chunks, degree, raw):
+@pytest.mark.parametrize("name,P,views,chunks,degree,raw,pieces", [("mini", 5000, [0, 3, 5, 6], 1, 3, False, False), ("mini", 4807, [1, 2], 3, 1, False, True),
+                                                                  ("c2", 80_000, list(range(8)), 2, 3, False, False), ("c2", 50_000, [0, 1, 2, 4], 2, 3, True, False),
+                                                                  ("c2", 80_001, [0, 2, 4, 6, 7], 4, 3, False, True), ("c2", 50_000, [5], 3, 3, True, True)])
+def test_slot_sum_combine_is_the_accumulation_of_the_view_gradients_bit_for_bit(gpu_device, name, P, views, chunks, degree, raw, pieces):
     """frg_pack_sum_rows + frg_backward_combine (round 6): the rows of the nine per-Gaussian sums phase 1 leaves, packed per view
     in index order behind a bit mask, and ONE pass that runs the per-Gaussian chain for every view's row in view order --
     against the gradients of the same views from one-call backwards, accumulated in view order in one process: every one of the
-    59 floats per Gaussian the same bits; lower SH degree; raw parameters (activation Jacobians per view); several chunks."""
+    59 floats per Gaussian the same bits; lower SH degree; raw parameters (activation Jacobians per view); several chunks; phase 1
+    in one call or in pieces, one per chunk; every tile size of the combine pass (eight views .. a single one)."""
     dev = gpu_device
     scene, _, _ = scenes.config_scene(name, 0, P=P)
     scene.sh_degree = degree
@@ -105,7 +111,7 @@ def test_slot_sum_combine_is_the_accumulation_of_the_view_gradients_bit_for_bit(
     vpr = ViewParallelRasterizer(scene.to(dev), dev, slotsum=True, chunks=chunks, raw_params=raw)
     ex = vpr.exchange
     assert isinstance(ex, SlotSumExchange) and len(ex.chunks) == chunks and sum(n for _, n in ex.chunks) == P
-    acc = _slot_sum_views(vpr, name, views, dev, P)
+    acc = _slot_sum_views(vpr, name, views, dev, P, pieces=pieces)
     for t in ex.views.values():
         t.fill_(float("nan"))                                   # every row must be written by the pass
     verdicts = ex.combine_local(len(views))

@@ -136,10 +136,11 @@ def test_extended_entry_points_validate_arguments_without_a_gpu():
     a.forward_only, a.instance_capacity = 1, 1000
     assert L.frg_forward_ex(C.byref(a)) == -1 and "deferred" in _lib.last_error()
     assert _lib.mode_fields({"forward_only": 1, "exact_blend": 1}) == {"exact_blend": 2, "tight_binning": 0, "async_sh": 0, "forward_only": 1}
-    # frg_backward_args: three generations, told apart by struct_size (up to shell_*, + exact_blend / shell_bary_mode,
-    # + phase); the ctypes mirror is the newest.  P == 0 returns before any pointer is looked at.
+    # frg_backward_args: five generations, told apart by struct_size (up to shell_*, + exact_blend / shell_bary_mode,
+    # + phase, + row_live, + range_first / range_count); the ctypes mirror is the newest.  P == 0 returns before any pointer is looked at.
     b = _lib.BackwardArgs(P=0, width=8, height=8)
-    for size in (C.sizeof(_lib.BackwardArgs), _lib.BackwardArgs.phase.offset, _lib.BackwardArgs.exact_blend.offset):
+    for size in (C.sizeof(_lib.BackwardArgs), _lib.BackwardArgs.range_first.offset, _lib.BackwardArgs.row_live.offset,
+                 _lib.BackwardArgs.phase.offset, _lib.BackwardArgs.exact_blend.offset):
         b.struct_size = size
         assert L.frg_backward_ex(C.byref(b)) == 0, (size, _lib.last_error())
     b.struct_size = C.sizeof(_lib.BackwardArgs) + 8
