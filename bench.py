@@ -240,7 +240,7 @@ def pmc_traffic(stage: str, cfg_name: str, P: int):
     if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"]:
         return None
     mine = _lib.build_fingerprint()["kernel_sources_sha256"]
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         try:
             doc = json.load(open(path))
@@ -275,7 +275,7 @@ def pmc_valu(stage: str, cfg_name: str, P: int, launch_ms: float):
     if cfg_name != "c3" or P != scenes.CONFIGS["c3"]["P"] or stage not in STAGE_KERNELS:
         return None
     mine = _lib.build_fingerprint()["kernel_sources_sha256"]
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_sq.json")
         try:
             doc = json.load(open(path))

@@ -209,6 +209,7 @@ struct HostMail {
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
 std::atomic<int> g_sh_no_dir{0};           // option "sh_dir_in_backward"
+std::atomic<int> g_fused_small{1};         // option "fused_small": frames of at most 2^20 instances sort their short lists inside the forward blend
 std::atomic<int> g_sparse_sh{1};            // option "sparse_sh": the SH pass over the visible Gaussians only, where a view sees a part of the model
 std::atomic<int> g_bwd_heavy_first{1};
 std::atomic<int> g_clear_image_state{0};   // 1: the memset in front of every forward, needed or not
@@ -478,6 +479,7 @@ int frg_set_option(const char* name, int value)
         const int old = frg::g_rows_grid; frg::g_rows_grid = value <= 0 ? 0 : value < 8 ? 8 : value; return old;
     }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
+    if (name && strcmp(name, "fused_small") == 0) return g_fused_small.exchange(value ? 1 : 0);
     // tuning: blocks of 64 Gaussians per tile of the combine pass (3, 6, 12 or 24; 0 = chosen from the number of views); same results
     if (name && strcmp(name, "combine_blocks") == 0) { const int old = frg::g_combine_blocks; frg::g_combine_blocks = value < 0 ? 0 : value; return old; }
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
@@ -526,6 +528,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "clear_image_state") == 0) return g_clear_image_state.load();
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
+    if (name && strcmp(name, "fused_small") == 0) return g_fused_small.load();
     if (name && strcmp(name, "combine_blocks") == 0) return frg::g_combine_blocks;
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -772,6 +775,10 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     const bool forked_plan = early && g_mail.long_lists;
     if (mail) g_mail.long_lists = c.class_count[4] > 0;
 
+    // small frames (at most 2^20 instances: C2 has 350 000 in 2 500 lists of 140): the lists of up to 512 entries are sorted by the
+    // forward blend's own workgroups (blend_impl.h FUSED) -- one launch and the point_list round trip less in a step that is a
+    // chain of short launches; the longest-first tile order (class lists) is what the fused form walks
+    const bool fused_small = g_fused_small.load() != 0 && R > 0 && R <= (1 << 20) && frg::g_fwd_order != 0 && !(g_probe.load() & 1);
     const bool probe_fwd = (g_probe.load() & 1) && R > 0 && !exact && g_probe_side.ensure();
     if (R > 0) {
         FRG_STAGE(frg::launch_sort_plan(T, c.class_count, img.counters->class_count, img.class_tiles, img.ranges, b.big_plan, (uint32_t)R, stream, forked_plan ? 2 : 0), "sort plan");
@@ -785,7 +792,7 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
             FRG_HIP(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, g_probe_side.stream));
             FRG_HIP(hipEventRecord(g_probe_side.join, g_probe_side.stream));
         }
-        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, b.big_plan, (uint32_t)R, max_tile, index_bits, b.point_list, stream), "sort"); }
+        { StageScope sc_(ST_SORT, stream); FRG_STAGE(frg::launch_tile_sort(T, c.class_count, nullptr, img.counters->class_count, img.class_tiles, img.ranges, b.pairs, b.pairs_tmp, b.big_hist, b.big_plan, (uint32_t)R, max_tile, index_bits, b.point_list, stream, fused_small), "sort"); }
         if (probe_fwd) { FRG_HIP(hipStreamWaitEvent(stream, g_probe_side.join, 0)); return R; }
     } else {
         // point_offsets must still be defined for backward
@@ -796,9 +803,9 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     {
         StageScope sc_(ST_BLEND_FWD, stream);
         if (exact)
-            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream, md.fwd_only != 0), "blend");
+            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream, md.fwd_only != 0, fused_small), "blend");
         else
-            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream, md.fwd_only != 0), "blend");
+            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream, md.fwd_only != 0, fused_small), "blend");
     }
     return R;
 }

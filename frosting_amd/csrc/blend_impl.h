@@ -30,6 +30,7 @@
 // floating-point contraction mode for everything below)
 #pragma once
 #include "frg_common.h"
+#include "sort_lds.h"
 #include <algorithm>
 
 namespace frg {
@@ -118,16 +119,23 @@ __device__ __forceinline__ void wave_lds_sync()
 // gather latency of its longest tiles' waves (C4: 0.321 -> 0.282 ms); with thousands of waves in flight the other
 // waves hide most of it (C3: 0.2135 -> 0.2025).  Same loads, same arithmetic: every output bit-identical.  (Round 2
 // measured a register double-buffering of the three separate arrays slower; with 48-byte records it pays.)
-template <bool EXACT, bool PREFETCH = false>
+// FUSED (small frames, round 6): a tile whose list has at most FRG_FUSED_SORT_CAP entries is SORTED HERE, by the tile's four waves
+// together (sort_lds.h: the tile sort's own passes, 2 entries per thread), from the scatter's unsorted pairs -- the host skips the
+// tile sort's launch for that size class; the sorted indices stay in LDS for the walk (and go to point_list for the record and
+// the backward).  A frame of 100 k Gaussians (C2: 2 500 lists of 140 entries) is six launches of 5 - 30 us, each a chain of
+// dependent memory round trips: this takes one launch boundary and the point_list round trip out of it.
+#define FRG_FUSED_SORT_CAP 512
+template <bool EXACT, bool PREFETCH = false, bool FUSED = false>
 __global__ void __launch_bounds__(BLEND_THREADS)
 blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
-                 const uint32_t* __restrict__ point_list, const float4* __restrict__ xydr,
+                 uint32_t* point_list /* FUSED: written here for the short lists */, const float4* __restrict__ xydr,
                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb_clamped,
                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  float* __restrict__ out_color, uint32_t* __restrict__ tile_work, float4* __restrict__ ckpt,
                  float4* __restrict__ final_C, const uint32_t* __restrict__ class_tiles, const uint32_t* __restrict__ class_count,
                  int seg_log, uint32_t* __restrict__ bwd_cnt, uint32_t* __restrict__ bwd_last, uint32_t cap_b,
-                 uint2* __restrict__ bwd_full, uint32_t cap_a, uint2* __restrict__ cutoff, Counters* __restrict__ counters)
+                 uint2* __restrict__ bwd_full, uint32_t cap_a, uint2* __restrict__ cutoff, Counters* __restrict__ counters,
+                 const uint2* __restrict__ pairs)
 {
     using M = BlendMath<EXACT>;
     const int SEG = 1 << seg_log;      // entries per segment of the backward blend (frg_common.h: bwd_seg_log)
@@ -170,6 +178,24 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     float4* s_co = s_co_all[q];
     float4* s_rgb = s_rgb_all[q];
 
+    // FUSED: the short list sorted by the four waves; its Gaussian indices then come from LDS
+    __shared__ uint2 s_sorted[FUSED ? FRG_FUSED_SORT_CAP : 1];
+    __shared__ uint32_t s_whist[FUSED ? 4 * 256 : 1];
+    __shared__ uint32_t s_sscratch[FUSED ? FRG_SORT_SCRATCH_WORDS : 1];
+    const bool in_lds = FUSED && n <= FRG_FUSED_SORT_CAP;          // workgroup-uniform
+    if (in_lds && n > 0) {
+        int begin, end;
+        wave_strip<4>(n, q, begin, end);
+        uint2 e[FRG_FUSED_SORT_CAP / BLEND_THREADS];
+#pragma unroll
+        for (int it = 0; it < FRG_FUSED_SORT_CAP / BLEND_THREADS; it++) {
+            const int i = begin + it * 64 + lane;
+            e[it] = i < end ? load_pair_stream(pairs + rg.x + i) : make_uint2(0u, 0u);
+        }
+        sort_block_lds<4, FRG_FUSED_SORT_CAP / BLEND_THREADS>(e, n, begin, end, s_sorted, s_whist, s_sscratch);
+        for (int i = threadIdx.x; i < n; i += BLEND_THREADS) point_list[rg.x + i] = s_sorted[i].y;
+    }
+
     const int qx0 = tx * FRG_TILE + (q & 1) * 8, qy0 = ty * FRG_TILE + (q >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
@@ -189,7 +215,9 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
     // (C4's limb) pays one such chain per round of 64 entries; with the indices a round further ahead it is one trip.
     float4 a_n = make_float4(0.f, 0.f, 0.f, 0.f), co_n = a_n, col_n = a_n;
     uint32_t id_n = 0;                 // this lane's list entry of the round after the one whose records are in flight
-    auto fetch_id = [&](int base) { id_n = point_list[rg.x + min(base + lane, n - 1)]; };   // unconditional loads at clamped positions (see blend_bwd_kernel)
+    auto fetch_id = [&](int base) {          // unconditional loads at clamped positions (see blend_bwd_kernel)
+        id_n = in_lds ? s_sorted[min(base + lane, n - 1)].y : point_list[rg.x + min(base + lane, n - 1)];
+    };
     auto fetch = [&](uint32_t id) {
         a_n = xydr[FRG_REC * id];
         co_n = conic_opacity[FRG_REC * id];
@@ -220,7 +248,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             }
             hit = lane < cnt && quadrant_hit(a.x, a.y, co, qx0, qy0);
         } else if (lane < cnt) {
-            const uint32_t id = point_list[rg.x + base + lane];
+            const uint32_t id = in_lds ? s_sorted[base + lane].y : point_list[rg.x + base + lane];
             a = xydr[FRG_REC * id];
             co = conic_opacity[FRG_REC * id];
             col = rgb_clamped[FRG_REC * id];
@@ -760,16 +788,18 @@ blend_bwd_kernel(int T, int gx, int gy, int W, int H, const uint2* __restrict__ 
 extern int g_fwd_order;       // tuning (frg_set_option("fwd_order")): 1 = forward blend walks the tiles longest list first
 template <bool EXACT>
 static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                     const float* bg, float* out_color, bool prefetch, hipStream_t s, bool forward_only = false)
+                                     const float* bg, float* out_color, bool prefetch, hipStream_t s, bool forward_only = false,
+                                     bool fused_sort = false)
 {
     const int T = vp.gx * vp.gy;
-#define FRG_FWD(PF)                                                                                                        \
-    hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
+#define FRG_FWD(PF, FS)                                                                                                    \
+    hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF, FS>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,   \
                        out_color, img.tile_work, forward_only ? nullptr : b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr,             \
                        img.counters->class_count, b.seg_log, img.bwd_cnt, img.bwd_last, img.bwd_cap_b, b.bwd_full,         \
-                       (uint32_t)BinningState::full_cap(b.carved_R), img.cutoff, img.counters)
-    if (prefetch) FRG_FWD(true); else FRG_FWD(false);
+                       (uint32_t)BinningState::full_cap(b.carved_R), img.cutoff, img.counters, b.pairs)
+    if (fused_sort) { if (prefetch) FRG_FWD(true, true); else FRG_FWD(false, true); }
+    else if (prefetch) FRG_FWD(true, false); else FRG_FWD(false, false);
 #undef FRG_FWD
     return hipGetLastError();
 }

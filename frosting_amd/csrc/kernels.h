@@ -41,13 +41,14 @@ hipError_t launch_sort_plan(int T, const uint32_t* class_count, const uint32_t* 
 hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* grid_hint, const uint32_t* class_count_dev,
                             const uint32_t* class_tiles, const uint2* ranges, uint2* pairs, uint2* pairs_tmp,
                             uint32_t* big_hist, uint32_t* big_plan, uint32_t R, int max_tile_count, int index_bits,
-                            uint32_t* point_list, hipStream_t stream);
+                            uint32_t* point_list, hipStream_t stream, bool skip_small = false /* the (0, 512] class is left to the forward blend's fused form */);
 
 // forward_only: no backward will follow (frg_forward_args::forward_only) -- no checkpoints, no final colours, no work items
+// fused_sort: the lists of at most 512 entries are sorted by the blend's own workgroups (launch_tile_sort was told skip_small)
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, float* out_color, hipStream_t s, bool forward_only = false);
+                                  const float* bg, float* out_color, hipStream_t s, bool forward_only = false, bool fused_sort = false);
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, float* out_color, hipStream_t s, bool forward_only = false);
+                                 const float* bg, float* out_color, hipStream_t s, bool forward_only = false, bool fused_sort = false);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 // R: the instance count the caller sized the slots for (bounds the number of work items: the grid)
 // as_stamped: the host launches BOTH arithmetics and each kernel leaves at once unless the forward's stamp (Counters::fwd_flags)

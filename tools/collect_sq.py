@@ -9,7 +9,7 @@ from frosting_amd import _lib
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for name in ("sq1", "sq2", "tcc"):
+for name in ("sq1", "sq2", "tcc", "l2w"):
     for f in glob.glob(os.path.join(src, name, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]

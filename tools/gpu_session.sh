@@ -11,6 +11,7 @@
 #   ab4/ab4b  alternating bench.py passes of library builds / options (SETTINGS, CONFIGS)
 #   tworank   bench.py's multi-rank path on one GPU: two ranks share GPU 0 over gloo (functional only)
 #   cmd       run $CMD (a one-off measurement) with its output in $O/cmd.log
+#   combine   tools/combine_bench.py ($COMBINE_ARGS, "|"-separated; COMBINE_PROF=1: + rocprofv3 stats)      combinepmc   its PMC passes
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${TAG:-r06}"
@@ -62,6 +63,7 @@ pmc)
   run fetch FETCH_SIZE
   run write WRITE_SIZE
   run tcc TCC_HIT_sum TCC_MISS_sum
+  run l2w TCP_TCC_WRITE_REQ_sum SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD TCP_TCC_READ_REQ_sum      # L2 requests per store / load instruction (scatter: VERDICT r05 next 6)
   python tools/collect_traffic.py gpurun_out/pmc $TAG > $O/pmc_traffic_stdout.json 2> $O/collect.err
   python tools/collect_sq.py gpurun_out/pmc $TAG > $O/pmc_sq_stdout.json 2>> $O/collect.err
   cp profiles/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_sq.json $O/ 2>/dev/null
@@ -90,6 +92,29 @@ combine)
     f=$(find $O/cprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/combine_kernel_stats.csv && head -14 $O/combine_kernel_stats.csv | cut -c1-60,140-230
     rm -rf $O/cprof
   fi ;;
+combinepmc)
+  # SQ / traffic / cache counters of the slot-sum exchange's kernels (pack, combine pass), separate passes
+  prun() { local name="$1"; shift
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$O/$name" -- python "$ROOTD/tools/combine_bench.py" --config c3 --chunks 1 --no-check --iters 3 > /dev/null 2> "$O/$name.err")
+    f=$(find $O/$name -name "*counter_collection.csv" | head -1)
+    python - "$f" "$name" <<'PY'
+import csv,sys,collections
+f,name=sys.argv[1],sys.argv[2]
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    k=r["Kernel_Name"]
+    if "combine" in k or "sum_rows" in k:
+        acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,d in acc.items():
+    print(name, k, {c: round(sum(v)/len(v)) for c,v in d.items()}, "launches", len(next(iter(d.values()))))
+PY
+    rm -rf $O/$name; }
+  { prun sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
+    prun sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_INSTS_LDS
+    prun fetch FETCH_SIZE
+    prun write WRITE_SIZE
+    prun tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum; } > $O/pmc_combine.log 2>&1
+  cat $O/pmc_combine.log | cut -c1-400 ;;
 gradab)
   # the default arithmetic's distance to float64, one A/B build (tools/build_variants.sh) at a time: $GRADAB_LIBS = names under frosting_amd/lib_ab/
   : > $O/grad_ab.log
