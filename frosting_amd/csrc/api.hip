@@ -209,6 +209,7 @@ struct HostMail {
 thread_local HostMail g_mail;
 std::atomic<int> g_use_mailbox{1};
 std::atomic<int> g_sh_no_dir{0};           // option "sh_dir_in_backward"
+std::atomic<int> g_fwd_unroll8{1};         // option "fwd_unroll8": 0 never | 1 frames of a few long lists (the host's rule) | 2 always
 std::atomic<int> g_fused_small{1};         // option "fused_small": frames of at most 2^20 instances sort their short lists inside the forward blend
 std::atomic<int> g_sparse_sh{1};            // option "sparse_sh": the SH pass over the visible Gaussians only, where a view sees a part of the model
 std::atomic<int> g_bwd_heavy_first{1};
@@ -480,6 +481,7 @@ int frg_set_option(const char* name, int value)
     }
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.exchange(value < 0 || value > 3 ? 1 : value);
     if (name && strcmp(name, "fused_small") == 0) return g_fused_small.exchange(value ? 1 : 0);
+    if (name && strcmp(name, "fwd_unroll8") == 0) return g_fwd_unroll8.exchange(value < 0 || value > 2 ? 1 : value);
     // tuning: blocks of 64 Gaussians per tile of the combine pass (3, 6, 12 or 24; 0 = chosen from the number of views); same results
     if (name && strcmp(name, "combine_blocks") == 0) { const int old = frg::g_combine_blocks; frg::g_combine_blocks = value < 0 ? 0 : value; return old; }
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
@@ -529,6 +531,7 @@ int frg_get_option(const char* name)
     if (name && strcmp(name, "sort_heavy_on_caller") == 0) return frg::g_sort_heavy_on_caller;
     if (name && strcmp(name, "async_sh") == 0) return g_async_sh.load();
     if (name && strcmp(name, "fused_small") == 0) return g_fused_small.load();
+    if (name && strcmp(name, "fwd_unroll8") == 0) return g_fwd_unroll8.load();
     if (name && strcmp(name, "combine_blocks") == 0) return frg::g_combine_blocks;
     return fail(FRG_EINVAL, "unknown option '%s'", name ? name : "(null)");
 }
@@ -802,10 +805,22 @@ static int forward_impl(frg_alloc_fn geometry_alloc, frg_alloc_fn binning_alloc,
     if (defer_sh) { FRG_HIP(hipStreamWaitEvent(stream, g_sh_side.sh_done, 0)); sh_join.armed = false; }
     {
         StageScope sc_(ST_BLEND_FWD, stream);
+        // A frame that does not fill the GPU (fewer than 1280 instances per tile of the image on average) and whose longest list
+        // is several times its mean list -- the limb of a shell seen from outside (C4: 792 per tile, 6 267 against a mean of
+        // 1 366 over the active tiles) -- walks eight entries per trip: its launch is stall-bound inside the waves of its long
+        // tiles (0.240 -> 0.222 ms).  A full frame is bound by instruction issue and keeps four, uniform (C3: 0.203 -> 0.243 with
+        // eight) or clustered (the skew scene, 2 670 per tile: 0.186 -> 0.218).  Same bits either way.
+        bool long_lists = false;
+        if (R > 0 && g_fwd_unroll8.load() != 0) {
+            uint32_t active = 0;
+            for (int k = 0; k < FRG_SORT_CLASSES; k++) active += c.class_count[k];
+            long_lists = g_fwd_unroll8.load() == 2 ||
+                         ((double)max_tile >= 3.5 * (double)R / (double)(active ? active : 1u) && (double)R < 1280.0 * (double)T);
+        }
         if (exact)
-            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream, md.fwd_only != 0, fused_small), "blend");
+            FRG_STAGE(frg::launch_blend_fwd_exact(vp, g, img, b, background, out_color, stream, md.fwd_only != 0, fused_small, long_lists), "blend");
         else
-            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream, md.fwd_only != 0, fused_small), "blend");
+            FRG_STAGE(frg::launch_blend_fwd_fast(vp, g, img, b, background, out_color, stream, md.fwd_only != 0, fused_small, long_lists), "blend");
     }
     return R;
 }

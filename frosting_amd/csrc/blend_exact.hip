@@ -5,9 +5,9 @@
 #include "kernels.h"
 namespace frg {
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, float* out_color, hipStream_t s, bool forward_only, bool fused_sort)
+                                  const float* bg, float* out_color, hipStream_t s, bool forward_only, bool fused_sort, bool long_lists)
 {
-    return launch_blend_fwd_t<true>(vp, g, img, b, bg, out_color, g_fwd_prefetch != 0, s, forward_only, fused_sort);
+    return launch_blend_fwd_t<true>(vp, g, img, b, bg, out_color, g_fwd_prefetch != 0, s, forward_only, fused_sort, long_lists);
 }
 
 hipError_t launch_blend_bwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,

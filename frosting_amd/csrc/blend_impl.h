@@ -125,7 +125,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // the backward).  A frame of 100 k Gaussians (C2: 2 500 lists of 140 entries) is six launches of 5 - 30 us, each a chain of
 // dependent memory round trips: this takes one launch boundary and the point_list round trip out of it.
 #define FRG_FUSED_SORT_CAP 512
-template <bool EXACT, bool PREFETCH = false, bool FUSED = false>
+template <bool EXACT, bool PREFETCH = false, bool FUSED = false, int UNROLL = 4>
 __global__ void __launch_bounds__(BLEND_THREADS)
 blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                  uint32_t* point_list /* FUSED: written here for the short lists */, const float4* __restrict__ xydr,
@@ -264,19 +264,19 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             s_rgb[d] = col;
         }
         wave_lds_sync();
-#ifndef FRG_FWD_UNROLL
-#define FRG_FWD_UNROLL 4       // same box, C4 forward blend: 1 -> 0.256 ms, 2 -> 0.249, 4 -> 0.245; C3 and C2 unchanged (profiles/r05_ab_fwd_unroll.log)
-#endif
-#if FRG_FWD_UNROLL > 1
-        // FRG_FWD_UNROLL entries per trip: the falloff of an entry (quadratic form, v_exp, min) does not depend on the pixel's
+        // UNROLL entries per trip: the falloff of an entry (quadratic form, v_exp, min) does not depend on the pixel's
         // state -- only T (1 - alpha), the stop test and the colour update do -- so the alphas of a group are computed side by
         // side and the sequential part of a pixel's chain shrinks to three dependent operations per entry.  Same operations on
-        // the same values in the same order: every output bit-identical.  A frame of few, long lists (C4's limb: 4 500 entries
-        // walked by ONE wave per quadrant while the GPU has run dry) is bound by that chain's latency.
-        for (int j = 0; j < nkeep; j += FRG_FWD_UNROLL) {
-            float al[FRG_FWD_UNROLL], pw[FRG_FWD_UNROLL], cw[FRG_FWD_UNROLL];
+        // the same values in the same order: every output bit-identical whatever UNROLL.  4 by default (same box, C4 forward
+        // blend: 1 -> 0.256 ms, 2 -> 0.249, 4 -> 0.245; C3 and C2 unchanged: profiles/r05_ab_fwd_unroll.log); 8 (r06) for frames
+        // whose work sits in a few long lists -- C4's limb: the launch is stall-bound inside every wave at < 5 waves per SIMD,
+        // 0.240 -> 0.222 ms -- and NOT for C3, whose walk is bound by instruction issue (0.203 -> 0.243 ms: the slots behind a
+        // round's last entry are executed as no-ops, and the registers cost occupancy): the launcher chooses per frame
+        // (profiles/r06_ab_fwd_unroll8.log).
+        for (int j = 0; j < nkeep; j += UNROLL) {
+            float al[UNROLL], pw[UNROLL], cw[UNROLL];
 #pragma unroll
-            for (int u = 0; u < FRG_FWD_UNROLL; u++) {
+            for (int u = 0; u < UNROLL; u++) {
                 const bool there = j + u < nkeep;            // wave-uniform; a slot beyond the round's entries is a no-op (alpha 0)
                 const float4 ga = s_a[min(j + u, 63)];
                 const float4 gco = s_co[min(j + u, 63)];
@@ -287,7 +287,7 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
                 cw[u] = ga.w;
             }
 #pragma unroll
-            for (int u = 0; u < FRG_FWD_UNROLL; u++) {
+            for (int u = 0; u < UNROLL; u++) {
                 const float alpha = al[u];
                 const bool keep_px = !(pw[u] > 0.0f) & !(alpha * alive < 1.0f / 255.0f);
                 const float test_T = M::attenuate(Tr, alpha);
@@ -302,28 +302,6 @@ blend_fwd_kernel(int T, int gx, int W, int H, const uint2* __restrict__ ranges,
             }
             if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
         }
-#else
-        for (int j = 0; j < nkeep; j++) {
-            const float4 ga = s_a[j];
-            const float4 gco = s_co[j];
-            float dx, dy;
-            const float power = M::power(ga.x, ga.y, gco, pxf, pyf, dx, dy);
-            // ONE divergence level for the reference's three tests (forward.cu:335-351): a wave almost
-            // never has all 64 pixels fail the same test, so nested branches skipped nothing
-            const float alpha = fminf(0.99f, gco.w * M::expo(power));
-            const bool keep_px = !(power > 0.0f) & !(alpha * alive < 1.0f / 255.0f);
-            const float test_T = M::attenuate(Tr, alpha);
-            const bool stop = keep_px & (test_T < 0.0001f);
-            alive = stop ? 0.0f : alive;
-            if (keep_px & !stop) {
-                const float4 gc = s_rgb[j];
-                M::accumulate(gc, alpha, Tr, C0, C1, C2);
-                Tr = test_T;
-                last = __float_as_uint(ga.w);
-            }
-            if (wave_ballot(alive != 0.0f) == 0ull) break;   // wave-uniform
-        }
-#endif
     }
     }
 
@@ -789,17 +767,19 @@ extern int g_fwd_order;       // tuning (frg_set_option("fwd_order")): 1 = forwa
 template <bool EXACT>
 static hipError_t launch_blend_fwd_t(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
                                      const float* bg, float* out_color, bool prefetch, hipStream_t s, bool forward_only = false,
-                                     bool fused_sort = false)
+                                     bool fused_sort = false, bool long_lists = false)
 {
     const int T = vp.gx * vp.gy;
-#define FRG_FWD(PF, FS)                                                                                                    \
-    hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF, FS>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
+#define FRG_FWD(PF, FS, UN)                                                                                                \
+    hipLaunchKernelGGL((blend_fwd_kernel<EXACT, PF, FS, UN>), dim3(xcd_grid_blocks(T)), dim3(BLEND_THREADS), 0, s, T, vp.gx, vp.W, vp.H, \
                        img.ranges, b.point_list, g.xydr, g.conic_opacity, g.rgb_clamped, bg, img.final_T, img.n_contrib,   \
                        out_color, img.tile_work, forward_only ? nullptr : b.ckpt, img.final_C, g_fwd_order ? img.class_tiles : nullptr,             \
                        img.counters->class_count, b.seg_log, img.bwd_cnt, img.bwd_last, img.bwd_cap_b, b.bwd_full,         \
                        (uint32_t)BinningState::full_cap(b.carved_R), img.cutoff, img.counters, b.pairs)
-    if (fused_sort) { if (prefetch) FRG_FWD(true, true); else FRG_FWD(false, true); }
-    else if (prefetch) FRG_FWD(true, false); else FRG_FWD(false, false);
+    // long_lists (the host's reading of the frame's counters): the work sits in a few long lists -> eight entries per trip
+    if (fused_sort) { if (prefetch) FRG_FWD(true, true, 4); else FRG_FWD(false, true, 4); }
+    else if (long_lists && prefetch) FRG_FWD(true, false, 8);
+    else if (prefetch) FRG_FWD(true, false, 4); else FRG_FWD(false, false, 4);
 #undef FRG_FWD
     return hipGetLastError();
 }

@@ -45,10 +45,11 @@ hipError_t launch_tile_sort(int T, const uint32_t* class_count, const uint32_t* 
 
 // forward_only: no backward will follow (frg_forward_args::forward_only) -- no checkpoints, no final colours, no work items
 // fused_sort: the lists of at most 512 entries are sorted by the blend's own workgroups (launch_tile_sort was told skip_small)
+// long_lists: the frame's work sits in a few long lists (the host's reading of the counters): eight list entries per trip instead of four
 hipError_t launch_blend_fwd_exact(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                  const float* bg, float* out_color, hipStream_t s, bool forward_only = false, bool fused_sort = false);
+                                  const float* bg, float* out_color, hipStream_t s, bool forward_only = false, bool fused_sort = false, bool long_lists = false);
 hipError_t launch_blend_fwd_fast(const ViewParams& vp, const GeomState& g, const ImageState& img, const BinningState& b,
-                                 const float* bg, float* out_color, hipStream_t s, bool forward_only = false, bool fused_sort = false);
+                                 const float* bg, float* out_color, hipStream_t s, bool forward_only = false, bool fused_sort = false, bool long_lists = false);
 // batch: instances reduced together per step of the backward blend (2 or 3; tuning knob, same results up to rounding order)
 // R: the instance count the caller sized the slots for (bounds the number of work items: the grid)
 // as_stamped: the host launches BOTH arithmetics and each kernel leaves at once unless the forward's stamp (Counters::fwd_flags)

@@ -45,6 +45,8 @@ def _reset_options():
     _lib.set_option("bwd_waves", 0)
     _lib.set_option("bwd_seg_log", 0)
     _lib.set_option("fwd_order", 1)
+    _lib.set_option("fwd_unroll8", 1)
+    _lib.set_option("fused_small", 1)
     _lib.set_option("counter_mailbox", 1)
     _lib.set_option("sparse_sh", 1)
     _lib.set_option("sh_dir_in_backward", 0)
@@ -1223,6 +1225,38 @@ def test_forward_tile_order_changes_nothing(gpu_device):
         if label == "corner":
             assert int((res[1][4] > 0).sum()) > 0
 
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_forward_blend_entries_per_trip_change_nothing(gpu_device, exact):
+    """Option fwd_unroll8 (0 never | 1 the host's rule: frames whose longest list is 3.5 x their mean list | 2 always): the
+    forward blend computes the falloff of four or of eight list entries side by side before the sequential part of the
+    pixels' chains -- the same operations on the same values in the same order: image, per-pixel bookkeeping and the gradients
+    of the backward that starts from its checkpoints are the same bits, in both arithmetics, on a full frame, a frame with most
+    tiles empty (long lists in a corner: the rule's case) and a ragged image."""
+    scene, cam, bg = scenes.config_scene("c2", 6, P=70_000)
+    corner = scenes.Scene(scene.means3D * 0.1 + torch.tensor([0.8, -0.7, 0.0]), scene.scales, scene.rotations, scene.opacities,
+                          scene.shs, scene.sh_degree)
+    ragged = scenes.ring_camera(2, 333, 201, 300.0, 300.0)
+    _lib.set_option("exact_blend", exact)
+    _lib.set_option("fused_small", 0)                  # (the small-frame form walks four entries per trip)
+    for label, sc, cm in (("full", scene, cam), ("corner", corner, cam), ("ragged", scene, ragged)):
+        res = {}
+        for mode in (0, 2, 1):
+            _lib.set_option("fwd_unroll8", mode)
+            out, args = Hh.run_ours_native(sc, cm, bg, gpu_device)
+            st = State(sc.P, cm.image_width, cm.image_height, out[0], out[3], out[4], out[5])
+            gpix, _ = scenes.l1_target_grad(out[1].cpu(), 23)
+            grads = _C.rasterize_gaussians_backward(*_bwd_args(args, out, gpix.to(gpu_device)))
+            res[mode] = (out[0], out[1].clone(), out[2].clone(), st.final_T.clone(), st.n_contrib.clone(), [g.clone() for g in grads])
+            del st
+        for other in (2, 1):
+            a, b = res[0], res[other]
+            assert a[0] == b[0] and all(torch.equal(x, y) for x, y in zip(a[1:5], b[1:5])), (label, other)
+            assert all(torch.equal(x, y) for x, y in zip(a[5], b[5])), (label, other)
+    _lib.set_option("fwd_unroll8", 1)
+    _lib.set_option("fused_small", 1)
+    _lib.set_option("exact_blend", 0)
 
 
 def test_a_backward_finds_its_forwards_modes_in_the_buffers_and_in_the_ctx(gpu_device, ops):
