@@ -551,7 +551,7 @@ def _hip_sum_combiner(ex: "SlotSumExchange", chunk: int, packets: torch.Tensor, 
                          opacities=None if raw else v(pr["opacities"]), raw_opacities=v(pr["opacities"]) if raw else None,
                          raw_scales=v(pr["scales"]) if raw else None, raw_rotations=v(pr["rotations"]) if raw else None,
                          dL_dmean3D=v(g["means3D"]), dL_dscale=v(g["scales"]), dL_drot=v(g["rotations"]), dL_dopacity=v(g["opacities"]),
-                         dL_dsh=v(g["shs"]), status=v(ex.status[chunk]), status_seq=int(seq), row_live=None,
+                         dL_dsh=v(g["shs"]), status=v(ex.status[chunk]), status_seq=int(seq), row_live=v(getattr(ex, "row_live", None)),
                          workspace=v(ex.combine_work), workspace_bytes=ex.combine_work.numel(), hip_stream=torch.cuda.current_stream(packets.device).cuda_stream)
     rc = _lib.lib().frg_backward_combine(C.byref(a))
     if rc < 0:
@@ -606,6 +606,9 @@ class SlotSumExchange(GradientExchange):
         self.params = None
         self.stats = {"rows_wanted_max": 0, "rows_per_view_max": 0, "repacks": 0, "packet_bytes": 0}
         self._no_post = False
+        # optional uint8 [P]: the combine pass then marks the Gaussians that have a row in some view and does NOT write the rows of the
+        # others (frg_combine_args::row_live) -- for a consumer that takes an unmarked row as zero (FlatAdam.step(row_live=...))
+        self.row_live = None
         self.combine_work = None      # the combine pass's scratch (256 bytes since the pass is one kernel; the ABI keeps the argument)
 
     def set_params(self, params: dict):

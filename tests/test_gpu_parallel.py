@@ -126,6 +126,35 @@ def test_slot_sum_combine_is_the_accumulation_of_the_view_gradients_bit_for_bit(
         assert torch.equal(ex.views[n], acc[n]), n
 
 
+@pytest.mark.parametrize("views,chunks", [([0, 1, 2, 3, 4, 5, 6, 7], 2), ([3], 1)])
+def test_slot_sum_combine_with_row_live_writes_only_the_rows_with_a_gradient(gpu_device, views, chunks):
+    """frg_combine_args::row_live: the combine pass marks the Gaussians that have a row in some view and leaves the rows of the
+    others UNWRITTEN (what frg_backward_args::row_live does for one view); the marked rows are the accumulation's, bit for bit."""
+    dev = gpu_device
+    P = 150_000
+    scene, _, _ = scenes.config_scene("c3", 0, P=P)             # the large image: most Gaussians are reached by no pixel of a view
+    vpr = ViewParallelRasterizer(scene.to(dev), dev, slotsum=True, chunks=chunks)
+    ex = vpr.exchange
+    acc = _slot_sum_views(vpr, "c3", views, dev, P)
+    ex.row_live = torch.full((P,), 7, dtype=torch.uint8, device=dev)
+    for t in ex.views.values():
+        t.fill_(123.0)
+    verdicts = ex.combine_local(len(views))
+    torch.cuda.synchronize(dev)
+    assert not any(o for o, _ in verdicts)
+    live = ex.row_live.bool()
+    assert set(ex.row_live.unique().tolist()) <= {0, 1} and 0 < int(live.sum()) < P
+    has_grad = torch.zeros(P, dtype=torch.bool, device=dev)
+    for n in PARAM_ORDER:
+        has_grad |= (acc[n].reshape(P, -1) != 0).any(1)
+    assert bool((has_grad <= live).all())                       # every Gaussian with a gradient is marked (a marked one may sum to zero)
+    for n in PARAM_ORDER:
+        got, want = ex.views[n].reshape(P, -1), acc[n].reshape(P, -1)
+        assert torch.equal(got[live], want[live]), n
+        assert bool((got[~live] == 123.0).all()), n             # untouched
+    ex.row_live = None
+
+
 def test_slot_sum_packets_report_an_overflow_and_fit_after_it(gpu_device):
     """A packet is all-gathered at a fixed capacity; a view that wants more rows says so in its header, the combine pass posts
     the verdict (pinned host memory), and the chunk is packed again with room for it: the sums are still in the workspace."""
