@@ -91,7 +91,7 @@ XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task sta
 # (tools/combine_bench.py: profiles/r06_combine_bench.log): pack = mask scan + rows; combine_ms[N] = frg_backward_combine over
 # N views' packets in one chunk; per_chunk_ms = what every further chunk adds (launch + tail); phase2_ms = one-call backward -
 # phase 1.  overlap_slowdown and slack are assumptions / settings, not measurements.
-SLOTSUM_LOCAL_MS = {"pack_ms": 0.036, "pack_per_chunk_ms": 0.005, "combine_ms": {1: 0.172, 2: 0.190, 4: 0.210, 8: 0.293},
+SLOTSUM_LOCAL_MS = {"pack_ms": 0.036, "pack_per_chunk_ms": 0.005, "combine_ms": {1: 0.168, 2: 0.189, 4: 0.215, 8: 0.293},
                     "per_chunk_ms": 0.011, "phase2_ms": 0.115, "overlap_slowdown": 1.15, "slack": 1.125}
 
 
