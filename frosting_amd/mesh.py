@@ -168,3 +168,29 @@ def occlusion_mask(point_cell_indices, face_idx_to_render, n_faces, n_background
     if n_background:
         keep = torch.cat([keep, torch.ones(n_background, dtype=torch.bool, device=keep.device)])
     return keep
+
+
+def depth_keep_mask(means3D, viewmatrix, projmatrix, depth, tolerance):
+    """Per-Gaussian keep mask of Frosting's OTHER culling variant -- against a depth map instead of the set of visible faces
+    (frosting_scene/frosting_model.py:70-135 get_points_depth_in_depthmaps, :1547-1562): a Gaussian survives iff it projects
+    inside the image AND (its view-space depth is in front of the depth map's value at its projection + tolerance, OR the
+    map holds no depth there: map_z <= 0).  The map is sampled as the reference samples it -- torch.nn.functional.grid_sample,
+    bilinear, zeros outside, align_corners=False -- at the Gaussian's centre.
+
+    means3D [P,3]; viewmatrix, projmatrix: the rasterizer's row-vector matrices (world -> view, world -> clip; the camera the
+    depth map was rendered with -- e.g. fragments(...).zbuf of this module's triangle raster, 0 where no triangle covers the
+    pixel); depth [H,W]; tolerance: absolute, in view-space units (the reference passes filtering_tolerance x the scene's
+    spatial extent).  Returns bool [P].  Plain torch on whatever device the tensors live on: this variant is host-side glue
+    in the reference too (non-default: refine.py:45).  The reference reaches the same quantities through pytorch3d cameras
+    (their NDC has +x left / +y up and is rescaled by -min(H, W) / W | H before grid_sample: frosting_model.py:107-111), which
+    this image does not have: the function follows the reference's formulas, its parity against the reference is UNPINNED."""
+    m = means3D.detach().to(torch.float32)
+    ones = torch.ones((m.shape[0], 1), dtype=m.dtype, device=m.device)
+    hom = torch.cat([m, ones], 1)
+    real_z = (hom @ viewmatrix.to(m))[:, 2]
+    clip = hom @ projmatrix.to(m)
+    ndc = clip[:, :2] / (clip[:, 3:4] + 1e-7)                    # x right, y down, [-1, 1] across the image: grid_sample's convention
+    inside = ~((ndc.min(-1)[0] < -1) | (ndc.max(-1)[0] > 1))
+    map_z = torch.nn.functional.grid_sample(depth.to(m)[None, None], ndc.view(1, -1, 1, 2), mode="bilinear", padding_mode="zeros",
+                                            align_corners=False)[0, 0, :, 0]
+    return ((real_z < map_z + float(tolerance)) | (map_z <= 0.0)) & inside

@@ -67,3 +67,45 @@ def test_contract_of_the_output_planes():
     assert ids[-2:, :].any() and ids[:, :].any() and cov[1].sum() > cov[-2].sum()
     area = MO.projected_area_px(pos, tri, 32, 32)
     assert abs(area[0] - 0.5 * 32 * 32) < 1e-6
+
+
+def test_depth_keep_mask_semantics():
+    """frosting_amd.mesh.depth_keep_mask, the 'depth' culling variant (frosting_model.py:1547-1562): in front of the map (plus a
+    tolerance), or no depth there, and inside the image; the map sampled bilinearly at the projected centre with zeros outside
+    (a literal four-tap restatement for interior points)."""
+    import math
+    import torch
+    from frosting_amd import mesh as M, scenes
+    cam = scenes.ring_camera(0, 64, 48, 60.0, 60.0)
+    H, W = 48, 64
+    depth = torch.zeros(H, W)
+    depth[:, : W // 2] = 5.0                                   # a wall at view depth 5 over the left half, nothing on the right
+    depth[10:20, 5:15] = 3.0
+    g = torch.Generator().manual_seed(5)
+    # points in VIEW space, then to world with the inverse of the (row-vector) view matrix
+    zs = torch.rand(400, generator=g) * 8 + 1
+    xs = (torch.rand(400, generator=g) * 2.3 - 1.15) * zs * (W / 2) / 60.0
+    ys = (torch.rand(400, generator=g) * 2.3 - 1.15) * zs * (H / 2) / 60.0
+    pv = torch.stack([xs, ys, zs, torch.ones(400)], 1)
+    world = (pv @ torch.linalg.inv(cam.viewmatrix))[:, :3].contiguous()
+    tol = 0.25
+    keep = M.depth_keep_mask(world, cam.viewmatrix, cam.projmatrix, depth, tol)
+    hom = torch.cat([world, torch.ones(400, 1)], 1) @ cam.projmatrix
+    ndc = hom[:, :2] / hom[:, 3:4]
+    n_in = n_out = n_cut = 0
+    for i in range(400):
+        x, y = float(ndc[i, 0]), float(ndc[i, 1])
+        if abs(x) > 1 or abs(y) > 1:
+            assert not bool(keep[i]); n_out += 1
+            continue
+        px, py = ((x + 1) * W - 1) / 2, ((y + 1) * H - 1) / 2       # ndc2Pix: the pixel-centre convention of align_corners=False
+        x0, y0 = math.floor(px), math.floor(py)
+        tap = lambda yy, xx: float(depth[yy, xx]) if 0 <= yy < H and 0 <= xx < W else 0.0
+        fx, fy = px - x0, py - y0
+        mz = (tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx) * (1 - fy) + (tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx) * fy
+        want = (float(zs[i]) < mz + tol) or mz <= 0.0
+        if abs(float(zs[i]) - (mz + tol)) > 1e-3 and abs(mz) > 1e-6:   # away from the decision boundaries (float32 sampling)
+            assert bool(keep[i]) == want, (i, float(zs[i]), mz)
+            n_in += 1
+            n_cut += int(not want)
+    assert n_out > 20 and n_in > 150 and n_cut > 30
