@@ -98,7 +98,7 @@ SLOTSUM_LOCAL_MS = {"pack_ms": 0.036, "pack_per_chunk_ms": 0.005, "combine_ms": 
 def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "factored", reduce: str = "allreduce",
                      schedule: str = "in-step", link_efficiency: float = 0.8, rebuild_ms_per_view: float = 0.019,
                      split_overhead_ms: float = 0.08, per_gaussian_bwd_ms: float = 0.29, bus_GBps: float = None,
-                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0, adam_ms: float = 0.8, chunks: int = 4,
+                     rows_fraction: float = 0.124, hbm_GBps: float = 5300.0, adam_ms: float = 0.8, chunks: int = 2,
                      slotsum_local: dict = None):
     """Predicted step time and scaling of the view-parallel step on ONE node of `world` MI355X: arithmetic, not a
     measurement (no 8-GPU run is available to this repository; bench.py prints it as `predicted`).

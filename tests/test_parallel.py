@@ -595,7 +595,7 @@ def test_bench_self_launch_at_world_8_dry_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["dry_run"] is True and d["all_ranks_agree"] is True
     assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["exchange"] == "slotsum"
-    assert d["config"]["chunks"] == 4 and d["config"]["repacks"] == 0
+    assert d["config"]["chunks"] == 2 and d["config"]["repacks"] == 0
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
 
 

@@ -48,7 +48,7 @@ train)
   timeout 600 python tools/train_step.py > $O/train_step.log 2>&1; tail -6 $O/train_step.log ;;
 exchange)
   : > $O/exchange_1rank.log
-  IFS='|' read -ra EMODES <<< "${EXCHANGE_MODES:---exchange slotsum|--exchange slotsum --chunks 1|--exchange slotsum --chunks 4|--exchange factored|--exchange factored --sync-exchange|--exchange factored --reduce direct|--exchange allreduce|--exchange sparse}"
+  IFS='|' read -ra EMODES <<< "${EXCHANGE_MODES:---exchange slotsum|--exchange slotsum --chunks 1|--exchange slotsum --chunks 2|--exchange slotsum --chunks 4|--exchange factored|--exchange factored --sync-exchange|--exchange factored --reduce direct|--exchange allreduce|--exchange sparse}"
   for mode in "${EMODES[@]}"; do
     echo "== bench.py --force-exchange $mode" >> $O/exchange_1rank.log
     timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --force-exchange $mode 2>&1 | grep -v "^Librccl\|^RCCL\|^HIP\|^ROCm\|^Hostname\|amdgpu.ids" | tail -2 >> $O/exchange_1rank.log
