@@ -416,8 +416,8 @@ def _slotsum_worker(rank, world, port, P, K, steps, chunks, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2)])
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2), (8, 2)])
 def test_slot_sum_exchange_then_adam_equals_single_process_accumulation_gloo(world, chunks):
     """SlotSumExchange on N ranks -- pack the view's rows at the capacity the previous step's views called for, all-gather the
     packets chunk by chunk, run the chain for every view's rows in view order -- with Adam between the views equals the
@@ -431,7 +431,7 @@ def test_slot_sum_exchange_then_adam_equals_single_process_accumulation_gloo(wor
     procs = [ctx.Process(target=_slotsum_worker, args=(r, world, port, P, K, steps, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
+    got = [q.get(timeout=200) for _ in range(world)]
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
