@@ -88,8 +88,8 @@ def parse_args():
                          "the first multi-rank run of a build should execute as few never-executed collectives as possible)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="slotsum: index ranges of Gaussians with a packet and a collective each -- the combine pass of one range "
-                         "runs while the next range's packets travel.  2: single-rank exposed cost 0.146 ms and 6.03 x at 8 GPUs / 450 GB/s "
-                         "by the arithmetic; 4: 0.175 ms and 6.2 x (more overlap, more launches and collectives per step)")
+                         "runs while the next range's packets travel.  2: single-rank exposed cost 0.146 - 0.16 ms and 6.06 x at 8 GPUs / "
+                         "450 GB/s by the arithmetic; 4: 0.165 - 0.18 ms and 6.17 x (more overlap, more launches and collectives per step)")
     ap.add_argument("--phase1-in-pieces", action="store_true",
                     help="slotsum with several chunks: the backward's phase 1 chunk by chunk, every chunk's packet leaving as soon as its "
                          "sums exist (frg_backward_args::range_first / range_count) instead of one phase-1 call followed by all the packets")

@@ -90,9 +90,10 @@ XGMI_LINK_GBPS = 153.0         # per link and direction (the figure the task sta
 # The slot-sum plan's local terms at C3 (3 M Gaussians, 0.127 P rows per view), measured on ONE MI355X with HIP events
 # (tools/combine_bench.py: profiles/r06_combine_bench.log): pack = mask scan + rows; combine_ms[N] = frg_backward_combine over
 # N views' packets in one chunk; per_chunk_ms = what every further chunk adds (launch + tail); phase2_ms = one-call backward -
-# phase 1.  overlap_slowdown and slack are assumptions / settings, not measurements.
+# phase 1.  overlap_slowdown: the combine pass beside a stand-in for a collective's kernel (a copy kernel of 8 .. 64 workgroups on a
+# side stream: 1.21 .. 1.34 x, profiles/r06_combine_beside_a_copy.log) -- a proxy, RCCL's own kernels were never beside it; slack: a setting.
 SLOTSUM_LOCAL_MS = {"pack_ms": 0.036, "pack_per_chunk_ms": 0.005, "combine_ms": {1: 0.168, 2: 0.189, 4: 0.215, 8: 0.293},
-                    "per_chunk_ms": 0.011, "phase2_ms": 0.115, "overlap_slowdown": 1.15, "slack": 1.125}
+                    "per_chunk_ms": 0.011, "phase2_ms": 0.115, "overlap_slowdown": 1.3, "slack": 1.125}
 
 
 def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "factored", reduce: str = "allreduce",
@@ -125,10 +126,9 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
     MI355X (slotsum_local, defaults = SLOTSUM_LOCAL_MS: tools/combine_bench.py, profiles/r06_combine_bench.log): pack_ms, the
     combine pass over `world` views' packets (combine_ms[world], total over the chunks), and phase2_ms = what the per-view
     backward no longer does (the per-Gaussian chain and the dense rows of ONE view: one-call backward - phase 1).  The chunks
-    pipeline: chunk k's combine pass runs while chunk k + 1 is on the wire, so gather + combine complete after
-    W + c (c = one chunk's pass, when c <= w = one chunk's wire time) or w + C (combine-bound); the pass is priced
-    overlap_slowdown x its stand-alone time while collectives run beside it (RCCL's kernels hold some CUs: an assumption,
-    1.15).  exposed = pack + that - phase2.
+    pipeline: chunk k's combine pass runs while chunk k + 1 is on the wire (simulated chunk by chunk); a pass is priced
+    overlap_slowdown x its stand-alone time for as long as a later chunk is still travelling (measured with a stand-in copy
+    kernel beside it: x 1.3), its stand-alone time afterwards.  exposed = pack + that - phase2.
     link_efficiency: achieved / nominal link rate.  Returns a dict."""
     rate = XGMI_LINK_GBPS * 1e9 * link_efficiency
     links = max(1, min(world - 1, XGMI_LINKS))
@@ -168,13 +168,26 @@ def predict_exchange(P: int, K: int, world: int, render_ms: float, plan: str = "
         ks = sorted(table)
         lo_k = max([k for k in ks if k <= world] or ks[:1]); hi_k = min([k for k in ks if k >= world] or ks[-1:])
         c_all = table[lo_k] if hi_k == lo_k else table[lo_k] + (table[hi_k] - table[lo_k]) * (world - lo_k) / (hi_k - lo_k)
-        c_all = (c_all + loc["per_chunk_ms"] * (K - 1)) * loc["overlap_slowdown"]
+        c_all = c_all + loc["per_chunk_ms"] * (K - 1)
+        # the two-stage pipeline, chunk by chunk: gather k ends at (k + 1) w; pass k starts when its packets are there and pass
+        # k - 1 is done, and takes c -- x overlap_slowdown while a later chunk is still on the wire (a second queue's kernel
+        # beside it: measured with a stand-in copy kernel, profiles/r06_combine_beside_a_copy.log), c alone for what remains
         w1, c1 = wire / K, c_all / K
-        done = wire + c1 if c1 <= w1 else w1 + c_all
+        t, slowed = 0.0, 0.0
+        for k in range(K):
+            start = max(t, (k + 1) * w1)
+            left, now = c1, start
+            if now < wire:                                     # some of this pass runs beside the remaining gathers
+                beside = min(left * loc["overlap_slowdown"], wire - now)
+                left -= beside / loc["overlap_slowdown"]
+                now += beside
+                slowed += beside
+            t = now + left
+        done = t
         pack = loc["pack_ms"] + loc["pack_per_chunk_ms"] * (K - 1)
         slot = {"chunks": K, "capacity_rows": cap, "packet_MB": packet_bytes / 1e6, "wire_ms": wire, "combine_ms": c_all, "pack_ms": pack,
-                "phase2_saved_ms": loc["phase2_ms"], "gather_and_combine_ms": done, "bound": "wire" if c1 <= w1 else "combine",
-                "local_terms": loc}
+                "phase2_saved_ms": loc["phase2_ms"], "gather_and_combine_ms": done, "combine_ms_beside_the_wire": slowed,
+                "bound": "wire" if done - wire <= c1 * 1.0001 else "combine", "local_terms": loc}
         dense_ms = gather_ms = rebuild_ms = 0.0
         dense_bytes = 0
     if world == 1:

@@ -550,8 +550,9 @@ def test_predicted_exchange_budget_arithmetic():
 
 def test_predicted_slot_sum_plan_from_measured_local_terms():
     """The slot-sum plan in predict_exchange: the packets' bytes, the two-stage pipeline of gather and combine
-    pass over the chunks, local terms = the single-GPU measurements (SLOTSUM_LOCAL_MS: profiles/r06_combine_bench.log) -- and what
-    the arithmetic then says at 450 GB/s of bus bandwidth."""
+    pass over the chunks -- a pass priced x overlap_slowdown while a later chunk is still on the wire --, local terms = the
+    single-GPU measurements (SLOTSUM_LOCAL_MS: profiles/r06_combine_bench.log, r06_combine_beside_a_copy.log) -- and what the
+    arithmetic then says at 450 GB/s of bus bandwidth."""
     from frosting_amd.parallel import SLOTSUM_LOCAL_MS, predict_exchange, sum_packet_words
     P, render = 3_000_000, 1.35
     loc = SLOTSUM_LOCAL_MS
@@ -562,16 +563,27 @@ def test_predicted_slot_sum_plan_from_measured_local_terms():
             cap = (int(0.1267 * P * loc["slack"]) // 256 + 1) * 256
             assert s["capacity_rows"] == cap and abs(s["packet_MB"] * 1e6 - (4.0 * sum_packet_words(P, cap) + 256.0 * (K - 1))) < 1.0
             assert abs(s["wire_ms"] - 7 * s["packet_MB"] * 1e6 / (bw * 1e9) * 1e3) < 1e-9
-            c_all = (loc["combine_ms"][8] + loc["per_chunk_ms"] * (K - 1)) * loc["overlap_slowdown"]
+            c_all = loc["combine_ms"][8] + loc["per_chunk_ms"] * (K - 1)
             assert abs(s["combine_ms"] - c_all) < 1e-12
-            done = s["wire_ms"] + c_all / K if c_all <= s["wire_ms"] else s["wire_ms"] / K + c_all
-            assert abs(s["gather_and_combine_ms"] - done) < 1e-12
-            assert abs(r["exposed_ms"] - (s["pack_ms"] + done - loc["phase2_ms"])) < 1e-12
+            # the pipeline, restated: gather k ends at (k + 1) W / K; pass k starts when its packets are there and pass k - 1 is done
+            w1, c1, t = s["wire_ms"] / K, c_all / K, 0.0
+            for k in range(K):
+                now, left = max(t, (k + 1) * w1), c1
+                if now < s["wire_ms"]:
+                    beside = min(left * loc["overlap_slowdown"], s["wire_ms"] - now)
+                    left -= beside / loc["overlap_slowdown"]
+                    now += beside
+                t = now + left
+            assert abs(s["gather_and_combine_ms"] - t) < 1e-12
+            if K == 1:
+                assert abs(t - (s["wire_ms"] + c_all)) < 1e-12          # one chunk: nothing overlaps, nothing is slowed
+            assert s["wire_ms"] + c1 - 1e-12 <= t <= s["wire_ms"] + c_all * loc["overlap_slowdown"] + 1e-12
+            assert abs(r["exposed_ms"] - (s["pack_ms"] + t - loc["phase2_ms"])) < 1e-12
             assert r["dense_MB"] == 0.0
     at = lambda bw, K: predict_exchange(P, 16, 8, render, "slotsum", "allgather", "in-step", bus_GBps=bw, rows_fraction=0.1267, chunks=K)["scaling_vs_1gpu"]
     assert at(450.0, 4) >= 6.0 and at(450.0, 2) >= 6.0 > at(450.0, 1)        # the chunks' overlap is what carries it past 6 x
-    assert at(450.0, 4) > predict_exchange(P, 16, 8, render, "factored", "direct", "in-step", bus_GBps=450.0)["scaling_vs_1gpu"]
-    assert at(1071.0, 4) >= 6.0 > at(300.0, 4)                               # 300 GB/s: wire-bound, below the target
+    assert at(450.0, 2) > predict_exchange(P, 16, 8, render, "factored", "direct", "in-step", bus_GBps=450.0)["scaling_vs_1gpu"]
+    assert at(1071.0, 2) >= 6.0 > at(300.0, 4)                               # 300 GB/s: wire-bound, below the target
     for n in (2, 4, 8):
         assert 0 < predict_exchange(P, 16, n, render, "slotsum", "allgather", "in-step", bus_GBps=450.0, rows_fraction=0.1267)["scaling_vs_1gpu"] < n
 

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--option", action="append", default=[], help="name=value for frg_set_option")
+    ap.add_argument("--side-copy", type=int, default=0,
+                    help="workgroups of a copy kernel (tools/micro/side_copy.hip) that streams 7 packets' worth of bytes on a side stream "
+                         "WHILE the combine pass runs: a stand-in for incoming all-gather traffic -- reports the pass's time beside it")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     from frosting_amd import _lib
@@ -80,12 +83,38 @@ def main():
         torch.cuda.synchronize(dev)
         t_cmb.append(e0.elapsed_time(e1))
     med = statistics.median
+    side = None
+    if a.side_copy > 0:
+        import ctypes as C
+        lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libside_copy.so"))
+        lib.side_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        nbytes = 7 * 4 * ex.wire_floats_per_rank // 16 * 16
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        s2 = torch.cuda.Stream(dev)
+        t_alone, t_cmb2, t_copy = [], [], []
+        for rep in range(a.iters):                     # the copy alone (its rate), then the combine pass beside it
+            c0, c1 = ev(), ev()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(s2):
+                c0.record(s2); lib.side_copy(src.data_ptr(), dst.data_ptr(), nbytes, a.side_copy, 1, s2.cuda_stream); c1.record(s2)
+            torch.cuda.synchronize(dev)
+            t_alone.append(c0.elapsed_time(c1))
+            e0, e1, c0, c1 = ev(), ev(), ev(), ev()
+            with torch.cuda.stream(s2):
+                c0.record(s2); lib.side_copy(src.data_ptr(), dst.data_ptr(), nbytes, a.side_copy, 2, s2.cuda_stream); c1.record(s2)
+            e0.record(); ex.combine_local(a.views); e1.record()
+            torch.cuda.synchronize(dev)
+            t_cmb2.append(e0.elapsed_time(e1)); t_copy.append(c0.elapsed_time(c1))
+        side = {"workgroups": a.side_copy, "bytes": nbytes, "copy_alone_ms": med(t_alone), "copy_alone_GBps": nbytes / med(t_alone) / 1e6,
+                "combine_beside_copy_ms": med(t_cmb2), "copy_of_twice_the_bytes_beside_combine_ms": med(t_copy),
+                "combine_slowdown": med(t_cmb2) / med(t_cmb)}
     live = int(((acc["opacities"] != 0).reshape(P, -1).any(1) | (acc["means3D"] != 0).any(1)).sum())
     print(json.dumps({"config": a.config, "P": P, "views": a.views, "chunks": a.chunks, "rows_wanted_per_view": counts,
                       "rows_fraction": max(counts) / P, "gaussians_with_a_row_in_some_view": live, "capacity_rows": sum(ex.capacity),
                       "packet_bytes_per_view": 4 * ex.wire_floats_per_rank, "backward_one_call_ms": med(t_one), "backward_phase1_ms": med(t_p1),
                       "pack_ms": med(t_pack), "combine_ms": med(t_cmb), "combine_ms_all": [round(x, 4) for x in t_cmb],
-                      "combine_equals_accumulation_bit_for_bit": ok}))
+                      "combine_equals_accumulation_bit_for_bit": ok, "side_copy": side}))
 
 
 if __name__ == "__main__":
